@@ -1,0 +1,212 @@
+/*
+ * tb_stepper.h -- C ABI of the MI355X-native batched physics stepper for the
+ * SwingRacket-v0 / Tennisbot-v0 environments of youliangtan/tennisbot-rl.
+ *
+ * This is the drop-in boundary. The reference has no FFI of its
+ * own: its envs call the third-party `pybullet` C-API from Python. Each entry point
+ * below therefore cites the reference call sites (file:line under the reference root)
+ * whose work it replaces for a whole batch of N independent worlds.
+ *
+ * Conventions
+ *   - plain C types only; no torch / HIP types in any signature. `stream` is a
+ *     hipStream_t passed as void* (NULL = the default stream); every call is
+ *     asynchronous on that stream unless stated otherwise.
+ *   - all `*_dev` pointers are DEVICE pointers owned by the caller (for example
+ *     torch tensors' data_ptr()). Layouts are row-major: actions [N][A], obs [N][O].
+ *   - return value: 0 = OK, negative = TB_E_* below, positive = a hipError_t.
+ *     Nothing throws across this boundary. tb_last_error() gives a thread-local
+ *     message for the last non-zero return on the calling thread.
+ *   - a handle is bound to one device and is not re-entrant.
+ *   - there is NO CPU fallback in this library: without a usable HIP device
+ *     tb_create fails.
+ */
+#ifndef TB_STEPPER_H
+#define TB_STEPPER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TB_ABI_VERSION 1
+
+/* library error codes (negative); positive return values are hipError_t */
+#define TB_OK 0
+#define TB_E_INVAL (-1)    /* bad argument (null pointer, n_envs <= 0, unknown env kind, ...) */
+#define TB_E_NODEVICE (-2) /* no usable HIP device / device index out of range */
+#define TB_E_PARAMS (-3)   /* TbParams failed validation (n_hull, dt, masses, ...) */
+#define TB_E_UNSUPPORTED (-4)
+
+/* env kinds: tennisbot/__init__.py:3-11 registers exactly these two ids */
+#define TB_ENV_SWING 0  /* SwingRacket-v0 -> tennisbot/envs/swingracket_env.py */
+#define TB_ENV_TENNIS 1 /* Tennisbot-v0   -> tennisbot/envs/tennisbot_env.py   */
+
+#define TB_SWING_ACT_DIM 6  /* swingracket_env.py:29-31 */
+#define TB_SWING_OBS_DIM 6  /* swingracket_env.py:34-39,143-144 */
+#define TB_TENNIS_ACT_DIM 2 /* tennisbot_env.py:43-44 */
+#define TB_TENNIS_OBS_DIM 12 /* tennisbot_env.py:52-55,134-136 */
+
+/* persistent state, structure-of-arrays: 32-bit words [TB_*_WORDS][N] + one byte [N] */
+#define TB_SWING_WORDS 30
+#define TB_TENNIS_WORDS 27
+/* rows shared by both envs */
+#define TB_W_RP 0   /* racket COM position (3)  racket.py:131 returns the COM frame */
+#define TB_W_RQ 3   /* racket orientation quaternion x,y,z,w (4) */
+#define TB_W_RV 7   /* racket linear velocity (3)  racket.py:142 */
+#define TB_W_RW 10  /* racket angular velocity, world frame (3) */
+#define TB_W_BP 13  /* ball position (3)  objects.py:57 */
+#define TB_W_BV 16  /* ball linear velocity (3)  objects.py:64 */
+#define TB_W_BW 19  /* ball angular velocity (3) */
+/* SwingRacket-v0 rows */
+#define TB_W_SW_GOAL 22   /* goal x,y (2)             swingracket_env.py:173 */
+#define TB_W_SW_SPAWN 24  /* racket LINK spawn pos (3) swingracket_env.py:168 */
+#define TB_W_SW_D0 27     /* initial_dist_to_goal      swingracket_env.py:174-175 */
+#define TB_W_SW_STEP 28   /* step_count (int32)        swingracket_env.py:83,108 */
+#define TB_W_SW_EPISODE 29 /* episode index (uint32), keys the reset RNG */
+/* Tennisbot-v0 rows */
+#define TB_W_TN_SHOOT 22  /* ball_shoot_force (3)      tennisbot_env.py:237-241 */
+#define TB_W_TN_STEP 25   /* step_count (int32)        tennisbot_env.py:122 */
+#define TB_W_TN_EPISODE 26
+
+/* done byte: 0 running; 1 done, and (Swing) the restoring force issued at the end
+ * of the last fast-forward substep (swingracket_env.py:135-141) is still pending in
+ * the engine's force accumulator; 2 done, nothing pending. */
+#define TB_DONE_NO 0
+#define TB_DONE_PENDING_FORCE 1
+#define TB_DONE_YES 2
+
+/* TbParams.flags */
+#define TB_F_AUTO_RESET 0x1u          /* VecEnv semantics: a done env is reset inside the step */
+#define TB_F_NET 0x2u                 /* court.urdf:43-47 second collision box */
+#define TB_F_RACKET_BALL 0x4u         /* racket<->ball narrowphase + impulse; clear = BASELINE configs[1] "no ball contact" bench mode */
+#define TB_F_DEFAULT (TB_F_NET | TB_F_RACKET_BALL)
+
+#define TB_MAX_HULL 64
+#define TB_HULL_REC 8 /* floats per hull edge record */
+
+/*
+ * Scene + engine parameters. Every engine-semantics value recalled from Bullet
+ *  is a named field so a host that has pybullet can calibrate.
+ * All derived values (inverses, edge records) are computed once by the host side in
+ * float64, rounded to float32 and consumed as given by the kernels.
+ */
+typedef struct TbParams {
+  /* engine (Appendix B.1/B.2) */
+  float dt;                 /* 1/240, racket.py:24 */
+  float inv_dt;             /* 240 */
+  float gravity;            /* 9.81, swingracket_env.py:154 setGravity(0,0,-9.81) */
+  float lin_damp;           /* k1 = k2 = 0.04, force -m v (k1 + k2 |v|) */
+  float ang_damp;           /* 0.04 */
+  float max_ang_step;       /* pi/4 per substep rotation clamp */
+  float rest_vel_threshold; /* 0.2 m/s: below it restitution is 0 */
+  float erp;                /* 0.2 Baumgarte */
+  float contact_threshold;  /* 0.02 * ball radius: manifold keeps points closer than this */
+  int32_t solver_iters;     /* sequential-impulse iterations (Bullet default 50) */
+  uint32_t flags;           /* TB_F_* */
+  /* racket: racket.urdf:17-21, racket.py:43-45 */
+  float racket_mass, racket_inv_mass;
+  float racket_inertia[3], racket_inv_inertia[3]; /* body-frame diagonal */
+  float racket_com[3];       /* inertial origin in the link frame, times racket_scale */
+  float racket_half_thick;   /* times racket_scale */
+  float hull_margin;         /* URDF convex-hull collision margin, 0.001 */
+  float hull_bound_radius;   /* max distance COM -> inflated hull, for the cull */
+  float racket_scale;        /* tennisbot_env.py:213-215,234 globalScaling */
+  /* ball: ball.urdf:11-15,27-32, objects.py:48-50,67-72 */
+  float ball_mass, ball_inv_mass, ball_inv_inertia, ball_radius;
+  float magnus_k;            /* F = k (w x v); 0 reproduces the reference (BASELINE configs[4] extension) */
+  float ball_spin_max;       /* reset: w0 ~ U(-max, max)^3; 0 reproduces the reference */
+  /* pair coefficients: product rule, objects.py:16-18,29-31,48-50; goal keeps defaults */
+  float rest_racket, rest_court, rest_goal;
+  float fric_racket, fric_court, fric_goal;
+  /* statics: court.urdf:19-24,43-47; simplegoal.urdf:17-22 (origins inside <geometry> are ignored) */
+  float ground_half[3];
+  float net_half[3];
+  float goal_radius, goal_half_len;
+  /* racket collision outline: CCW convex polygon in the COM frame (y, z), pre-scaled.
+   * record i = { a.y, a.z, e.y, e.z, 1/|e|^2, 1/|e|, 0, 0 } with e = v[i+1] - v[i] */
+  int32_t n_hull;
+  float hull_edges[TB_MAX_HULL][TB_HULL_REC];
+} TbParams;
+
+typedef struct TbHandle TbHandle;
+
+/* library identity / shape queries (host only, no device touched) */
+int tb_abi_version(void);
+int tb_obs_dim(int env_kind);
+int tb_act_dim(int env_kind);
+int tb_state_words(int env_kind);
+const char *tb_last_error(void);
+
+/*
+ * Create a batch of n_envs independent worlds on `device`.
+ * Replaces, per world: p.connect (swingracket_env.py:44-47, tennisbot_env.py:65-68),
+ * and the one-time part of every loadURDF/changeDynamics (racket.py:35-45,
+ * objects.py:25-36,43-50,102-104). State is NOT initialised: call tb_reset.
+ * seed / env_id_base key the counter-based reset RNG: env i draws from
+ * (seed, env_id_base + i, episode_index), so results do not depend on how a
+ * global batch is sharded over GPUs.
+ */
+int tb_create(const TbParams *params, int env_kind, int n_envs, int device, uint64_t seed,
+              uint64_t env_id_base, TbHandle **out);
+
+/* Replaces p.disconnect (swingracket_env.py:189, tennisbot_env.py:291). Synchronous. */
+int tb_destroy(TbHandle *h);
+
+/* Replace the parameter block (e.g. after set_racket_scale, tennisbot_env.py:213-215).
+ * Takes effect for launches enqueued after it on `stream`. */
+int tb_set_params(TbHandle *h, const TbParams *params, void *stream);
+
+/*
+ * reset(): swingracket_env.py:151-186 / tennisbot_env.py:217-261 for every env i with
+ * mask_dev == NULL or mask_dev[i] != 0. Starts a new episode (episode index + 1) and
+ * writes the initial observation to obs_dev[i] if obs_dev != NULL.
+ */
+int tb_reset(TbHandle *h, const uint8_t *mask_dev, float *obs_dev, void *stream);
+
+/*
+ * step(action): swingracket_env.py:75-145 / tennisbot_env.py:104-207 for all envs,
+ * including every p.stepSimulation() (swingracket_env.py:82,107; tennisbot_env.py:121),
+ * the p.getContactPoints queries (swingracket_env.py:99,111,119; tennisbot_env.py:170),
+ * Racket.apply_target_action (racket.py:92-100), Ball.apply_force (objects.py:67-72)
+ * and the pose/velocity reads (racket.py:124-143, objects.py:52-65).
+ *   actions_dev  [N][A] float32 in
+ *   obs_dev      [N][O] float32 out
+ *   reward_dev   [N]    float32 out
+ *   done_dev     [N]    uint8   out (0/1)
+ *   terminal_obs_dev [N][O] or NULL: with TB_F_AUTO_RESET, the last observation of an
+ *                episode that ended in this step (untouched for other envs)
+ *   substeps_dev [N] int32 or NULL: physics substeps executed for env i in this call
+ */
+int tb_step(TbHandle *h, const float *actions_dev, float *obs_dev, float *reward_dev,
+            uint8_t *done_dev, float *terminal_obs_dev, int32_t *substeps_dev, void *stream);
+
+/*
+ * T consecutive step() calls in ONE launch with the state kept in registers:
+ * actions [T][N][A] in; obs [T][N][O], reward [T][N], done [T][N] out; substeps_total
+ * [N] int32 or NULL. Requires TB_F_AUTO_RESET. Same results as T calls of tb_step.
+ */
+int tb_rollout(TbHandle *h, int n_steps, const float *actions_dev, float *obs_dev,
+               float *reward_dev, uint8_t *done_dev, int32_t *substeps_total_dev, void *stream);
+
+/* Snapshot / restore the persistent state (the reference never checkpoints env state;
+ * SURVEY.md section 5). words: [tb_state_words][N] uint32 bit patterns, done: [N] bytes.
+ * `on_device` != 0: the buffers are device memory (async on stream); 0: host memory
+ * (the call synchronises the stream before returning). */
+int tb_get_state(TbHandle *h, uint32_t *words, uint8_t *done, int on_device, void *stream);
+int tb_set_state(TbHandle *h, const uint32_t *words, const uint8_t *done, int on_device, void *stream);
+
+/* per-handle event counters since create or the last tb_counters_reset: the batched
+ * stand-in for the reference's per-step prints (swingracket_env.py:102,115,124,129;
+ * tennisbot_env.py:172,191,202). out[0] racket-ball contact substeps, [1] ball-court
+ * terminations, [2] goal hits, [3] timeouts, [4] pass-racket terminations, [5] episodes
+ * finished, [6] substeps, [7] non-finite state detections. Synchronises the stream. */
+#define TB_N_COUNTERS 8
+int tb_counters(TbHandle *h, uint64_t *out, void *stream);
+int tb_counters_reset(TbHandle *h, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TB_STEPPER_H */

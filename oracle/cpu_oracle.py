@@ -1,0 +1,175 @@
+"""ctypes front-end of oracle/libtb_oracle_{f32,f64}.so (TEST INFRASTRUCTURE).
+
+Mirrors the product's tensor API on numpy arrays so that a parity test is literally
+"same params, same actions, compare outputs".
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from tennisbot_rl_amd.params import ACT_DIM, N_COUNTERS, OBS_DIM, STATE_ROWS, STATE_WORDS, TbParams
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = {}
+
+
+def lib_path(precision="f32"):
+    return os.path.join(_HERE, "libtb_oracle_%s.so" % precision)
+
+
+def build(force=False):
+    """Compile both precisions with gcc (seconds). Building the checker is not using it."""
+    if force or not (os.path.exists(lib_path("f32")) and os.path.exists(lib_path("f64"))):
+        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
+
+
+def _lib(precision):
+    if precision not in _LIBS:
+        if not os.path.exists(lib_path(precision)):
+            build()
+        L = ctypes.CDLL(lib_path(precision))
+        vp, u64, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int
+        L.tbo_create.restype = vp
+        L.tbo_create.argtypes = [ctypes.POINTER(TbParams), i32, i32, u64, u64]
+        L.tbo_destroy.argtypes = [vp]
+        L.tbo_set_params.argtypes = [vp, ctypes.POINTER(TbParams)]
+        L.tbo_set_threads.argtypes = [vp, i32]
+        L.tbo_real_bytes.restype = i32
+        L.tbo_reset.argtypes = [vp, vp, vp]
+        L.tbo_step.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        L.tbo_counters.argtypes = [vp, vp]
+        L.tbo_counters_reset.argtypes = [vp]
+        L.tbo_get_state.argtypes = [vp, vp, vp]
+        L.tbo_get_state_f64.argtypes = [vp, vp, vp]
+        L.tbo_set_state.argtypes = [vp, vp, vp]
+        L.tbo_philox4x32.argtypes = [vp, vp, vp]
+        L.tbo_query_racket.argtypes = [ctypes.POINTER(TbParams), vp, vp, vp, vp]
+        L.tbo_query_racket.restype = i32
+        L.tbo_query_box.argtypes = [ctypes.POINTER(TbParams), vp, vp, vp]
+        L.tbo_query_box.restype = i32
+        L.tbo_query_goal.argtypes = [ctypes.POINTER(TbParams), ctypes.c_float, ctypes.c_float, vp, vp]
+        L.tbo_query_goal.restype = i32
+        assert L.tbo_real_bytes() == (4 if precision == "f32" else 8)
+        _LIBS[precision] = L
+    return _LIBS[precision]
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class OracleBatch:
+    """N independent worlds stepped on the CPU by the restatement."""
+
+    def __init__(self, params, env_kind, n_envs, seed=0, env_id_base=0, precision="f32", threads=1):
+        self.L = _lib(precision)
+        self.kind, self.n, self.precision = env_kind, int(n_envs), precision
+        self.params = params.copy()
+        self.h = self.L.tbo_create(ctypes.byref(self.params), env_kind, self.n, seed, env_id_base)
+        if not self.h:
+            raise ValueError("tbo_create rejected the arguments")
+        self.L.tbo_set_threads(self.h, threads)
+        self.obs_dim, self.act_dim, self.words = OBS_DIM[env_kind], ACT_DIM[env_kind], STATE_WORDS[env_kind]
+
+    def close(self):
+        if self.h:
+            self.L.tbo_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_params(self, params):
+        self.params = params.copy()
+        self.L.tbo_set_params(self.h, ctypes.byref(self.params))
+
+    def reset(self, mask=None):
+        obs = np.zeros((self.n, self.obs_dim), np.float32)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        self.L.tbo_reset(self.h, _p(m), _p(obs))
+        return obs
+
+    def step(self, actions, want_terminal=False):
+        a = np.ascontiguousarray(actions, np.float32).reshape(self.n, self.act_dim)
+        obs = np.zeros((self.n, self.obs_dim), np.float32)
+        rew = np.zeros(self.n, np.float32)
+        done = np.zeros(self.n, np.uint8)
+        sub = np.zeros(self.n, np.int32)
+        term = np.full((self.n, self.obs_dim), np.nan, np.float32) if want_terminal else None
+        self.L.tbo_step(self.h, _p(a), _p(obs), _p(rew), _p(done), _p(term), _p(sub))
+        return (obs, rew, done, sub, term) if want_terminal else (obs, rew, done, sub)
+
+    def counters(self):
+        c = np.zeros(N_COUNTERS, np.uint64)
+        self.L.tbo_counters(self.h, _p(c))
+        return c
+
+    def get_state_words(self):
+        w = np.zeros((self.words, self.n), np.uint32)
+        d = np.zeros(self.n, np.uint8)
+        self.L.tbo_get_state(self.h, _p(w), _p(d))
+        return w, d
+
+    def set_state_words(self, words, done=None):
+        w = np.ascontiguousarray(words, np.uint32).reshape(self.words, self.n)
+        d = np.zeros(self.n, np.uint8) if done is None else np.ascontiguousarray(done, np.uint8)
+        self.L.tbo_set_state(self.h, _p(w), _p(d))
+
+    def get_state_f64(self):
+        v = np.zeros((self.words, self.n), np.float64)
+        d = np.zeros(self.n, np.uint8)
+        self.L.tbo_get_state_f64(self.h, _p(v), _p(d))
+        return v, d
+
+    def get_state(self):
+        """dict of named float64 arrays [n, k] (+ step_count, episode, done)."""
+        v, d = self.get_state_f64()
+        return rows_to_dict(self.kind, v, d)
+
+
+def rows_to_dict(kind, vals, done):
+    names = STATE_ROWS[kind]
+    out, i = {}, 0
+    while i < len(names):
+        j = i
+        while j < len(names) and names[j] == names[i]:
+            j += 1
+        out[names[i]] = np.ascontiguousarray(vals[i:j].T)
+        i = j
+    out["step_count"] = out["step_count"][:, 0].astype(np.int64)
+    out["episode"] = out["episode"][:, 0].astype(np.int64)
+    out["init_dist"] = out["init_dist"][:, 0] if "init_dist" in out else None
+    if out["init_dist"] is None:
+        del out["init_dist"]
+    out["done"] = np.asarray(done).copy()
+    return out
+
+
+def philox4x32(ctr, key, precision="f32"):
+    c = np.asarray(ctr, np.uint32)
+    k = np.asarray(key, np.uint32)
+    o = np.zeros(4, np.uint32)
+    _lib(precision).tbo_philox4x32(_p(c), _p(k), _p(o))
+    return o
+
+
+def query_racket(params, racket_pos, racket_quat, ball_pos, precision="f64"):
+    out = np.zeros(8, np.float64)
+    a, b, c = (np.asarray(x, np.float32) for x in (racket_pos, racket_quat, ball_pos))
+    hit = _lib(precision).tbo_query_racket(ctypes.byref(params), _p(a), _p(b), _p(c), _p(out))
+    return bool(hit), out[0], out[1:4].copy(), out[4:7].copy()
+
+
+def query_box(params, half, ball_pos, precision="f64"):
+    out = np.zeros(4, np.float64)
+    a, c = np.asarray(half, np.float32), np.asarray(ball_pos, np.float32)
+    hit = _lib(precision).tbo_query_box(ctypes.byref(params), _p(a), _p(c), _p(out))
+    return bool(hit), out[0], out[1:4].copy()
+
+
+def query_goal(params, gx, gy, ball_pos, precision="f64"):
+    out = np.zeros(4, np.float64)
+    c = np.asarray(ball_pos, np.float32)
+    hit = _lib(precision).tbo_query_goal(ctypes.byref(params), gx, gy, _p(c), _p(out))
+    return bool(hit), out[0], out[1:4].copy()

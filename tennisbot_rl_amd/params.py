@@ -1,0 +1,161 @@
+"""Scene / engine parameters: the ctypes mirror of `TbParams` (include/tb_stepper.h).
+
+The reference spreads these numbers over URDF files and `changeDynamics` calls that are
+re-executed on every reset (racket.py:35-45, objects.py:16-18,29-31,48-50,102-104);
+here they are parsed once (tools/extract_assets.py -> assets/scene.json) and handed to
+the kernels as one POD block. Derived values are computed in float64 and rounded once.
+"""
+import ctypes
+import json
+import math
+import os
+
+import numpy as np
+
+TB_MAX_HULL = 64
+TB_HULL_REC = 8
+
+ENV_SWING = 0   # SwingRacket-v0, tennisbot/__init__.py:8-11
+ENV_TENNIS = 1  # Tennisbot-v0,   tennisbot/__init__.py:3-6
+
+F_AUTO_RESET = 0x1
+F_NET = 0x2
+F_RACKET_BALL = 0x4
+F_DEFAULT = F_NET | F_RACKET_BALL
+
+DONE_NO, DONE_PENDING_FORCE, DONE_YES = 0, 1, 2
+
+N_COUNTERS = 8
+COUNTER_NAMES = ("racket_ball_contact_substeps", "ball_court_terminations", "goal_hits", "timeouts",
+                 "pass_racket_terminations", "episodes_finished", "substeps", "nonfinite_states")
+
+OBS_DIM = {ENV_SWING: 6, ENV_TENNIS: 12}
+ACT_DIM = {ENV_SWING: 6, ENV_TENNIS: 2}
+STATE_WORDS = {ENV_SWING: 30, ENV_TENNIS: 27}
+
+# SoA row names (include/tb_stepper.h TB_W_*); the last two rows are integers
+_COMMON_ROWS = (["racket_pos"] * 3 + ["racket_quat"] * 4 + ["racket_vel"] * 3 + ["racket_angvel"] * 3
+                + ["ball_pos"] * 3 + ["ball_vel"] * 3 + ["ball_angvel"] * 3)
+STATE_ROWS = {
+    ENV_SWING: _COMMON_ROWS + ["goal"] * 2 + ["spawn_pos"] * 3 + ["init_dist", "step_count", "episode"],
+    ENV_TENNIS: _COMMON_ROWS + ["shoot_force"] * 3 + ["step_count", "episode"],
+}
+
+_ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "scene.json")
+
+
+class TbParams(ctypes.Structure):
+    _fields_ = [
+        ("dt", ctypes.c_float), ("inv_dt", ctypes.c_float), ("gravity", ctypes.c_float),
+        ("lin_damp", ctypes.c_float), ("ang_damp", ctypes.c_float), ("max_ang_step", ctypes.c_float),
+        ("rest_vel_threshold", ctypes.c_float), ("erp", ctypes.c_float), ("contact_threshold", ctypes.c_float),
+        ("solver_iters", ctypes.c_int32), ("flags", ctypes.c_uint32),
+        ("racket_mass", ctypes.c_float), ("racket_inv_mass", ctypes.c_float),
+        ("racket_inertia", ctypes.c_float * 3), ("racket_inv_inertia", ctypes.c_float * 3),
+        ("racket_com", ctypes.c_float * 3), ("racket_half_thick", ctypes.c_float),
+        ("hull_margin", ctypes.c_float), ("hull_bound_radius", ctypes.c_float), ("racket_scale", ctypes.c_float),
+        ("ball_mass", ctypes.c_float), ("ball_inv_mass", ctypes.c_float), ("ball_inv_inertia", ctypes.c_float),
+        ("ball_radius", ctypes.c_float), ("magnus_k", ctypes.c_float), ("ball_spin_max", ctypes.c_float),
+        ("rest_racket", ctypes.c_float), ("rest_court", ctypes.c_float), ("rest_goal", ctypes.c_float),
+        ("fric_racket", ctypes.c_float), ("fric_court", ctypes.c_float), ("fric_goal", ctypes.c_float),
+        ("ground_half", ctypes.c_float * 3), ("net_half", ctypes.c_float * 3),
+        ("goal_radius", ctypes.c_float), ("goal_half_len", ctypes.c_float),
+        ("n_hull", ctypes.c_int32), ("hull_edges", (ctypes.c_float * TB_HULL_REC) * TB_MAX_HULL),
+    ]
+
+    def copy(self):
+        out = TbParams()
+        ctypes.memmove(ctypes.byref(out), ctypes.byref(self), ctypes.sizeof(TbParams))
+        return out
+
+    def hull_vertices(self):
+        """CCW (y, z) hull vertices in the COM frame, as the kernels see them."""
+        e = np.ctypeslib.as_array(self.hull_edges)[: self.n_hull]
+        return e[:, :2].astype(np.float64)
+
+
+def load_scene(path=_ASSETS):
+    with open(path) as f:
+        return json.load(f)
+
+
+def hull_edge_table(hull_yz_link, com_yz, scale):
+    """Edge records {a.y, a.z, e.y, e.z, 1/|e|^2, 1/|e|, 0, 0} for the CCW polygon, moved to
+    the COM frame (hull vertices in the COM frame = STL vertices - inertial
+    origin) and scaled by globalScaling (tennisbot_env.py:234)."""
+    v = (np.asarray(hull_yz_link, dtype=np.float64) - np.asarray(com_yz, dtype=np.float64)) * float(scale)
+    v = v.astype(np.float32).astype(np.float64)  # the vertices the kernels will see
+    e = np.roll(v, -1, axis=0) - v
+    l2 = (e ** 2).sum(1)
+    rec = np.zeros((len(v), TB_HULL_REC), dtype=np.float64)
+    rec[:, 0:2] = v
+    rec[:, 2:4] = e
+    rec[:, 4] = 1.0 / l2
+    rec[:, 5] = 1.0 / np.sqrt(l2)
+    return rec.astype(np.float32)
+
+
+def default_params(racket_scale=1.0, flags=F_DEFAULT, scene=None, **overrides):
+    """Reference scene + the Bullet defaults of SURVEY.md Appendix B.2.
+
+    Any TbParams field can be overridden by keyword (calibration on a host with pybullet).
+    Derived fields (inverses, hull table, bound radius) are recomputed from the primary ones.
+    """
+    sc = scene or load_scene()
+    rk, bl = sc["racket"], sc["ball"]
+    s = float(racket_scale)
+    prim = dict(
+        dt=1.0 / 240.0,                 # racket.py:24; PyBullet default fixed time step
+        gravity=9.81,                   # swingracket_env.py:154
+        lin_damp=0.04, ang_damp=0.04,   # [3P-recalled] PyBullet default damping
+        max_ang_step=0.25 * math.pi,
+        rest_vel_threshold=0.2, erp=0.2,
+        contact_threshold=0.02 * bl["radius"],
+        solver_iters=50,
+        racket_mass=rk["mass"], racket_inertia=tuple(rk["inertia_diag"]),
+        hull_margin=0.001,
+        ball_mass=bl["mass"], ball_inertia=bl["inertia_diag"][0], ball_radius=bl["radius"],
+        magnus_k=0.0, ball_spin_max=0.0,
+        # restitution .9 / lateralFriction .2 on racket, ball, court (racket.py:43-45,
+        # objects.py:29-31,48-50); the goal keeps Bullet's defaults (0 / 0.5); pair = product
+        rest_racket=0.9 * 0.9, rest_court=0.9 * 0.9, rest_goal=0.9 * 0.0,
+        fric_racket=0.2 * 0.2, fric_court=0.2 * 0.2, fric_goal=0.2 * 0.5,
+        ground_half=tuple(0.5 * x for x in sc["court"]["ground_box_size"]),
+        net_half=tuple(0.5 * x for x in sc["court"]["net_box_size"]),
+        goal_radius=sc["goal"]["radius"], goal_half_len=0.5 * sc["goal"]["length"],
+    )
+    unknown = set(overrides) - set(prim)
+    if unknown:
+        raise TypeError("unknown parameter(s): %s" % sorted(unknown))
+    prim.update(overrides)
+
+    p = TbParams()
+    for k in ("dt", "gravity", "lin_damp", "ang_damp", "max_ang_step", "rest_vel_threshold", "erp",
+              "contact_threshold", "racket_mass", "hull_margin", "ball_mass", "ball_radius", "magnus_k",
+              "ball_spin_max", "rest_racket", "rest_court", "rest_goal", "fric_racket", "fric_court",
+              "fric_goal", "goal_radius", "goal_half_len"):
+        setattr(p, k, float(prim[k]))
+    p.inv_dt = 1.0 / float(prim["dt"])
+    p.solver_iters = int(prim["solver_iters"])
+    p.flags = int(flags)
+    p.racket_inv_mass = 1.0 / float(prim["racket_mass"])
+    p.ball_inv_mass = 1.0 / float(prim["ball_mass"])
+    p.ball_inv_inertia = 1.0 / float(prim["ball_inertia"])
+    for i in range(3):
+        p.racket_inertia[i] = float(prim["racket_inertia"][i])
+        p.racket_inv_inertia[i] = 1.0 / float(prim["racket_inertia"][i])
+        p.racket_com[i] = float(rk["inertial_origin"][i]) * s
+        p.ground_half[i] = float(prim["ground_half"][i])
+        p.net_half[i] = float(prim["net_half"][i])
+    p.racket_half_thick = float(rk["half_thickness"]) * s
+    p.racket_scale = s
+    com = rk["inertial_origin"]
+    rec = hull_edge_table(rk["hull_yz_ccw"], (com[1], com[2]), s)
+    if len(rec) > TB_MAX_HULL:
+        raise ValueError("hull has %d vertices, the kernels take at most %d" % (len(rec), TB_MAX_HULL))
+    p.n_hull = len(rec)
+    np.ctypeslib.as_array(p.hull_edges)[: len(rec)] = rec
+    # bound radius about the COM, x extent and margin included (slightly rounded up)
+    vmax = float(np.sqrt((rec[:, :2].astype(np.float64) ** 2).sum(1).max() + float(p.racket_half_thick) ** 2))
+    p.hull_bound_radius = (vmax + float(prim["hull_margin"])) * 1.0001
+    return p

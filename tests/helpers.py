@@ -1,0 +1,47 @@
+"""Shared helpers for the test-suite: state construction in the library's SoA word layout."""
+import numpy as np
+
+from tennisbot_rl_amd.params import ENV_SWING, STATE_ROWS, STATE_WORDS
+
+IDENT_Q = (0.0, 0.0, 0.0, 1.0)
+
+
+def make_words(kind, n, **fields):
+    """Build [words, n] uint32 + done[n] from named fields (each scalar, [k] or [n, k]).
+
+    Unspecified rows default to 0 (quaternion: identity; init_dist: 1)."""
+    names = STATE_ROWS[kind]
+    vals = np.zeros((STATE_WORDS[kind], n), np.float64)
+    defaults = {"racket_quat": IDENT_Q, "init_dist": (1.0,)}
+    done = np.asarray(fields.pop("done", np.zeros(n)), np.uint8) * np.ones(n, np.uint8)
+    groups = {}
+    for i, nm in enumerate(names):
+        groups.setdefault(nm, []).append(i)
+    for nm, rows in groups.items():
+        v = fields.pop(nm, defaults.get(nm, 0.0))
+        v = np.asarray(v, np.float64)
+        if v.ndim == 0:
+            v = np.full((n, len(rows)), float(v))
+        elif v.ndim == 1 and v.shape[0] == len(rows):
+            v = np.tile(v, (n, 1))
+        elif v.ndim == 1 and v.shape[0] == n and len(rows) == 1:
+            v = v[:, None]
+        vals[rows] = v.reshape(n, len(rows)).T
+    assert not fields, "unknown state fields: %s" % sorted(fields)
+    words = vals.astype(np.float32).view(np.uint32).copy()
+    nw = STATE_WORDS[kind]
+    words[nw - 2] = vals[nw - 2].astype(np.int32).view(np.uint32)
+    words[nw - 1] = vals[nw - 1].astype(np.uint32)
+    return words, done
+
+
+def words_to_f32(kind, words):
+    """float view of the float rows + int rows split out."""
+    nw = STATE_WORDS[kind]
+    f = words[: nw - 2].view(np.float32)
+    return f, words[nw - 2].view(np.int32), words[nw - 1]
+
+
+def far_ball(kind):
+    """A ball position that touches nothing (high above the court)."""
+    return (0.0, 3.0, 50.0) if kind == ENV_SWING else (0.0, 3.0, 50.0)
