@@ -453,25 +453,31 @@ static void integrate_velocities(const Prm *P, Racket *rk, Ball *b, v3 Fr, v3 Tr
     real kd = FMA(P->lin_damp, SQRT(dot3(rk->v, rk->v)), P->lin_damp);
     v3 a = V3(FMA(Fr.x, P->racket_inv_mass, -(rk->v.x * kd)), FMA(Fr.y, P->racket_inv_mass, -(rk->v.y * kd)),
               FMA(Fr.z, P->racket_inv_mass, -(rk->v.z * kd)) - g);
-    /* angular, body frame: w' = I^-1 (T - w x I w - I w (k1 + k2 |w|)) */
-    v3 wb = qrot_inv(rk->q, rk->w), Tb = qrot_inv(rk->q, Tr);
-    v3 L = V3(P->racket_inertia[0] * wb.x, P->racket_inertia[1] * wb.y, P->racket_inertia[2] * wb.z);
-    v3 gy = cross3(wb, L);
-    real ka = FMA(P->ang_damp, SQRT(dot3(wb, wb)), P->ang_damp);
-    v3 ab = V3(P->racket_inv_inertia[0] * ((Tb.x - gy.x) - L.x * ka), P->racket_inv_inertia[1] * ((Tb.y - gy.y) - L.y * ka),
-               P->racket_inv_inertia[2] * ((Tb.z - gy.z) - L.z * ka));
     rk->v = axpy3(dt, a, rk->v);
-    rk->w = axpy3(dt, qrot(rk->q, ab), rk->w);
+    /* angular, body frame: w' = I^-1 (T - w x I w - I w (k1 + k2 |w|)); a racket that neither
+     * spins nor is torqued has zero angular acceleration and is left untouched */
+    int active = (rk->w.x != R(0)) | (rk->w.y != R(0)) | (rk->w.z != R(0)) | (Tr.x != R(0)) | (Tr.y != R(0)) | (Tr.z != R(0));
+    if (active) {
+      v3 wb = qrot_inv(rk->q, rk->w), Tb = qrot_inv(rk->q, Tr);
+      v3 L = V3(P->racket_inertia[0] * wb.x, P->racket_inertia[1] * wb.y, P->racket_inertia[2] * wb.z);
+      v3 gy = cross3(wb, L);
+      real ka = FMA(P->ang_damp, SQRT(dot3(wb, wb)), P->ang_damp);
+      v3 ab = V3(P->racket_inv_inertia[0] * ((Tb.x - gy.x) - L.x * ka), P->racket_inv_inertia[1] * ((Tb.y - gy.y) - L.y * ka),
+                 P->racket_inv_inertia[2] * ((Tb.z - gy.z) - L.z * ka));
+      rk->w = axpy3(dt, qrot(rk->q, ab), rk->w);
+    }
   }
   { /* ball: isotropic inertia => no gyroscopic term */
     if (P->magnus_k != R(0)) Fb = axpy3(P->magnus_k, cross3(b->w, b->v), Fb);
     real kd = FMA(P->lin_damp, SQRT(dot3(b->v, b->v)), P->lin_damp);
     v3 a = V3(FMA(Fb.x, P->ball_inv_mass, -(b->v.x * kd)), FMA(Fb.y, P->ball_inv_mass, -(b->v.y * kd)),
               FMA(Fb.z, P->ball_inv_mass, -(b->v.z * kd)) - g);
-    real ka = FMA(P->ang_damp, SQRT(dot3(b->w, b->w)), P->ang_damp);
-    v3 aw = V3(-(b->w.x * ka), -(b->w.y * ka), -(b->w.z * ka));
     b->v = axpy3(dt, a, b->v);
-    b->w = axpy3(dt, aw, b->w);
+    if ((b->w.x != R(0)) | (b->w.y != R(0)) | (b->w.z != R(0))) {
+      real ka = FMA(P->ang_damp, SQRT(dot3(b->w, b->w)), P->ang_damp);
+      v3 aw = V3(-(b->w.x * ka), -(b->w.y * ka), -(b->w.z * ka));
+      b->w = axpy3(dt, aw, b->w);
+    }
   }
 }
 

@@ -1,0 +1,410 @@
+// tb_device.hpp -- device-side rigid-body physics of the batched stepper (gfx950).
+//
+// One lane = one world: a 6-DoF floating racket, a ball and the static court / net /
+// goal. Everything here runs in registers; the only memory the physics touches is the
+// racket outline table, staged once per workgroup into LDS and read at a wave-uniform
+// index (LDS broadcast, no bank conflicts).
+//
+// What this replaces (per world, per call) in the reference:
+//   p.stepSimulation()          swingracket_env.py:82,107; tennisbot_env.py:121
+//   p.getContactPoints(a, b)    swingracket_env.py:99,111,119; tennisbot_env.py:170
+//   applyExternalForce/Torque   racket.py:97-100; objects.py:72
+// The engine semantics follow Bullet's multibody pipeline as recalled in SURVEY.md
+// Appendix B; each recalled constant is a TbParams field.
+//
+// Arithmetic contract: compiled with -ffp-contract=off; every fused
+// multiply-add below is an explicit __builtin_fmaf; sqrt and divide are IEEE-rounded
+// (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt); sin/cos of the half angle are
+// fixed polynomials. Integer outputs (done, step counters, contact bits) therefore do not
+// depend on host/device libm differences.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tb_stepper.h"
+
+#define TB_DEV __device__ __forceinline__
+#define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+
+namespace tb {
+
+struct vec3 { float x, y, z; };
+struct quat { float x, y, z, w; };
+
+TB_DEV vec3 mk(float x, float y, float z) { vec3 r; r.x = x; r.y = y; r.z = z; return r; }
+TB_DEV vec3 operator+(vec3 a, vec3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+TB_DEV vec3 operator-(vec3 a, vec3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+TB_DEV vec3 operator*(float s, vec3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+TB_DEV vec3 fma3(float s, vec3 x, vec3 y) { return mk(FMA(s, x.x, y.x), FMA(s, x.y, y.y), FMA(s, x.z, y.z)); }
+TB_DEV float dot(vec3 a, vec3 b) { return FMA(a.z, b.z, FMA(a.y, b.y, a.x * b.x)); }
+TB_DEV vec3 cross(vec3 a, vec3 b) {
+  return mk(FMA(a.y, b.z, -(a.z * b.y)), FMA(a.z, b.x, -(a.x * b.z)), FMA(a.x, b.y, -(a.y * b.x)));
+}
+TB_DEV vec3 rotate(quat q, vec3 v) {
+  vec3 u = mk(q.x, q.y, q.z);
+  vec3 t = 2.0f * cross(u, v);
+  return fma3(q.w, t, v) + cross(u, t);
+}
+TB_DEV vec3 rotate_inv(quat q, vec3 v) {
+  quat c; c.x = -q.x; c.y = -q.y; c.z = -q.z; c.w = q.w;
+  return rotate(c, v);
+}
+TB_DEV quat qmul(quat a, quat b) {
+  quat r;
+  r.w = FMA(-a.z, b.z, FMA(-a.y, b.y, FMA(-a.x, b.x, a.w * b.w)));
+  r.x = FMA(-a.z, b.y, FMA(a.y, b.z, FMA(a.x, b.w, a.w * b.x)));
+  r.y = FMA(a.z, b.x, FMA(a.y, b.w, FMA(-a.x, b.z, a.w * b.y)));
+  r.z = FMA(a.z, b.w, FMA(-a.y, b.x, FMA(a.x, b.y, a.w * b.z)));
+  return r;
+}
+// half rotation angle is clamped to pi/8: degree-9 / degree-10 Taylor is below 1 ulp there
+TB_DEV float sin_small(float x) {
+  float z = x * x;
+  float p = FMA(z, (float)(1.0 / 362880.0), (float)(-1.0 / 5040.0));
+  p = FMA(z, p, (float)(1.0 / 120.0));
+  p = FMA(z, p, (float)(-1.0 / 6.0));
+  p = FMA(z, p, 1.0f);
+  return x * p;
+}
+TB_DEV float cos_small(float x) {
+  float z = x * x;
+  float p = FMA(z, (float)(-1.0 / 3628800.0), (float)(1.0 / 40320.0));
+  p = FMA(z, p, (float)(-1.0 / 720.0));
+  p = FMA(z, p, (float)(1.0 / 24.0));
+  p = FMA(z, p, -0.5f);
+  return FMA(z, p, 1.0f);
+}
+
+// ---------------------------------------------------------------- counter RNG (Philox4x32-10)
+// stands in for the reference's unseedable global `random` / numpy draws
+// (swingracket_env.py:161-162,173; tennisbot_env.py:227-229,238-239; objects.py:91-93)
+TB_DEV void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+TB_DEV float uniform(float lo, float span, uint32_t u) { return lo + span * ((float)(u >> 8) * 5.9604644775390625e-08f); }
+
+// ---------------------------------------------------------------- kernel-argument parameter block
+// the scalar part of TbParams travels in the kernarg segment (SGPRs, wave-uniform);
+// the outline table goes through LDS
+struct KParams {
+  float dt, inv_dt, gravity, lin_damp, ang_damp, max_ang_step, rest_vel_threshold, erp, contact_threshold;
+  int solver_iters; uint32_t flags;
+  float racket_inv_mass, racket_inertia[3], racket_inv_inertia[3], racket_com[3], racket_half_thick, hull_margin, hull_bound_radius;
+  float ball_inv_mass, ball_inv_inertia, ball_radius, magnus_k, ball_spin_max;
+  float rest_racket, rest_court, rest_goal, fric_racket, fric_court, fric_goal;
+  float ground_half[3], net_half[3], goal_radius, goal_half_len;
+  int n_hull;
+};
+
+struct Racket { vec3 p; quat q; vec3 v; vec3 w; };
+struct Ball { vec3 p; vec3 v; vec3 w; };
+
+struct Hit {
+  bool hit;
+  float dist;  // surface distance, negative = penetration
+  vec3 n;      // unit, toward the ball centre
+  vec3 rr;     // racket pair: contact point on the racket relative to its COM
+};
+
+constexpr int CT_RACKET = 1, CT_GROUND = 2, CT_NET = 4, CT_GOAL = 8;
+
+// ---------------------------------------------------------------- narrowphase
+// sphere vs racket: prism over the convex (y, z) outline of racket.stl in the COM frame,
+// inflated by the URDF hull margin (racket.urdf:12-16).
+// `hull` points at the LDS copy of the edge records {a.y a.z e.y e.z | 1/|e|^2 1/|e| - -}.
+TB_DEV Hit sphere_vs_racket(const KParams& P, const float4* hull, const Racket& rk, vec3 c) {
+  Hit h; h.hit = false; h.dist = 0.0f; h.n = mk(0, 0, 0); h.rr = mk(0, 0, 0);
+  const float r = P.ball_radius, thr = P.contact_threshold;
+  vec3 d = c - rk.p;
+  float reach = (P.hull_bound_radius + r) + thr;
+  if (dot(d, d) > reach * reach) return h;
+  vec3 l = rotate_inv(rk.q, d);
+  float ax = fabsf(l.x) - P.racket_half_thick;
+  float sx = l.x < 0.0f ? -1.0f : 1.0f;
+  bool inside = true;
+  int deep_edge = 0;
+  float best_d2 = 3.0e38f, best_ry = 0.0f, best_rz = 0.0f, max_sd = -3.0e38f;
+  for (int i = 0; i < P.n_hull; ++i) {
+    float4 e0 = hull[2 * i];
+    float4 e1 = hull[2 * i + 1];
+    float wy = l.y - e0.x, wz = l.z - e0.y;
+    float cr = FMA(e0.z, wz, -(e0.w * wy));
+    if (cr < 0.0f) inside = false;
+    float sd = -(cr * e1.y);
+    if (sd > max_sd) { max_sd = sd; deep_edge = i; }
+    float t = FMA(wy, e0.z, wz * e0.w) * e1.x;
+    t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+    float ry = FMA(-t, e0.z, wy), rz = FMA(-t, e0.w, wz);
+    float d2 = FMA(ry, ry, rz * rz);
+    if (d2 < best_d2) { best_d2 = d2; best_ry = ry; best_rz = rz; }
+  }
+  float dist_hull; vec3 nl;
+  if (inside) {
+    if (ax > 0.0f || ax >= max_sd) { dist_hull = ax; nl = mk(sx, 0.0f, 0.0f); }
+    else {
+      float4 e0 = hull[2 * deep_edge];
+      float4 e1 = hull[2 * deep_edge + 1];
+      dist_hull = max_sd;
+      nl = mk(0.0f, e0.w * e1.y, -(e0.z * e1.y));
+    }
+  } else {
+    float dx = ax > 0.0f ? sx * ax : 0.0f;
+    float dd = FMA(dx, dx, best_d2);
+    dist_hull = sqrtf(dd);
+    float inv = 1.0f / dist_hull;
+    nl = mk(dx * inv, best_ry * inv, best_rz * inv);
+  }
+  h.dist = (dist_hull - P.hull_margin) - r;
+  h.hit = h.dist < thr;
+  h.n = rotate(rk.q, nl);
+  h.rr = fma3(-(r + h.dist), h.n, d);
+  return h;
+}
+
+// sphere vs axis-aligned static box centred at the origin (court.urdf:19-24 ground,
+// :43-47 net; both <origin>s sit inside <geometry> and are ignored by URDF parsers)
+TB_DEV Hit sphere_vs_box(const KParams& P, float hx, float hy, float hz, vec3 c) {
+  Hit h; h.hit = false; h.dist = 0.0f; h.n = mk(0, 0, 0); h.rr = mk(0, 0, 0);
+  const float r = P.ball_radius, thr = P.contact_threshold;
+  float sx = fabsf(c.x) - hx, sy = fabsf(c.y) - hy, sz = fabsf(c.z) - hz;
+  if (sx - r >= thr || sy - r >= thr || sz - r >= thr) return h;
+  float gx = c.x < 0.0f ? -1.0f : 1.0f, gy = c.y < 0.0f ? -1.0f : 1.0f, gz = c.z < 0.0f ? -1.0f : 1.0f;
+  bool ox = sx > 0.0f, oy = sy > 0.0f, oz = sz > 0.0f;
+  int nout = (int)ox + (int)oy + (int)oz;
+  float ds;
+  if (nout == 0) {
+    if (sz >= sx && sz >= sy) { ds = sz; h.n = mk(0.0f, 0.0f, gz); }
+    else if (sx >= sy) { ds = sx; h.n = mk(gx, 0.0f, 0.0f); }
+    else { ds = sy; h.n = mk(0.0f, gy, 0.0f); }
+  } else if (nout == 1) {
+    if (oz) { ds = sz; h.n = mk(0.0f, 0.0f, gz); }
+    else if (ox) { ds = sx; h.n = mk(gx, 0.0f, 0.0f); }
+    else { ds = sy; h.n = mk(0.0f, gy, 0.0f); }
+  } else {
+    vec3 dl = mk(ox ? gx * sx : 0.0f, oy ? gy * sy : 0.0f, oz ? gz * sz : 0.0f);
+    ds = sqrtf(dot(dl, dl));
+    h.n = (1.0f / ds) * dl;
+  }
+  h.dist = ds - r;
+  h.hit = h.dist < thr;
+  return h;
+}
+
+// sphere vs the goal cylinder, axis z, centred at (gx, gy, 0) (simplegoal.urdf:17-22, objects.py:99-104)
+TB_DEV Hit sphere_vs_goal(const KParams& P, float gx, float gy, vec3 c) {
+  Hit h; h.hit = false; h.dist = 0.0f; h.n = mk(0, 0, 0); h.rr = mk(0, 0, 0);
+  const float r = P.ball_radius, thr = P.contact_threshold;
+  const float RG = P.goal_radius, hl = P.goal_half_len;
+  float rx = c.x - gx, ry = c.y - gy, rz = c.z;
+  float sz = fabsf(rz) - hl;
+  if (sz - r >= thr) return h;
+  float rad2 = FMA(rx, rx, ry * ry);
+  float reach = (RG + r) + thr;
+  if (rad2 > reach * reach) return h;
+  float rad = sqrtf(rad2);
+  float sr = rad - RG;
+  float gz = rz < 0.0f ? -1.0f : 1.0f;
+  vec3 radial = rad > 0.0f ? mk(rx / rad, ry / rad, 0.0f) : mk(1.0f, 0.0f, 0.0f);
+  float ds;
+  if (sr <= 0.0f && sz <= 0.0f) {
+    if (sz >= sr) { ds = sz; h.n = mk(0.0f, 0.0f, gz); }
+    else { ds = sr; h.n = radial; }
+  } else if (sr <= 0.0f) { ds = sz; h.n = mk(0.0f, 0.0f, gz); }
+  else if (sz <= 0.0f) { ds = sr; h.n = radial; }
+  else {
+    ds = sqrtf(FMA(sr, sr, sz * sz));
+    float inv = 1.0f / ds;
+    h.n = mk(radial.x * (sr * inv), radial.y * (sr * inv), gz * (sz * inv));
+  }
+  h.dist = ds - r;
+  h.hit = h.dist < thr;
+  return h;
+}
+
+// ---------------------------------------------------------------- sequential-impulse contact rows
+struct Row {
+  bool racket;
+  vec3 n, rr, t1, t2;
+  float mu, target, kn, kt1, kt2, jn, jt1, jt2;
+};
+
+TB_DEV vec3 racket_invI(const KParams& P, quat q, vec3 x) {
+  vec3 b = rotate_inv(q, x);
+  b = mk(b.x * P.racket_inv_inertia[0], b.y * P.racket_inv_inertia[1], b.z * P.racket_inv_inertia[2]);
+  return rotate(q, b);
+}
+TB_DEV vec3 rel_vel(const Row& c, const Racket& rk, const Ball& b, vec3 rb) {
+  vec3 pv = b.v + cross(b.w, rb);
+  if (c.racket) pv = pv - (rk.v + cross(rk.w, c.rr));
+  return pv;
+}
+TB_DEV void plane_space(vec3 n, vec3& p, vec3& q) {
+  if (fabsf(n.z) > 0.7071067811865475244f) {
+    float a = FMA(n.y, n.y, n.z * n.z);
+    float k = 1.0f / sqrtf(a);
+    p = mk(0.0f, -(n.z * k), n.y * k);
+    q = mk(a * k, -(n.x * p.z), n.x * p.y);
+  } else {
+    float a = FMA(n.x, n.x, n.y * n.y);
+    float k = 1.0f / sqrtf(a);
+    p = mk(-(n.y * k), n.x * k, 0.0f);
+    q = mk(-(n.z * p.y), n.z * p.x, a * k);
+  }
+}
+TB_DEV void apply_impulse(const KParams& P, const Row& c, Racket& rk, Ball& b, vec3 rb, vec3 dir, float j, bool angular_ball) {
+  b.v = fma3(j * P.ball_inv_mass, dir, b.v);
+  if (angular_ball) b.w = fma3(j * P.ball_inv_inertia, cross(rb, dir), b.w);
+  if (c.racket) {
+    rk.v = fma3(-(j * P.racket_inv_mass), dir, rk.v);
+    rk.w = fma3(-j, racket_invI(P, rk.q, cross(c.rr, dir)), rk.w);
+  }
+}
+TB_DEV void setup_row(const KParams& P, Row& c, const Hit& h, bool racket, float e, float mu, const Racket& rk, const Ball& b) {
+  const float r = P.ball_radius;
+  c.racket = racket; c.n = h.n; c.rr = h.rr; c.mu = mu;
+  c.jn = 0.0f; c.jt1 = 0.0f; c.jt2 = 0.0f;
+  plane_space(c.n, c.t1, c.t2);
+  vec3 rb = (-r) * c.n;
+  float kn = P.ball_inv_mass, kt1 = FMA(P.ball_inv_inertia, r * r, P.ball_inv_mass), kt2 = kt1;
+  if (racket) {
+    vec3 a;
+    a = cross(c.rr, c.n);  kn = (kn + P.racket_inv_mass) + dot(a, racket_invI(P, rk.q, a));
+    a = cross(c.rr, c.t1); kt1 = (kt1 + P.racket_inv_mass) + dot(a, racket_invI(P, rk.q, a));
+    a = cross(c.rr, c.t2); kt2 = (kt2 + P.racket_inv_mass) + dot(a, racket_invI(P, rk.q, a));
+  }
+  c.kn = 1.0f / kn; c.kt1 = 1.0f / kt1; c.kt2 = 1.0f / kt2;
+  float vn = dot(c.n, rel_vel(c, rk, b, rb));
+  float rest = fabsf(vn) < P.rest_vel_threshold ? 0.0f : e * (-vn);
+  if (rest < 0.0f) rest = 0.0f;
+  float pos = h.dist > 0.0f ? -(h.dist * P.inv_dt) : -(h.dist * P.erp) * P.inv_dt;
+  c.target = rest + pos;
+}
+TB_DEV void solve_contacts(const KParams& P, Row* rows, int nrows, Racket& rk, Ball& b) {
+  const float r = P.ball_radius;
+  for (int it = 0; it < P.solver_iters; ++it) {
+    bool moved = false;
+    for (int i = 0; i < nrows; ++i) {
+      Row& c = rows[i];
+      vec3 rb = (-r) * c.n;
+      float vn = dot(c.n, rel_vel(c, rk, b, rb));
+      float jn = FMA(c.target - vn, c.kn, c.jn);
+      if (jn < 0.0f) jn = 0.0f;
+      float d = jn - c.jn;
+      c.jn = jn;
+      if (d != 0.0f) { moved = true; apply_impulse(P, c, rk, b, rb, c.n, d, false); }
+    }
+    for (int i = 0; i < nrows; ++i) {
+      Row& c = rows[i];
+      float lim = c.mu * c.jn;
+      if (!(lim > 0.0f)) continue;
+      vec3 rb = (-r) * c.n;
+      for (int k = 0; k < 2; ++k) {
+        vec3 t = k ? c.t2 : c.t1;
+        float acc = k ? c.jt2 : c.jt1;
+        float kt = k ? c.kt2 : c.kt1;
+        float vt = dot(t, rel_vel(c, rk, b, rb));
+        float jt = FMA(-vt, kt, acc);
+        jt = jt < -lim ? -lim : (jt > lim ? lim : jt);
+        float d = jt - acc;
+        if (k) c.jt2 = jt; else c.jt1 = jt;
+        if (d != 0.0f) { moved = true; apply_impulse(P, c, rk, b, rb, t, d, true); }
+      }
+    }
+    if (!moved) break;
+  }
+}
+
+// ---------------------------------------------------------------- one 1/240 s substep
+TB_DEV void integrate_velocities(const KParams& P, Racket& rk, Ball& b, vec3 Fr, vec3 Tr, vec3 Fb) {
+  const float dt = P.dt, g = P.gravity;
+  {
+    float kd = FMA(P.lin_damp, sqrtf(dot(rk.v, rk.v)), P.lin_damp);
+    vec3 a = mk(FMA(Fr.x, P.racket_inv_mass, -(rk.v.x * kd)), FMA(Fr.y, P.racket_inv_mass, -(rk.v.y * kd)),
+                FMA(Fr.z, P.racket_inv_mass, -(rk.v.z * kd)) - g);
+    rk.v = fma3(dt, a, rk.v);
+    // a racket that neither spins nor is torqued has zero angular acceleration: skip the
+    // body-frame round trip (Tennisbot rackets until they are hit; every fast-forward substep
+    // of a racket that was never torqued)
+    bool active = (rk.w.x != 0.0f) | (rk.w.y != 0.0f) | (rk.w.z != 0.0f) | (Tr.x != 0.0f) | (Tr.y != 0.0f) | (Tr.z != 0.0f);
+    if (active) {
+      vec3 wb = rotate_inv(rk.q, rk.w), Tb = rotate_inv(rk.q, Tr);
+      vec3 L = mk(P.racket_inertia[0] * wb.x, P.racket_inertia[1] * wb.y, P.racket_inertia[2] * wb.z);
+      vec3 gy = cross(wb, L);
+      float ka = FMA(P.ang_damp, sqrtf(dot(wb, wb)), P.ang_damp);
+      vec3 ab = mk(P.racket_inv_inertia[0] * ((Tb.x - gy.x) - L.x * ka), P.racket_inv_inertia[1] * ((Tb.y - gy.y) - L.y * ka),
+                   P.racket_inv_inertia[2] * ((Tb.z - gy.z) - L.z * ka));
+      rk.w = fma3(dt, rotate(rk.q, ab), rk.w);
+    }
+  }
+  {
+    if (P.magnus_k != 0.0f) Fb = fma3(P.magnus_k, cross(b.w, b.v), Fb);
+    float kd = FMA(P.lin_damp, sqrtf(dot(b.v, b.v)), P.lin_damp);
+    vec3 a = mk(FMA(Fb.x, P.ball_inv_mass, -(b.v.x * kd)), FMA(Fb.y, P.ball_inv_mass, -(b.v.y * kd)),
+                FMA(Fb.z, P.ball_inv_mass, -(b.v.z * kd)) - g);
+    b.v = fma3(dt, a, b.v);
+    bool spinning = (b.w.x != 0.0f) | (b.w.y != 0.0f) | (b.w.z != 0.0f);
+    if (spinning) {
+      float ka = FMA(P.ang_damp, sqrtf(dot(b.w, b.w)), P.ang_damp);
+      vec3 aw = mk(-(b.w.x * ka), -(b.w.y * ka), -(b.w.z * ka));
+      b.w = fma3(dt, aw, b.w);
+    }
+  }
+}
+
+TB_DEV void integrate_pose(const KParams& P, Racket& rk, Ball& b) {
+  const float dt = P.dt;
+  rk.p = fma3(dt, rk.v, rk.p);
+  b.p = fma3(dt, b.v, b.p);
+  float ang = sqrtf(dot(rk.w, rk.w));
+  if (ang > 0.0f) {
+    if (ang * dt > P.max_ang_step) ang = P.max_ang_step * P.inv_dt;
+    float s;
+    if (ang < 0.001f) s = FMA(-(((dt * dt) * dt) * 0.020833333333f), ang * ang, 0.5f * dt);
+    else s = sin_small((0.5f * ang) * dt) / ang;
+    quat dq; dq.x = rk.w.x * s; dq.y = rk.w.y * s; dq.z = rk.w.z * s; dq.w = cos_small((0.5f * ang) * dt);
+    quat q = qmul(dq, rk.q);
+    float inv = 1.0f / sqrtf(FMA(q.w, q.w, FMA(q.z, q.z, FMA(q.y, q.y, q.x * q.x))));
+    rk.q.x = q.x * inv; rk.q.y = q.y * inv; rk.q.z = q.z * inv; rk.q.w = q.w * inv;
+  }
+}
+
+// returns the contact bits of this substep's manifold (the `len(getContactPoints) > 0` tests)
+template <int KIND>
+TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, vec3 Fr, vec3 Tr, vec3 Fb, float goal_x, float goal_y) {
+  int bits = 0;
+  Hit hr; hr.hit = false;
+  if (P.flags & TB_F_RACKET_BALL) hr = sphere_vs_racket(P, hull, rk, b.p);
+  Hit hg = sphere_vs_box(P, P.ground_half[0], P.ground_half[1], P.ground_half[2], b.p);
+  Hit hn; hn.hit = false;
+  if (P.flags & TB_F_NET) hn = sphere_vs_box(P, P.net_half[0], P.net_half[1], P.net_half[2], b.p);
+  Hit hc; hc.hit = false;
+  if (KIND == TB_ENV_SWING) hc = sphere_vs_goal(P, goal_x, goal_y, b.p);
+  if (hr.hit) bits |= CT_RACKET;
+  if (hg.hit) bits |= CT_GROUND;
+  if (hn.hit) bits |= CT_NET;
+  if (hc.hit) bits |= CT_GOAL;
+
+  integrate_velocities(P, rk, b, Fr, Tr, Fb);
+
+  if (bits) {  // rare: only lanes whose ball touches something enter the solver
+    Row rows[4];
+    int nrows = 0;
+    if (bits & CT_RACKET) setup_row(P, rows[nrows++], hr, true, P.rest_racket, P.fric_racket, rk, b);
+    if (bits & CT_GROUND) setup_row(P, rows[nrows++], hg, false, P.rest_court, P.fric_court, rk, b);
+    if (bits & CT_NET) setup_row(P, rows[nrows++], hn, false, P.rest_court, P.fric_court, rk, b);
+    if (bits & CT_GOAL) setup_row(P, rows[nrows++], hc, false, P.rest_goal, P.fric_goal, rk, b);
+    solve_contacts(P, rows, nrows, rk, b);
+  }
+  integrate_pose(P, rk, b);
+  return bits;
+}
+
+}  // namespace tb

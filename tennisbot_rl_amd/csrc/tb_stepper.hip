@@ -1,0 +1,599 @@
+// tb_stepper.hip -- HIP kernels (gfx950 / MI355X) and the C ABI of include/tb_stepper.h.
+//
+// Data layout in HBM (DESIGN.md "Layout"): persistent state is structure-of-arrays along
+// the env index, 32-bit words [W][N] (W = 30 Swing / 27 Tennisbot) plus one done byte [N],
+// so lane i of a wave reads word k at base + (k*N + i)*4: every row access is one fully
+// coalesced 256-B wave transaction. Per-call I/O keeps the caller's natural row-major
+// shapes (actions [N][A], obs [N][O]); a lane's 8/24/48-byte row is read/written with
+// 8- or 16-byte vector accesses and the rows of a wave are contiguous.
+//
+// Kernel shape: one lane = one world, state held in registers for the whole call
+// (including the <= 775-substep SwingRacket fast-forward, swingracket_env.py:105-141, and
+// the T steps of tb_rollout). No inter-lane communication except wave-level counter
+// reductions; no inter-workgroup communication at all, so blockIdx -> XCD placement does
+// not matter for correctness or reuse (there is no shared tile to keep in one L2).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/tb_stepper.h"
+#include "tb_device.hpp"
+
+using namespace tb;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// kernel arguments
+struct KArgs {
+  KParams P;
+  uint32_t* words;        // [W][n]
+  uint8_t* done_state;    // [n]
+  const float4* hull;     // [2 * n_hull] edge records (device global), staged into LDS
+  const float* actions;   // [T][n][A]
+  float* obs;             // [T][n][O]
+  float* reward;          // [T][n]
+  uint8_t* done_out;      // [T][n]
+  float* term_obs;        // [n][O] or null (T == 1 only)
+  int32_t* substeps;      // [n] or null
+  const uint8_t* mask;    // reset kernel: [n] or null
+  unsigned long long* counters;  // [TB_N_COUNTERS]
+  unsigned long long seed, env_id_base;
+  int n, T;
+};
+
+struct EnvRegs {
+  Racket r;
+  Ball b;
+  float aux[6];  // swing: goal.x goal.y spawn.x spawn.y spawn.z d0 ; tennis: shoot force xyz
+  int step_count;
+  uint32_t episode;
+  uint32_t done;
+};
+
+template <int KIND> struct Dims;
+template <> struct Dims<TB_ENV_SWING> { static constexpr int W = TB_SWING_WORDS, A = TB_SWING_ACT_DIM, O = TB_SWING_OBS_DIM, NAUX = 6; };
+template <> struct Dims<TB_ENV_TENNIS> { static constexpr int W = TB_TENNIS_WORDS, A = TB_TENNIS_ACT_DIM, O = TB_TENNIS_OBS_DIM, NAUX = 3; };
+
+TB_DEV float ld(const uint32_t* w, int row, int n, int i) { return __uint_as_float(w[(size_t)row * n + i]); }
+TB_DEV void st(uint32_t* w, int row, int n, int i, float v) { w[(size_t)row * n + i] = __float_as_uint(v); }
+
+template <int KIND>
+TB_DEV void load_env(const KArgs& A, int i, EnvRegs& e) {
+  const uint32_t* w = A.words;
+  const int n = A.n;
+  e.r.p = mk(ld(w, TB_W_RP, n, i), ld(w, TB_W_RP + 1, n, i), ld(w, TB_W_RP + 2, n, i));
+  e.r.q.x = ld(w, TB_W_RQ, n, i); e.r.q.y = ld(w, TB_W_RQ + 1, n, i); e.r.q.z = ld(w, TB_W_RQ + 2, n, i); e.r.q.w = ld(w, TB_W_RQ + 3, n, i);
+  e.r.v = mk(ld(w, TB_W_RV, n, i), ld(w, TB_W_RV + 1, n, i), ld(w, TB_W_RV + 2, n, i));
+  e.r.w = mk(ld(w, TB_W_RW, n, i), ld(w, TB_W_RW + 1, n, i), ld(w, TB_W_RW + 2, n, i));
+  e.b.p = mk(ld(w, TB_W_BP, n, i), ld(w, TB_W_BP + 1, n, i), ld(w, TB_W_BP + 2, n, i));
+  e.b.v = mk(ld(w, TB_W_BV, n, i), ld(w, TB_W_BV + 1, n, i), ld(w, TB_W_BV + 2, n, i));
+  e.b.w = mk(ld(w, TB_W_BW, n, i), ld(w, TB_W_BW + 1, n, i), ld(w, TB_W_BW + 2, n, i));
+#pragma unroll
+  for (int k = 0; k < 6; ++k) e.aux[k] = k < Dims<KIND>::NAUX ? ld(w, 22 + k, n, i) : 0.0f;
+  e.step_count = (int)w[(size_t)(Dims<KIND>::W - 2) * n + i];
+  e.episode = w[(size_t)(Dims<KIND>::W - 1) * n + i];
+  e.done = A.done_state[i];
+}
+
+// `all`: also the rows that only change on reset (goal / spawn / d0 / shoot force / episode)
+template <int KIND>
+TB_DEV void store_env(const KArgs& A, int i, const EnvRegs& e, bool all) {
+  uint32_t* w = A.words;
+  const int n = A.n;
+  st(w, TB_W_RP, n, i, e.r.p.x); st(w, TB_W_RP + 1, n, i, e.r.p.y); st(w, TB_W_RP + 2, n, i, e.r.p.z);
+  st(w, TB_W_RQ, n, i, e.r.q.x); st(w, TB_W_RQ + 1, n, i, e.r.q.y); st(w, TB_W_RQ + 2, n, i, e.r.q.z); st(w, TB_W_RQ + 3, n, i, e.r.q.w);
+  st(w, TB_W_RV, n, i, e.r.v.x); st(w, TB_W_RV + 1, n, i, e.r.v.y); st(w, TB_W_RV + 2, n, i, e.r.v.z);
+  st(w, TB_W_RW, n, i, e.r.w.x); st(w, TB_W_RW + 1, n, i, e.r.w.y); st(w, TB_W_RW + 2, n, i, e.r.w.z);
+  st(w, TB_W_BP, n, i, e.b.p.x); st(w, TB_W_BP + 1, n, i, e.b.p.y); st(w, TB_W_BP + 2, n, i, e.b.p.z);
+  st(w, TB_W_BV, n, i, e.b.v.x); st(w, TB_W_BV + 1, n, i, e.b.v.y); st(w, TB_W_BV + 2, n, i, e.b.v.z);
+  st(w, TB_W_BW, n, i, e.b.w.x); st(w, TB_W_BW + 1, n, i, e.b.w.y); st(w, TB_W_BW + 2, n, i, e.b.w.z);
+  if (all) {
+#pragma unroll
+    for (int k = 0; k < Dims<KIND>::NAUX; ++k) st(w, 22 + k, n, i, e.aux[k]);
+    w[(size_t)(Dims<KIND>::W - 1) * n + i] = e.episode;
+  }
+  w[(size_t)(Dims<KIND>::W - 2) * n + i] = (uint32_t)e.step_count;
+  A.done_state[i] = (uint8_t)e.done;
+}
+
+template <int KIND>
+TB_DEV void make_obs(const EnvRegs& e, float* o) {
+  if (KIND == TB_ENV_SWING) {  // swingracket_env.py:143-144,184-185
+    o[0] = e.r.p.x; o[1] = e.r.p.y; o[2] = e.b.p.x; o[3] = e.b.p.y; o[4] = e.aux[0]; o[5] = e.aux[1];
+  } else {  // tennisbot_env.py:134-136,259-261
+    o[0] = e.r.p.x; o[1] = e.r.p.y; o[2] = e.r.p.z; o[3] = e.r.v.x; o[4] = e.r.v.y; o[5] = e.r.v.z;
+    o[6] = e.b.p.x; o[7] = e.b.p.y; o[8] = e.b.p.z; o[9] = e.b.v.x; o[10] = e.b.v.y; o[11] = e.b.v.z;
+  }
+}
+template <int KIND>
+TB_DEV void write_obs(float* dst, size_t row, const float* o) {
+  if (KIND == TB_ENV_SWING) {  // 24-byte rows: three 8-byte stores
+    float2* p = reinterpret_cast<float2*>(dst + row * 6);
+    p[0] = make_float2(o[0], o[1]); p[1] = make_float2(o[2], o[3]); p[2] = make_float2(o[4], o[5]);
+  } else {  // 48-byte rows: three 16-byte stores
+    float4* p = reinterpret_cast<float4*>(dst + row * 12);
+    p[0] = make_float4(o[0], o[1], o[2], o[3]); p[1] = make_float4(o[4], o[5], o[6], o[7]); p[2] = make_float4(o[8], o[9], o[10], o[11]);
+  }
+}
+
+// reset(): swingracket_env.py:151-186 / tennisbot_env.py:217-261. The world rebuild
+// (resetSimulation + 3-4 loadURDF + STL hull + texture) collapses to re-drawing the state.
+template <int KIND>
+TB_DEV void reset_env(const KArgs& A, int i, EnvRegs& e) {
+  const KParams& P = A.P;
+  unsigned long long id = A.env_id_base + (unsigned long long)i;
+  uint32_t k0 = (uint32_t)A.seed, k1 = (uint32_t)(A.seed >> 32);
+  uint32_t c0 = (uint32_t)id, c1 = (uint32_t)(id >> 32);
+  uint32_t u[4], w[4];
+  philox4x32(c0, c1, e.episode, 0u, k0, k1, u);
+  vec3 zero = mk(0.0f, 0.0f, 0.0f);
+  e.r.v = zero; e.r.w = zero; e.b.v = zero; e.b.w = zero;
+  vec3 com = mk(P.racket_com[0], P.racket_com[1], P.racket_com[2]);
+  uint32_t spin_block;
+  if (KIND == TB_ENV_SWING) {
+    // swingracket_env.py:161-170: link x~U(5.5,11), y~U(-4,4), z=.6, rpy=(0,.5,0); ball (x-.1, y, z+.8)
+    float x = uniform(5.5f, 5.5f, u[0]), y = uniform(-4.0f, 8.0f, u[1]), z = 0.6f;
+    quat q0; q0.x = 0.0f; q0.y = (float)0.24740395925452292; q0.z = 0.0f; q0.w = (float)0.96891242171064473;
+    e.r.q = q0;
+    e.r.p = mk(x, y, z) + rotate(q0, com);  // racket.py:131 reports the COM frame
+    e.b.p = mk(x - 0.1f, y, z + 0.8f);
+    float gx = uniform(-3.0f, -9.0f, u[2]), gy = uniform(-5.0f, 10.0f, u[3]);  // :173
+    e.aux[0] = gx; e.aux[1] = gy; e.aux[2] = x; e.aux[3] = y; e.aux[4] = z;
+    float dx = e.b.p.x - gx, dy = e.b.p.y - gy;
+    e.aux[5] = sqrtf(FMA(dx, dx, dy * dy));  // :174-175
+    spin_block = 1u;
+  } else {
+    // tennisbot_env.py:227-246; objects.py:82-96 (ball born at (-9,0,1))
+    philox4x32(c0, c1, e.episode, 1u, k0, k1, w);
+    float x = uniform(7.5f, 5.0f, u[0]), y = uniform(-5.0f, 10.0f, u[1]), z = uniform(0.2f, 0.21f - 0.2f, u[2]);
+    quat q0; q0.x = 0.0f; q0.y = 0.0f; q0.z = 0.0f; q0.w = 1.0f;
+    e.r.q = q0;
+    e.r.p = mk(x, y, z) + com;
+    e.aux[0] = uniform(25.0f, 12.5f, u[3]);
+    e.aux[1] = uniform(-10.0f, 20.0f, w[0]);
+    e.aux[2] = 20.0f;
+    e.aux[3] = 0.0f; e.aux[4] = 0.0f; e.aux[5] = 0.0f;
+    e.b.p = mk(uniform(-12.0f, 6.0f, w[1]), uniform(-1.0f, 2.0f, w[2]), uniform(1.0f, 0.5f, w[3]));
+    spin_block = 2u;
+  }
+  if (P.ball_spin_max != 0.0f) {  // extension; 0 reproduces the reference
+    philox4x32(c0, c1, e.episode, spin_block, k0, k1, w);
+    float m = P.ball_spin_max;
+    e.b.w = mk(uniform(-m, 2.0f * m, w[0]), uniform(-m, 2.0f * m, w[1]), uniform(-m, 2.0f * m, w[2]));
+  }
+  e.step_count = 0;
+  e.done = TB_DONE_NO;
+}
+
+// swingracket_env.py:63-73
+TB_DEV float moved_dist_to_goal(const EnvRegs& e) {
+  float dx = e.b.p.x - e.aux[0], dy = e.b.p.y - e.aux[1];
+  float d = sqrtf(FMA(dx, dx, dy * dy));
+  return ((e.aux[5] - d) / e.aux[5]) * 20.0f;
+}
+TB_DEV vec3 restoring_force(const EnvRegs& e) {  // swingracket_env.py:135-141
+  return mk(-50.0f * (e.r.p.x - e.aux[2]), -2.0f * (e.r.p.y - e.aux[3]), -2.0f * ((e.r.p.z - e.aux[4]) - 4.0f));
+}
+
+// swingracket_env.py:75-145
+TB_DEV float swing_step(const KParams& P, const float4* hull, EnvRegs& e, const float* a, int& ns, uint32_t* cnt) {
+  vec3 F = mk(a[0] * 400.0f, a[1] * 400.0f, FMA(a[2], 400.0f, 4.0f * 9.81f));  // :76-77
+  vec3 T = mk(a[3] * 5.0f, a[4] * 5.0f, a[5] * 5.0f);                          // :78
+  const vec3 zero = mk(0.0f, 0.0f, 0.0f);
+  if (e.done == TB_DONE_PENDING_FORCE) {  // the force of :135-141 is still in the accumulator
+    F = F + restoring_force(e);
+    e.done = TB_DONE_YES;
+  }
+  int bits = substep<TB_ENV_SWING>(P, hull, e.r, e.b, F, T, zero, e.aux[0], e.aux[1]);  // :82
+  e.step_count += 1;                                                                      // :83
+  ns = 1;
+  float reward = 0.0f;
+  if (bits & CT_RACKET) cnt[0]++;
+  if (e.step_count < 25 && (bits & CT_RACKET)) reward += 2.0f;  // :98-101
+  if (e.step_count > 25) {                                      // :105
+    vec3 Fp = zero;  // the substep above cleared the accumulated forces
+    while (!e.done) {  // :106 -- per-lane loop; the wave leaves when its last lane is done
+      bits = substep<TB_ENV_SWING>(P, hull, e.r, e.b, Fp, zero, zero, e.aux[0], e.aux[1]);  // :107
+      e.step_count += 1; ns++;
+      if (bits & CT_RACKET) cnt[0]++;
+      if (bits & (CT_GROUND | CT_NET)) { e.done = TB_DONE_PENDING_FORCE; reward += moved_dist_to_goal(e); cnt[1]++; }  // :111-114
+      if (bits & CT_GOAL) { reward += moved_dist_to_goal(e); reward += 50.0f; e.done = TB_DONE_PENDING_FORCE; cnt[2]++; }  // :119-123
+      if (e.step_count > 800) { if (!e.done) cnt[3]++; e.done = TB_DONE_PENDING_FORCE; }  // :127-128
+      Fp = restoring_force(e);  // :135-141
+    }
+  }
+  return reward;
+}
+
+// tennisbot_env.py:90-102
+TB_DEV float dist_to_reward(float d) {
+  return d < 0.5f ? 20.0f : d < 1.0f ? 15.0f : d < 2.0f ? 10.0f : d < 3.0f ? 5.0f : d < 4.0f ? 1.0f : 0.0f;
+}
+
+// tennisbot_env.py:104-207 (the DELAY_MODE sleep at :124-126 is dropped on purpose)
+TB_DEV float tennis_step(const KParams& P, const float4* hull, EnvRegs& e, const float* a, float* obs, bool& ret_done, uint32_t* cnt) {
+  const vec3 zero = mk(0.0f, 0.0f, 0.0f);
+  vec3 F = mk(a[0] * 10.0f, a[1] * 10.0f, 4.0f * 9.81f);  // :112-115
+  vec3 Fb = zero;
+  if (e.step_count < 5) Fb = mk(e.aux[0], e.aux[1], e.aux[2]);  // :118-119
+  int bits = substep<TB_ENV_TENNIS>(P, hull, e.r, e.b, F, zero, Fb, 0.0f, 0.0f);  // :121
+  e.step_count += 1;                                                                // :122
+  if (bits & CT_RACKET) cnt[0]++;
+  make_obs<TB_ENV_TENNIS>(e, obs);  // :134-136
+  float reward = 0.0f;
+  ret_done = false;
+  if (e.step_count < 5) return reward;  // :138-139 returns the literal False
+  float dz = e.b.p.z - e.r.p.z, dy = e.b.p.y - e.r.p.y;
+  float delta = sqrtf(FMA(dz, dz, dy * dy));  // :142-143
+  if (bits & CT_RACKET) { reward += 25.0f; reward += dist_to_reward(delta); }  // :170-174
+  if (!(e.b.p.x - e.r.p.x < 0.5f)) {  // :182-194
+    if (!e.done) cnt[4]++;
+    e.done = TB_DONE_YES;
+    reward += dist_to_reward(delta);
+  }
+  // :197-198 `3 > x > 15` is never true
+  if (e.step_count > 1000) { if (!e.done) cnt[3]++; e.done = TB_DONE_YES; }  // :201-203
+  ret_done = e.done != TB_DONE_NO;
+  return reward;
+}
+
+TB_DEV bool finite3(vec3 v) { return isfinite(v.x) && isfinite(v.y) && isfinite(v.z); }
+
+// wave-level sum of per-lane event counts; one atomic per wave and counter that is non-zero
+TB_DEV void flush_counters(unsigned long long* counters, const uint32_t* cnt) {
+#pragma unroll
+  for (int k = 0; k < TB_N_COUNTERS; ++k) {
+    uint32_t v = cnt[k];
+    if (__ballot(v != 0) == 0ull) continue;  // wave-uniform skip: most counters are zero most steps
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&counters[k], (unsigned long long)v);
+  }
+}
+
+TB_DEV void stage_hull(float4* s_hull, const KArgs& A) {
+  for (int k = threadIdx.x; k < 2 * A.P.n_hull; k += blockDim.x) s_hull[k] = A.hull[k];
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// step / rollout kernel: T agent steps of every env, state in registers throughout
+template <int KIND>
+__global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
+  constexpr int NA = Dims<KIND>::A, NO = Dims<KIND>::O;
+  __shared__ float4 s_hull[TB_MAX_HULL * 2];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < A.n;
+  EnvRegs e;
+  if (live) load_env<KIND>(A, i, e);  // issue the state loads first; the outline staging overlaps them
+  stage_hull(s_hull, A);
+
+  uint32_t cnt[TB_N_COUNTERS];
+#pragma unroll
+  for (int k = 0; k < TB_N_COUNTERS; ++k) cnt[k] = 0u;
+
+  if (live) {
+    bool any_reset = false;
+    int ns_total = 0;
+    for (int t = 0; t < A.T; ++t) {
+      const size_t row = (size_t)t * A.n + i;
+      float a[NA];
+      if (KIND == TB_ENV_SWING) {
+        const float2* ap = reinterpret_cast<const float2*>(A.actions + row * 6);
+        float2 a0 = ap[0], a1 = ap[1], a2 = ap[2];
+        a[0] = a0.x; a[1] = a0.y; a[2] = a1.x; a[3] = a1.y; a[4] = a2.x; a[5] = a2.y;
+      } else {
+        float2 a0 = *reinterpret_cast<const float2*>(A.actions + row * 2);
+        a[0] = a0.x; a[1] = a0.y;
+      }
+      float o[NO];
+      int ns = 1;
+      bool d;
+      float rew;
+      if (KIND == TB_ENV_SWING) {
+        rew = swing_step(A.P, s_hull, e, a, ns, cnt);
+        make_obs<TB_ENV_SWING>(e, o);
+        d = e.done != TB_DONE_NO;  // swingracket_env.py:145 returns self.done
+      } else {
+        rew = tennis_step(A.P, s_hull, e, a, o, d, cnt);
+      }
+      cnt[6] += (uint32_t)ns;
+      ns_total += ns;
+      if (!(finite3(e.r.p) && finite3(e.r.v) && finite3(e.r.w) && finite3(e.b.p) && finite3(e.b.v) && finite3(e.b.w) &&
+            isfinite(e.r.q.x) && isfinite(e.r.q.y) && isfinite(e.r.q.z) && isfinite(e.r.q.w)))
+        cnt[7]++;
+      if (d && (A.P.flags & TB_F_AUTO_RESET)) {
+        cnt[5]++;
+        if (A.term_obs) write_obs<KIND>(A.term_obs, (size_t)i, o);
+        e.episode += 1u;
+        reset_env<KIND>(A, i, e);
+        make_obs<KIND>(e, o);
+        any_reset = true;
+      }
+      write_obs<KIND>(A.obs, row, o);
+      A.reward[row] = rew;
+      A.done_out[row] = d ? 1 : 0;
+    }
+    if (A.substeps) A.substeps[i] = ns_total;
+    store_env<KIND>(A, i, e, any_reset);
+  }
+  flush_counters(A.counters, cnt);
+}
+
+// reset kernel (masked)
+template <int KIND>
+__global__ void __launch_bounds__(256) tb_reset_kernel(KArgs A) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= A.n) return;
+  if (A.mask && !A.mask[i]) return;
+  EnvRegs e;
+  e.episode = A.words[(size_t)(Dims<KIND>::W - 1) * A.n + i] + 1u;
+  reset_env<KIND>(A, i, e);
+  store_env<KIND>(A, i, e, true);
+  if (A.obs) {
+    float o[Dims<KIND>::O];
+    make_obs<KIND>(e, o);
+    write_obs<KIND>(A.obs, (size_t)i, o);
+  }
+}
+
+// identity orientation, episode = -1 so that the first reset starts episode 0
+__global__ void tb_init_kernel(uint32_t* words, uint8_t* done, int n, int nwords) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int k = 0; k < nwords; ++k) words[(size_t)k * n + i] = 0u;
+  words[(size_t)(TB_W_RQ + 3) * n + i] = __float_as_uint(1.0f);
+  words[(size_t)(nwords - 1) * n + i] = 0xFFFFFFFFu;
+  done[i] = TB_DONE_NO;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* what) {
+  if (code > 0) snprintf(g_err, sizeof g_err, "%s: %s (%s)", what, hipGetErrorString((hipError_t)code), hipGetErrorName((hipError_t)code));
+  else snprintf(g_err, sizeof g_err, "%s", what);
+  return code;
+}
+#define HIP_TRY(expr)                                              \
+  do {                                                             \
+    hipError_t _e = (expr);                                        \
+    if (_e != hipSuccess) return fail((int)_e, #expr);             \
+  } while (0)
+
+struct DeviceGuard {  // calls run on the handle's device without disturbing the caller's current device
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) { err = hipSetDevice(dev); switched = err == hipSuccess; }
+  }
+  ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+
+bool kind_ok(int k) { return k == TB_ENV_SWING || k == TB_ENV_TENNIS; }
+
+int validate_params(const TbParams* p) {
+  if (p->n_hull < 3 || p->n_hull > TB_MAX_HULL) return fail(TB_E_PARAMS, "TbParams.n_hull must be in [3, 64]");
+  if (!(p->dt > 0.0f) || !(p->inv_dt > 0.0f)) return fail(TB_E_PARAMS, "TbParams.dt / inv_dt must be positive");
+  if (!(p->racket_inv_mass > 0.0f) || !(p->ball_inv_mass > 0.0f) || !(p->ball_inv_inertia > 0.0f)) return fail(TB_E_PARAMS, "TbParams masses must be positive");
+  for (int i = 0; i < 3; ++i)
+    if (!(p->racket_inertia[i] > 0.0f) || !(p->racket_inv_inertia[i] > 0.0f)) return fail(TB_E_PARAMS, "TbParams.racket_inertia must be positive");
+  if (!(p->ball_radius > 0.0f) || !(p->contact_threshold >= 0.0f)) return fail(TB_E_PARAMS, "TbParams.ball_radius / contact_threshold invalid");
+  if (p->solver_iters < 1 || p->solver_iters > 1000) return fail(TB_E_PARAMS, "TbParams.solver_iters must be in [1, 1000]");
+  return TB_OK;
+}
+
+void to_kparams(const TbParams* p, KParams* k) {
+  k->dt = p->dt; k->inv_dt = p->inv_dt; k->gravity = p->gravity; k->lin_damp = p->lin_damp; k->ang_damp = p->ang_damp;
+  k->max_ang_step = p->max_ang_step; k->rest_vel_threshold = p->rest_vel_threshold; k->erp = p->erp;
+  k->contact_threshold = p->contact_threshold; k->solver_iters = p->solver_iters; k->flags = p->flags;
+  k->racket_inv_mass = p->racket_inv_mass;
+  for (int i = 0; i < 3; ++i) {
+    k->racket_inertia[i] = p->racket_inertia[i]; k->racket_inv_inertia[i] = p->racket_inv_inertia[i];
+    k->racket_com[i] = p->racket_com[i]; k->ground_half[i] = p->ground_half[i]; k->net_half[i] = p->net_half[i];
+  }
+  k->racket_half_thick = p->racket_half_thick; k->hull_margin = p->hull_margin; k->hull_bound_radius = p->hull_bound_radius;
+  k->ball_inv_mass = p->ball_inv_mass; k->ball_inv_inertia = p->ball_inv_inertia; k->ball_radius = p->ball_radius;
+  k->magnus_k = p->magnus_k; k->ball_spin_max = p->ball_spin_max;
+  k->rest_racket = p->rest_racket; k->rest_court = p->rest_court; k->rest_goal = p->rest_goal;
+  k->fric_racket = p->fric_racket; k->fric_court = p->fric_court; k->fric_goal = p->fric_goal;
+  k->goal_radius = p->goal_radius; k->goal_half_len = p->goal_half_len;
+  k->n_hull = p->n_hull;
+}
+
+}  // namespace
+
+struct TbHandle {
+  int device, kind, n, block;
+  uint64_t seed, env_id_base;
+  TbParams params;
+  KParams kp;
+  uint32_t* d_words;
+  uint8_t* d_done;
+  float4* d_hull;
+  float4* h_hull;  // pinned staging copy of the outline table
+  unsigned long long* d_counters;
+};
+
+namespace {
+
+int words_of(int kind) { return kind == TB_ENV_SWING ? TB_SWING_WORDS : TB_TENNIS_WORDS; }
+
+// small batches: one wave per workgroup so the waves spread over as many CUs as possible
+// (4096 envs = 64 waves -> 64 CUs); large batches: 256-thread workgroups amortise the LDS staging
+int pick_block(int n) {
+  const char* env = getenv("TB_BLOCK");
+  if (env) { int b = atoi(env); if (b == 64 || b == 128 || b == 256) return b; }
+  return n <= 131072 ? 64 : 256;
+}
+
+KArgs base_args(const TbHandle* h) {
+  KArgs a;
+  memset(&a, 0, sizeof a);
+  a.P = h->kp; a.words = h->d_words; a.done_state = h->d_done; a.hull = h->d_hull; a.counters = h->d_counters;
+  a.seed = h->seed; a.env_id_base = h->env_id_base; a.n = h->n; a.T = 1;
+  return a;
+}
+
+int upload_hull(TbHandle* h, hipStream_t s) {
+  memcpy(h->h_hull, h->params.hull_edges, sizeof(float) * TB_HULL_REC * TB_MAX_HULL);
+  HIP_TRY(hipMemcpyAsync(h->d_hull, h->h_hull, sizeof(float) * TB_HULL_REC * TB_MAX_HULL, hipMemcpyHostToDevice, s));
+  return TB_OK;
+}
+
+int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* reward, uint8_t* done, float* term, int32_t* substeps, hipStream_t s) {
+  KArgs a = base_args(h);
+  a.actions = actions; a.obs = obs; a.reward = reward; a.done_out = done; a.term_obs = term; a.substeps = substeps; a.T = T;
+  dim3 grid((unsigned)((h->n + h->block - 1) / h->block)), block((unsigned)h->block);
+  if (h->kind == TB_ENV_SWING) hipLaunchKernelGGL(tb_step_kernel<TB_ENV_SWING>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(tb_step_kernel<TB_ENV_TENNIS>, grid, block, 0, s, a);
+  HIP_TRY(hipGetLastError());
+  return TB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tb_abi_version(void) { return TB_ABI_VERSION; }
+int tb_obs_dim(int k) { return k == TB_ENV_SWING ? TB_SWING_OBS_DIM : k == TB_ENV_TENNIS ? TB_TENNIS_OBS_DIM : TB_E_INVAL; }
+int tb_act_dim(int k) { return k == TB_ENV_SWING ? TB_SWING_ACT_DIM : k == TB_ENV_TENNIS ? TB_TENNIS_ACT_DIM : TB_E_INVAL; }
+int tb_state_words(int k) { return kind_ok(k) ? words_of(k) : TB_E_INVAL; }
+const char* tb_last_error(void) { return g_err; }
+
+int tb_create(const TbParams* params, int env_kind, int n_envs, int device, uint64_t seed, uint64_t env_id_base, TbHandle** out) {
+  if (!params || !out) return fail(TB_E_INVAL, "tb_create: null argument");
+  *out = nullptr;
+  if (!kind_ok(env_kind)) return fail(TB_E_INVAL, "tb_create: unknown env kind");
+  if (n_envs <= 0 || n_envs > (1 << 26)) return fail(TB_E_INVAL, "tb_create: n_envs must be in [1, 2^26]");
+  if (int rc = validate_params(params)) return rc;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) return fail(TB_E_NODEVICE, "tb_create: no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(TB_E_NODEVICE, "tb_create: device index out of range");
+  DeviceGuard g(device);
+  if (g.err != hipSuccess) return fail((int)g.err, "hipSetDevice");
+
+  TbHandle* h = (TbHandle*)calloc(1, sizeof(TbHandle));
+  if (!h) return fail(TB_E_INVAL, "tb_create: out of host memory");
+  h->device = device; h->kind = env_kind; h->n = n_envs; h->seed = seed; h->env_id_base = env_id_base;
+  h->params = *params; to_kparams(params, &h->kp); h->block = pick_block(n_envs);
+  const int nw = words_of(env_kind);
+  hipError_t err;
+#define CREATE_TRY(expr) if ((err = (expr)) != hipSuccess) { int rc = fail((int)err, #expr); tb_destroy(h); return rc; }
+  CREATE_TRY(hipMalloc((void**)&h->d_words, sizeof(uint32_t) * (size_t)nw * n_envs));
+  CREATE_TRY(hipMalloc((void**)&h->d_done, (size_t)n_envs));
+  CREATE_TRY(hipMalloc((void**)&h->d_hull, sizeof(float) * TB_HULL_REC * TB_MAX_HULL));
+  CREATE_TRY(hipHostMalloc((void**)&h->h_hull, sizeof(float) * TB_HULL_REC * TB_MAX_HULL, hipHostMallocDefault));
+  CREATE_TRY(hipMalloc((void**)&h->d_counters, sizeof(unsigned long long) * TB_N_COUNTERS));
+  CREATE_TRY(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * TB_N_COUNTERS, 0));
+  hipLaunchKernelGGL(tb_init_kernel, dim3((unsigned)((n_envs + 255) / 256)), dim3(256), 0, 0, h->d_words, h->d_done, n_envs, nw);
+  CREATE_TRY(hipGetLastError());
+  if (int rc = upload_hull(h, 0)) { tb_destroy(h); return rc; }
+  CREATE_TRY(hipStreamSynchronize(0));
+#undef CREATE_TRY
+  *out = h;
+  return TB_OK;
+}
+
+int tb_destroy(TbHandle* h) {
+  if (!h) return TB_OK;
+  DeviceGuard g(h->device);
+  (void)hipDeviceSynchronize();
+  if (h->d_words) (void)hipFree(h->d_words);
+  if (h->d_done) (void)hipFree(h->d_done);
+  if (h->d_hull) (void)hipFree(h->d_hull);
+  if (h->h_hull) (void)hipHostFree(h->h_hull);
+  if (h->d_counters) (void)hipFree(h->d_counters);
+  free(h);
+  return TB_OK;
+}
+
+int tb_set_params(TbHandle* h, const TbParams* params, void* stream) {
+  if (!h || !params) return fail(TB_E_INVAL, "tb_set_params: null argument");
+  if (int rc = validate_params(params)) return rc;
+  DeviceGuard g(h->device);
+  hipStream_t s = (hipStream_t)stream;
+  // the staging buffer may still feed an earlier async copy on another stream: settle it first
+  HIP_TRY(hipStreamSynchronize(s));
+  h->params = *params;
+  to_kparams(params, &h->kp);
+  if (int rc = upload_hull(h, s)) return rc;
+  HIP_TRY(hipStreamSynchronize(s));
+  return TB_OK;
+}
+
+int tb_reset(TbHandle* h, const uint8_t* mask_dev, float* obs_dev, void* stream) {
+  if (!h) return fail(TB_E_INVAL, "tb_reset: null handle");
+  DeviceGuard g(h->device);
+  KArgs a = base_args(h);
+  a.mask = mask_dev; a.obs = obs_dev;
+  dim3 grid((unsigned)((h->n + 255) / 256)), block(256);
+  if (h->kind == TB_ENV_SWING) hipLaunchKernelGGL(tb_reset_kernel<TB_ENV_SWING>, grid, block, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(tb_reset_kernel<TB_ENV_TENNIS>, grid, block, 0, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
+  return TB_OK;
+}
+
+int tb_step(TbHandle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, float* terminal_obs_dev,
+            int32_t* substeps_dev, void* stream) {
+  if (!h || !actions_dev || !obs_dev || !reward_dev || !done_dev) return fail(TB_E_INVAL, "tb_step: null argument");
+  DeviceGuard g(h->device);
+  return launch_step(h, 1, actions_dev, obs_dev, reward_dev, done_dev, terminal_obs_dev, substeps_dev, (hipStream_t)stream);
+}
+
+int tb_rollout(TbHandle* h, int n_steps, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev,
+               int32_t* substeps_total_dev, void* stream) {
+  if (!h || !actions_dev || !obs_dev || !reward_dev || !done_dev) return fail(TB_E_INVAL, "tb_rollout: null argument");
+  if (n_steps < 1) return fail(TB_E_INVAL, "tb_rollout: n_steps must be >= 1");
+  if (!(h->kp.flags & TB_F_AUTO_RESET)) return fail(TB_E_UNSUPPORTED, "tb_rollout needs TB_F_AUTO_RESET (episodes must restart inside the launch)");
+  DeviceGuard g(h->device);
+  return launch_step(h, n_steps, actions_dev, obs_dev, reward_dev, done_dev, nullptr, substeps_total_dev, (hipStream_t)stream);
+}
+
+int tb_get_state(TbHandle* h, uint32_t* words, uint8_t* done, int on_device, void* stream) {
+  if (!h || !words) return fail(TB_E_INVAL, "tb_get_state: null argument");
+  DeviceGuard g(h->device);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t wb = sizeof(uint32_t) * (size_t)words_of(h->kind) * h->n;
+  hipMemcpyKind k = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  HIP_TRY(hipMemcpyAsync(words, h->d_words, wb, k, s));
+  if (done) HIP_TRY(hipMemcpyAsync(done, h->d_done, (size_t)h->n, k, s));
+  if (!on_device) HIP_TRY(hipStreamSynchronize(s));
+  return TB_OK;
+}
+
+int tb_set_state(TbHandle* h, const uint32_t* words, const uint8_t* done, int on_device, void* stream) {
+  if (!h || !words) return fail(TB_E_INVAL, "tb_set_state: null argument");
+  DeviceGuard g(h->device);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t wb = sizeof(uint32_t) * (size_t)words_of(h->kind) * h->n;
+  hipMemcpyKind k = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  HIP_TRY(hipMemcpyAsync(h->d_words, words, wb, k, s));
+  if (done) HIP_TRY(hipMemcpyAsync(h->d_done, done, (size_t)h->n, k, s));
+  else HIP_TRY(hipMemsetAsync(h->d_done, 0, (size_t)h->n, s));
+  if (!on_device) HIP_TRY(hipStreamSynchronize(s));
+  return TB_OK;
+}
+
+int tb_counters(TbHandle* h, uint64_t* out, void* stream) {
+  if (!h || !out) return fail(TB_E_INVAL, "tb_counters: null argument");
+  DeviceGuard g(h->device);
+  HIP_TRY(hipMemcpyAsync(out, h->d_counters, sizeof(uint64_t) * TB_N_COUNTERS, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return TB_OK;
+}
+
+int tb_counters_reset(TbHandle* h, void* stream) {
+  if (!h) return fail(TB_E_INVAL, "tb_counters_reset: null handle");
+  DeviceGuard g(h->device);
+  HIP_TRY(hipMemsetAsync(h->d_counters, 0, sizeof(uint64_t) * TB_N_COUNTERS, (hipStream_t)stream));
+  return TB_OK;
+}
+
+}  // extern "C"

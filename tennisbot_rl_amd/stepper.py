@@ -1,0 +1,271 @@
+"""Tensor API over the C ABI (include/tb_stepper.h): N independent (racket, ball) worlds
+stepped in lockstep on one MI355X.
+
+This is the measured path: `step(actions)` takes and returns device tensors and never
+synchronises with the host. torch is used for device memory and streams only; all
+arithmetic happens in libtb_stepper.so (hand-written HIP, csrc/tb_stepper.hip). There is
+no CPU or eager-PyTorch fallback: if the library or a GPU is missing, construction raises.
+
+Reference counterparts: `SwingRacketEnv` (tennisbot/envs/swingracket_env.py:24-192) and
+`TennisbotEnv` (tennisbot/envs/tennisbot_env.py:27-291), one PyBullet world each.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from .params import (ACT_DIM, COUNTER_NAMES, ENV_SWING, ENV_TENNIS, F_AUTO_RESET, F_DEFAULT, N_COUNTERS, OBS_DIM,
+                     STATE_ROWS, STATE_WORDS, TbParams, default_params)
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtb_stepper.so")
+_LIB = None
+
+ENV_IDS = {"SwingRacket-v0": ENV_SWING, "Tennisbot-v0": ENV_TENNIS}  # tennisbot/__init__.py:3-11
+
+
+class StepperError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """dlopen the HIP library. Fails loudly: the product has no fallback path."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(_LIB_PATH):
+        raise StepperError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % _LIB_PATH)
+    L = ctypes.CDLL(_LIB_PATH)
+    vp, i32, u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64
+    L.tb_abi_version.restype = i32
+    L.tb_obs_dim.argtypes = [i32]
+    L.tb_act_dim.argtypes = [i32]
+    L.tb_state_words.argtypes = [i32]
+    L.tb_last_error.restype = ctypes.c_char_p
+    L.tb_create.argtypes = [ctypes.POINTER(TbParams), i32, i32, i32, u64, u64, ctypes.POINTER(vp)]
+    L.tb_destroy.argtypes = [vp]
+    L.tb_set_params.argtypes = [vp, ctypes.POINTER(TbParams), vp]
+    L.tb_reset.argtypes = [vp, vp, vp, vp]
+    L.tb_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.tb_rollout.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
+    L.tb_get_state.argtypes = [vp, vp, vp, i32, vp]
+    L.tb_set_state.argtypes = [vp, vp, vp, i32, vp]
+    L.tb_counters.argtypes = [vp, vp, vp]
+    L.tb_counters_reset.argtypes = [vp, vp]
+    for f in ("tb_create", "tb_destroy", "tb_set_params", "tb_reset", "tb_step", "tb_rollout", "tb_get_state",
+              "tb_set_state", "tb_counters", "tb_counters_reset", "tb_obs_dim", "tb_act_dim", "tb_state_words"):
+        getattr(L, f).restype = i32
+    if L.tb_abi_version() != 1:
+        raise StepperError("libtb_stepper.so ABI version %d, expected 1" % L.tb_abi_version())
+    for kind in (ENV_SWING, ENV_TENNIS):
+        assert L.tb_obs_dim(kind) == OBS_DIM[kind] and L.tb_act_dim(kind) == ACT_DIM[kind]
+        assert L.tb_state_words(kind) == STATE_WORDS[kind]
+    _LIB = L
+    return L
+
+
+def _check(L, rc, what):
+    if rc != 0:
+        raise StepperError("%s failed (%d): %s" % (what, rc, L.tb_last_error().decode()))
+
+
+class BatchedEnv:
+    """N lockstep worlds of one env kind on one GPU.
+
+    step(actions) -> (obs, reward, done): float32 [N, O], float32 [N], uint8 [N] device tensors.
+    With auto_reset (default, SB3 VecEnv semantics) an env that finishes is reset inside the
+    same kernel: `obs` then holds the first observation of the new episode and
+    `terminal_obs()` the last one of the old episode. With auto_reset=False `done` is sticky
+    until reset(), exactly like the reference's `self.done`.
+    """
+
+    def __init__(self, env_kind, num_envs, device=None, seed=0, env_id_base=0, params=None, auto_reset=True,
+                 reuse_buffers=False, track_terminal_obs=True):
+        import torch
+        self.torch = torch
+        if isinstance(env_kind, str):
+            env_kind = ENV_IDS[env_kind]
+        if env_kind not in (ENV_SWING, ENV_TENNIS):
+            raise ValueError("unknown env kind %r" % (env_kind,))
+        self.L = load_library()
+        if not torch.cuda.is_available():
+            raise StepperError("no GPU visible to torch: the batched stepper is HIP-only (no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.type != "cuda":
+            raise StepperError("device must be a cuda (ROCm) device, got %s" % self.device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.kind, self.num_envs = env_kind, int(num_envs)
+        self.obs_dim, self.act_dim, self.words = OBS_DIM[env_kind], ACT_DIM[env_kind], STATE_WORDS[env_kind]
+        self.seed, self.env_id_base = int(seed), int(env_id_base)
+        p = (params or default_params()).copy()
+        p.flags = (p.flags | F_AUTO_RESET) if auto_reset else (p.flags & ~F_AUTO_RESET)
+        self.params = p
+        self.auto_reset = bool(auto_reset)
+        self.reuse_buffers = bool(reuse_buffers)
+        self._h = ctypes.c_void_p()
+        _check(self.L, self.L.tb_create(ctypes.byref(p), env_kind, self.num_envs, self.device.index, self.seed,
+                                        self.env_id_base, ctypes.byref(self._h)), "tb_create")
+        n, o = self.num_envs, self.obs_dim
+        self._term = torch.zeros((n, o), dtype=torch.float32, device=self.device) if (auto_reset and track_terminal_obs) else None
+        self._substeps = torch.zeros(n, dtype=torch.int32, device=self.device)
+        self._bufs = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _out(self, T=None):
+        t, n, o = self.torch, self.num_envs, self.obs_dim
+        lead = (n,) if T is None else (T, n)
+        if self.reuse_buffers and T is None:
+            if self._bufs is None:
+                self._bufs = (t.empty(lead + (o,), dtype=t.float32, device=self.device),
+                              t.empty(lead, dtype=t.float32, device=self.device),
+                              t.empty(lead, dtype=t.uint8, device=self.device))
+            return self._bufs
+        return (t.empty(lead + (o,), dtype=t.float32, device=self.device), t.empty(lead, dtype=t.float32, device=self.device),
+                t.empty(lead, dtype=t.uint8, device=self.device))
+
+    def _check_tensor(self, x, shape, dtype, name):
+        t = self.torch
+        if not isinstance(x, t.Tensor):
+            raise TypeError("%s must be a torch tensor" % name)
+        if x.device != self.device:
+            raise ValueError("%s is on %s, the env batch lives on %s" % (name, x.device, self.device))
+        if x.dtype != dtype:
+            raise TypeError("%s must be %s, got %s" % (name, dtype, x.dtype))
+        if tuple(x.shape) != tuple(shape):
+            raise ValueError("%s must have shape %s, got %s" % (name, tuple(shape), tuple(x.shape)))
+        if not x.is_contiguous():
+            raise ValueError("%s must be contiguous" % name)
+        return x
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.L.tb_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ env surface
+    def reset(self, mask=None):
+        """Start a new episode in every env (or those with mask != 0). Returns obs [N, O]."""
+        t = self.torch
+        obs = t.empty((self.num_envs, self.obs_dim), dtype=t.float32, device=self.device)
+        if mask is not None:
+            mask = self._check_tensor(mask.to(t.uint8) if mask.dtype == t.bool else mask, (self.num_envs,), t.uint8, "mask")
+            # unmasked rows keep their current observation
+            obs.copy_(self.observe())
+        _check(self.L, self.L.tb_reset(self._h, None if mask is None else mask.data_ptr(), obs.data_ptr(), self._stream()), "tb_reset")
+        return obs
+
+    def step(self, actions):
+        t = self.torch
+        a = self._check_tensor(actions, (self.num_envs, self.act_dim), t.float32, "actions")
+        obs, rew, done = self._out()
+        _check(self.L, self.L.tb_step(self._h, a.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(),
+                                      None if self._term is None else self._term.data_ptr(), self._substeps.data_ptr(),
+                                      self._stream()), "tb_step")
+        return obs, rew, done
+
+    def rollout(self, actions):
+        """T steps in one launch: actions [T, N, A] -> obs [T, N, O], reward [T, N], done [T, N]."""
+        t = self.torch
+        if actions.dim() != 3:
+            raise ValueError("actions must be [T, N, A]")
+        T = int(actions.shape[0])
+        a = self._check_tensor(actions, (T, self.num_envs, self.act_dim), t.float32, "actions")
+        obs, rew, done = self._out(T)
+        _check(self.L, self.L.tb_rollout(self._h, T, a.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(),
+                                         self._substeps.data_ptr(), self._stream()), "tb_rollout")
+        return obs, rew, done
+
+    def terminal_obs(self):
+        """[N, O]: for envs whose episode ended in the latest step, its final observation."""
+        if self._term is None:
+            raise StepperError("terminal observations are only tracked with auto_reset=True")
+        return self._term
+
+    def last_substeps(self):
+        """int32 [N]: physics substeps executed by the latest step()/rollout() call."""
+        return self._substeps
+
+    def observe(self):
+        """Current observation rebuilt from the state (no stepping)."""
+        t = self.torch
+        w, _ = self.get_state_words()
+        f = w.view(t.float32)
+        if self.kind == ENV_SWING:
+            rows = [0, 1, 13, 14, 22, 23]
+        else:
+            rows = [0, 1, 2, 7, 8, 9, 13, 14, 15, 16, 17, 18]
+        return f[rows].t().contiguous()
+
+    def set_params(self, params):
+        p = params.copy()
+        p.flags = (p.flags | F_AUTO_RESET) if self.auto_reset else (p.flags & ~F_AUTO_RESET)
+        _check(self.L, self.L.tb_set_params(self._h, ctypes.byref(p), self._stream()), "tb_set_params")
+        self.params = p
+
+    def set_racket_scale(self, scale):
+        """tennisbot_env.py:213-215: takes effect at the next reset of each env (the reference
+        rebuilds the racket with globalScaling=scale in reset(), :230-234)."""
+        self.set_params(default_params(racket_scale=scale, flags=self.params.flags))
+
+    # ------------------------------------------------------------------ state save / restore
+    def get_state_words(self):
+        t = self.torch
+        w = t.empty((self.words, self.num_envs), dtype=t.int32, device=self.device)
+        d = t.empty(self.num_envs, dtype=t.uint8, device=self.device)
+        _check(self.L, self.L.tb_get_state(self._h, w.data_ptr(), d.data_ptr(), 1, self._stream()), "tb_get_state")
+        return w, d
+
+    def set_state_words(self, words, done=None):
+        t = self.torch
+        w = words if isinstance(words, t.Tensor) else t.from_numpy(np.ascontiguousarray(words).view(np.int32))
+        w = self._check_tensor(w.to(self.device).contiguous(), (self.words, self.num_envs), t.int32, "words")
+        dptr = None
+        if done is not None:
+            d = done if isinstance(done, t.Tensor) else t.from_numpy(np.ascontiguousarray(done, np.uint8))
+            d = self._check_tensor(d.to(self.device).contiguous(), (self.num_envs,), t.uint8, "done")
+            dptr = d.data_ptr()
+        _check(self.L, self.L.tb_set_state(self._h, w.data_ptr(), dptr, 1, self._stream()), "tb_set_state")
+        self.torch.cuda.current_stream(self.device).synchronize()  # the source tensors may be temporaries
+
+    def get_state(self):
+        """dict of named numpy arrays (host copy): the env checkpoint the reference never had."""
+        w, d = self.get_state_words()
+        w = w.cpu().numpy().view(np.uint32)
+        names = STATE_ROWS[self.kind]
+        out, i = {}, 0
+        fl = w.view(np.float32)
+        while i < len(names):
+            j = i
+            while j < len(names) and names[j] == names[i]:
+                j += 1
+            out[names[i]] = np.ascontiguousarray(fl[i:j].T)
+            i = j
+        out["step_count"] = w[self.words - 2].view(np.int32).copy()
+        out["episode"] = w[self.words - 1].copy()
+        if "init_dist" in out:
+            out["init_dist"] = out["init_dist"][:, 0]
+        out["done"] = d.cpu().numpy()
+        return out
+
+    def counters(self):
+        c = (ctypes.c_uint64 * N_COUNTERS)()
+        _check(self.L, self.L.tb_counters(self._h, c, self._stream()), "tb_counters")
+        return dict(zip(COUNTER_NAMES, [int(x) for x in c]))
+
+    def counters_reset(self):
+        _check(self.L, self.L.tb_counters_reset(self._h, self._stream()), "tb_counters_reset")

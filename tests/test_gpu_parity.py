@@ -1,0 +1,291 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle on a real MI355X.
+
+Bar (BASELINE.json north_star): done flags and step/substep counters bit-exact; floats
+within a stated float32 tolerance. The float32 oracle build follows the same operation
+order as the kernels, so these tests assert BIT equality for floats too and would fall
+back to the stated tolerance only through TOL below (kept at 0 while it holds).
+The float64 build measures how far float32 drifts from the "true" trajectory.
+"""
+import numpy as np
+import pytest
+
+from helpers import make_words
+from oracle import OracleBatch
+from tennisbot_rl_amd.params import (ENV_SWING, ENV_TENNIS, F_AUTO_RESET, F_DEFAULT, F_NET, STATE_WORDS, default_params)
+
+pytestmark = pytest.mark.gpu
+
+TOL = 0.0  # float tolerance HIP vs float32 oracle: bit-exact
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch
+
+
+def make_pair(torch, kind, n, seed=11, auto_reset=True, env_id_base=0, **over):
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    flags = over.pop("flags", F_DEFAULT)
+    p = default_params(flags=flags, **over)
+    env = BatchedEnv(kind, n, device="cuda:0", seed=seed, env_id_base=env_id_base, params=p, auto_reset=auto_reset)
+    pf = p.copy()
+    pf.flags = (pf.flags | F_AUTO_RESET) if auto_reset else (pf.flags & ~F_AUTO_RESET)
+    ref = OracleBatch(pf, kind, n, seed=seed, env_id_base=env_id_base, precision="f32")
+    return env, ref
+
+
+def same(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    if TOL == 0.0:
+        if a.dtype.kind == "f":
+            ok = np.array_equal(a.view(np.uint32), b.view(np.uint32)) or np.array_equal(a, b)
+        else:
+            ok = np.array_equal(a, b)
+        if not ok:
+            bad = np.argwhere(a != b)
+            raise AssertionError("%s: %d mismatches, first at %s: %r vs %r" % (what, len(bad), bad[0], a[tuple(bad[0])], b[tuple(bad[0])]))
+    else:
+        np.testing.assert_allclose(a, b, rtol=TOL, atol=TOL, err_msg=what)
+
+
+def compare_state(env, ref, what):
+    w_gpu, d_gpu = env.get_state_words()
+    w_cpu, d_cpu = ref.get_state_words()
+    w_gpu = w_gpu.cpu().numpy().view(np.uint32)
+    nw = STATE_WORDS[env.kind]
+    same(w_gpu[nw - 2:], w_cpu[nw - 2:], what + " step_count/episode")  # integers: always exact
+    same(d_gpu.cpu().numpy(), d_cpu, what + " done byte")
+    same(w_gpu[: nw - 2].view(np.float32), w_cpu[: nw - 2].view(np.float32), what + " float state")
+
+
+def run_lockstep(torch, env, ref, steps, rng, what, check_state_every=1):
+    n = env.num_envs
+    same(env.reset().cpu().numpy(), ref.reset(), what + " reset obs")
+    compare_state(env, ref, what + " after reset")
+    for t in range(steps):
+        a = rng.uniform(-1, 1, (n, env.act_dim)).astype(np.float32)
+        obs, rew, done = env.step(torch.from_numpy(a).cuda())
+        o2, r2, d2, s2, t2 = ref.step(a, want_terminal=True)
+        tag = "%s step %d" % (what, t)
+        same(done.cpu().numpy(), d2, tag + " done")
+        same(env.last_substeps().cpu().numpy(), s2, tag + " substeps")
+        same(obs.cpu().numpy(), o2, tag + " obs")
+        same(rew.cpu().numpy(), r2, tag + " reward")
+        if env.auto_reset and d2.any():
+            m = d2.astype(bool)
+            same(env.terminal_obs().cpu().numpy()[m], t2[m], tag + " terminal obs")
+        if t % check_state_every == 0:
+            compare_state(env, ref, tag)
+    got, want = env.counters(), ref.counters()
+    assert list(got.values()) == [int(x) for x in want], (got, want)
+
+
+def test_native_library_is_the_one_running(torch):
+    from tennisbot_rl_amd import stepper
+    L = stepper.load_library()
+    assert L.tb_abi_version() == 1
+    with open("/proc/self/maps") as f:
+        assert "libtb_stepper.so" in f.read()
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 257, 4096])
+def test_swing_lockstep_ragged_sizes(torch, n):
+    env, ref = make_pair(torch, ENV_SWING, n)
+    run_lockstep(torch, env, ref, 54, np.random.default_rng(n), "swing n=%d" % n)  # two full episodes + resets
+    env.close()
+
+
+@pytest.mark.parametrize("n", [1, 65, 4096])
+def test_tennis_lockstep(torch, n):
+    env, ref = make_pair(torch, ENV_TENNIS, n)
+    run_lockstep(torch, env, ref, 700, np.random.default_rng(100 + n), "tennis n=%d" % n, check_state_every=50)
+    c = env.counters()
+    assert c["episodes_finished"] > 0 and c["nonfinite_states"] == 0
+    env.close()
+
+
+def test_swing_without_auto_reset_sticky_done(torch):
+    env, ref = make_pair(torch, ENV_SWING, 300, auto_reset=False)
+    run_lockstep(torch, env, ref, 30, np.random.default_rng(5), "swing sticky")  # 4 steps past done
+    assert env.get_state()["done"].min() == 2  # pending force consumed once, then plain done
+    env.close()
+
+
+def test_tennis_without_auto_reset(torch):
+    env, ref = make_pair(torch, ENV_TENNIS, 300, auto_reset=False)
+    run_lockstep(torch, env, ref, 400, np.random.default_rng(6), "tennis sticky", check_state_every=25)
+    env.close()
+
+
+def test_contact_off_bench_mode(torch):
+    """BASELINE configs[1]: racket-only dynamics, racket<->ball pair disabled"""
+    env, ref = make_pair(torch, ENV_SWING, 1024, flags=F_NET)
+    run_lockstep(torch, env, ref, 27, np.random.default_rng(7), "swing contact-off")
+    assert env.counters()["racket_ball_contact_substeps"] == 0
+    env.close()
+
+
+def test_forced_contacts_exercise_the_solver(torch):
+    """random policies rarely hit the ball; inject states where every lane is in contact
+    (racket face, rim, ground, net, goal) so that the narrowphase sweep + impulse solver
+    are compared lane by lane"""
+    n = 512
+    rng = np.random.default_rng(21)
+    p = default_params()
+    env, ref = make_pair(torch, ENV_TENNIS, n, auto_reset=False)
+    rp = np.stack([rng.uniform(8, 12, n), rng.uniform(-4, 4, n), rng.uniform(0.7, 1.5, n)], 1)
+    # random racket orientation, ball placed just outside the +-x face at a random spot of the outline
+    q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    side = np.where(rng.random(n) < 0.5, -1.0, 1.0)
+    loc = np.stack([side * (p.racket_half_thick + p.hull_margin + p.ball_radius + rng.uniform(-0.004, 0.0006, n)),
+                    rng.uniform(-0.16, 0.16, n), rng.uniform(-0.1, 0.22, n)], 1)
+    def rot(q, v):
+        u, w = q[:, :3], q[:, 3:4]
+        t = 2 * np.cross(u, v)
+        return v + w * t + np.cross(u, t)
+    bp = rp + rot(q, loc)
+    bv = rot(q, np.stack([-side * rng.uniform(1, 25, n), rng.uniform(-5, 5, n), rng.uniform(-5, 5, n)], 1))
+    w, d = make_words(ENV_TENNIS, n, racket_pos=rp, racket_quat=q, racket_vel=rng.uniform(-3, 3, (n, 3)),
+                      racket_angvel=rng.uniform(-4, 4, (n, 3)), ball_pos=bp, ball_vel=bv, ball_angvel=rng.uniform(-20, 20, (n, 3)),
+                      shoot_force=(30, 0, 20), step_count=50)
+    env.set_state_words(w.view(np.int32), d); ref.set_state_words(w, d)
+    for t in range(6):
+        a = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+        obs, rew, done = env.step(torch.from_numpy(a).cuda())
+        o2, r2, d2, s2 = ref.step(a)
+        same(obs.cpu().numpy(), o2, "forced racket contact obs %d" % t)
+        same(rew.cpu().numpy(), r2, "forced racket contact reward %d" % t)
+        compare_state(env, ref, "forced racket contact %d" % t)
+    assert env.counters()["racket_ball_contact_substeps"] > n // 2
+    env.close()
+
+    # statics: ground, net, goal (Swing has all three)
+    env, ref = make_pair(torch, ENV_SWING, n, auto_reset=False)
+    which = rng.integers(0, 3, n)
+    goal = np.stack([rng.uniform(-11, -4, n), rng.uniform(-4, 4, n)], 1)
+    r = p.ball_radius
+    ground = np.stack([rng.uniform(-13.9, 14.2, n), rng.uniform(-6.9, 7.1, n), 0.005 + r + rng.uniform(-0.003, 0.0006, n)], 1)
+    net = np.stack([np.where(rng.random(n) < 0.5, -1, 1) * (p.net_half[0] + r + rng.uniform(-0.003, 0.0006, n)), rng.uniform(-6.4, 6.4, n), rng.uniform(0.05, 0.56, n)], 1)
+    ang = rng.uniform(0, 2 * np.pi, n); rad = rng.uniform(0, 1.55, n)
+    gl = np.stack([goal[:, 0] + rad * np.cos(ang), goal[:, 1] + rad * np.sin(ang), 0.125 + r + rng.uniform(-0.003, 0.0006, n)], 1)
+    bp = np.where(which[:, None] == 0, ground, np.where(which[:, None] == 1, net, gl))
+    bv = np.stack([rng.uniform(-12, 12, n), rng.uniform(-6, 6, n), rng.uniform(-9, 1, n)], 1)
+    w, d = make_words(ENV_SWING, n, racket_pos=(9, 0, 1.0), ball_pos=bp, ball_vel=bv, ball_angvel=rng.uniform(-30, 30, (n, 3)),
+                      goal=goal, spawn_pos=(9, 0, 0.6), init_dist=rng.uniform(8, 20, n), step_count=rng.integers(0, 30, n))
+    env.set_state_words(w.view(np.int32), d); ref.set_state_words(w, d)
+    for t in range(4):
+        a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
+        obs, rew, done = env.step(torch.from_numpy(a).cuda())
+        o2, r2, d2, s2 = ref.step(a)
+        same(done.cpu().numpy(), d2, "forced statics done %d" % t)
+        same(env.last_substeps().cpu().numpy(), s2, "forced statics substeps %d" % t)
+        same(obs.cpu().numpy(), o2, "forced statics obs %d" % t)
+        same(rew.cpu().numpy(), r2, "forced statics reward %d" % t)
+        compare_state(env, ref, "forced statics %d" % t)
+    c = env.counters()
+    assert c["ball_court_terminations"] > 0 and c["goal_hits"] > 0
+    env.close()
+
+
+def test_rollout_equals_repeated_steps(torch):
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    n, T = 1000, 60
+    rng = np.random.default_rng(3)
+    for kind, A in ((ENV_SWING, 6), (ENV_TENNIS, 2)):
+        acts = torch.from_numpy(rng.uniform(-1, 1, (T, n, A)).astype(np.float32)).cuda()
+        e1 = BatchedEnv(kind, n, seed=4)
+        e2 = BatchedEnv(kind, n, seed=4)
+        e1.reset(); e2.reset()
+        obs, rew, done = e1.rollout(acts)
+        sub_total = e1.last_substeps().clone()
+        acc = torch.zeros_like(sub_total)
+        for t in range(T):
+            o, r, d = e2.step(acts[t])
+            acc += e2.last_substeps()
+            assert torch.equal(o, obs[t]) and torch.equal(r, rew[t]) and torch.equal(d, done[t])
+        assert torch.equal(acc, sub_total)
+        w1, d1 = e1.get_state_words(); w2, d2 = e2.get_state_words()
+        assert torch.equal(w1, w2) and torch.equal(d1, d2)
+        e1.close(); e2.close()
+
+
+def test_sharding_independence(torch):
+    """RNG keyed by the GLOBAL env id: two half batches == one whole batch"""
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    n = 512
+    rng = np.random.default_rng(8)
+    acts = torch.from_numpy(rng.uniform(-1, 1, (30, n, 6)).astype(np.float32)).cuda()
+    whole = BatchedEnv(ENV_SWING, n, seed=5)
+    lo = BatchedEnv(ENV_SWING, n // 2, seed=5, env_id_base=0)
+    hi = BatchedEnv(ENV_SWING, n // 2, seed=5, env_id_base=n // 2)
+    a = whole.reset(); b = torch.cat([lo.reset(), hi.reset()])
+    assert torch.equal(a, b)
+    for t in range(30):
+        o, r, d = whole.step(acts[t])
+        o1, r1, d1 = lo.step(acts[t, : n // 2].contiguous())
+        o2, r2, d2 = hi.step(acts[t, n // 2:].contiguous())
+        assert torch.equal(o, torch.cat([o1, o2])) and torch.equal(r, torch.cat([r1, r2])) and torch.equal(d, torch.cat([d1, d2]))
+    for e in (whole, lo, hi):
+        e.close()
+
+
+def test_masked_reset_and_state_roundtrip(torch):
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    n = 200
+    env, ref = make_pair(torch, ENV_TENNIS, n, auto_reset=False)
+    env.reset(); ref.reset()
+    mask = (np.arange(n) % 3 == 0).astype(np.uint8)
+    o1 = env.reset(torch.from_numpy(mask).cuda())
+    o2 = ref.reset(mask)
+    same(o1.cpu().numpy()[mask.astype(bool)], o2[mask.astype(bool)], "masked reset obs")
+    compare_state(env, ref, "masked reset")
+    st = env.get_state()
+    assert set(np.unique(st["episode"])) == {0, 1}
+    w, d = env.get_state_words()
+    other = BatchedEnv(ENV_TENNIS, n, seed=999, auto_reset=False)
+    other.set_state_words(w, d)
+    a = torch.zeros((n, 2), device="cuda")
+    x = env.step(a); y = other.step(a)
+    assert all(torch.equal(p, q) for p, q in zip(x, y))
+    env.close(); other.close()
+
+
+def test_scaled_racket_and_spin_extensions(torch):
+    """curriculum racket scale (tennisbot_env.py:213-215) and the configs[4] extensions
+    (Magnus term, random spin) stay in lockstep with the oracle"""
+    env, ref = make_pair(torch, ENV_TENNIS, 512, magnus_k=2e-4, ball_spin_max=150.0)
+    run_lockstep(torch, env, ref, 300, np.random.default_rng(31), "tennis magnus", check_state_every=30)
+    env.close()
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    p = default_params(racket_scale=2.3)
+    env = BatchedEnv(ENV_TENNIS, 512, seed=2, params=p)
+    pf = p.copy(); pf.flags |= F_AUTO_RESET
+    ref = OracleBatch(pf, ENV_TENNIS, 512, seed=2, precision="f32")
+    run_lockstep(torch, env, ref, 300, np.random.default_rng(32), "tennis scale 2.3", check_state_every=30)
+    env.close()
+
+
+def test_float32_drift_vs_float64_truth(torch):
+    """stated float32 tolerance: over one Swing episode without contacts the float32 state stays
+    within 2e-4 (abs, metres / m/s) of the float64 oracle; done and step counters agree wherever
+    the float64 trajectory is not within 1e-4 m of a contact threshold"""
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    n = 2048
+    rng = np.random.default_rng(17)
+    p = default_params()
+    env = BatchedEnv(ENV_SWING, n, seed=13, params=p, auto_reset=False)
+    ref = OracleBatch(p, ENV_SWING, n, seed=13, precision="f64")
+    env.reset(); ref.reset()
+    for t in range(25):
+        a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
+        env.step(torch.from_numpy(a).cuda()); ref.step(a)
+    g, c = env.get_state(), ref.get_state()
+    quiet = ref.counters()[0] == 0 and env.counters()["racket_ball_contact_substeps"] == 0
+    for k in ("racket_pos", "racket_vel", "ball_pos", "ball_vel"):
+        err = np.abs(g[k] - c[k]).max()
+        if quiet:
+            assert err < 2e-4, (k, err)
+    assert np.array_equal(g["step_count"], c["step_count"])
