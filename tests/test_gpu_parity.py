@@ -101,7 +101,8 @@ def test_swing_lockstep_ragged_sizes(torch, n):
 @pytest.mark.parametrize("n", [1, 65, 4096])
 def test_tennis_lockstep(torch, n):
     env, ref = make_pair(torch, ENV_TENNIS, n)
-    run_lockstep(torch, env, ref, 700, np.random.default_rng(100 + n), "tennis n=%d" % n, check_state_every=50)
+    # 1010 steps: past the 1000-step timeout (tennisbot_env.py:201-203), so every env finishes at least once
+    run_lockstep(torch, env, ref, 1010, np.random.default_rng(100 + n), "tennis n=%d" % n, check_state_every=50)
     c = env.counters()
     assert c["episodes_finished"] > 0 and c["nonfinite_states"] == 0
     env.close()
