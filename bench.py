@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env steps/sec (whole node), SwingRacket-v0 @ 4096 envs/GPU.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one agent-level env.step() of every env of the batch (BASELINE.json metric;
+SURVEY.md 8d): one launch of the HIP step kernel over N envs, i.e. 1 physics substep for
+agent steps 1-25 of an episode and 1 + (up to 775) substeps on the 26th (the fast-forward
+of swingracket_env.py:105-141), plus the in-kernel auto-reset. Inputs (state, synthetic
+U(-1,1) actions from PCG64) are resident in HBM before the timed region; every step writes
+obs / reward / done straight into the rank's rollout buffer, and with N > 1 the timed
+region ends with the ONE all-gather of the rollout shards (RCCL over xGMI) that the PPO
+collect boundary needs. Rank 0 prints ONE JSON line.
+
+Also in that line:
+  roofline     -- HBM roofline of the step kernel: algorithmic bytes per launch (267 B/env
+                  Swing, 263 B/env Tennisbot: DESIGN.md) / average launch duration from HIP
+                  events on the launch stream. This path is launch- and ALU-latency-bound at
+                  4096 envs, and the number says so; `sweep` shows the
+                  asymptote at large N.
+  cpu_baseline -- the float32 CPU oracle (a port, not PyBullet, which is not installable
+                  here) timed on this host's cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+ALGO_BYTES = {"swing": {"read": 145, "write": 122}, "tennis": {"read": 117, "write": 146}}  # SURVEY.md 8d / DESIGN.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1040, help="timed agent steps (default 40 Swing episodes of 26)")
+    ap.add_argument("--warmup", type=int, default=52)
+    ap.add_argument("--env", choices=["swing", "tennis"], default="swing")
+    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--contact-off", action="store_true", help="BASELINE configs[1] bench mode: racket<->ball pair disabled")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound for each CPU baseline leg")
+    ap.add_argument("--sweep", action="store_true", help="also time N = 4096 .. 4M envs on one GPU (extra JSON key)")
+    ap.add_argument("--seed", type=int, default=0)
+    return ap.parse_args()
+
+
+def fill_actions(buf_actions, seed, torch):
+    """synthetic U(-1,1) float32 actions from numpy PCG64, uploaded once; the
+    host draw is bounded (one 104-step block, tiled) so set-up stays short at large N"""
+    import numpy as np
+    T, N, A = buf_actions.shape
+    block = min(T, 104)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    a = torch.from_numpy(rng.uniform(-1.0, 1.0, (block, N, A)).astype(np.float32)).to(buf_actions.device)
+    for t0 in range(0, T, block):
+        n = min(block, T - t0)
+        buf_actions[t0:t0 + n].copy_(a[:n])
+
+
+def time_steps(env, buf, steps, warmup, torch, dist_on, tail_gather=True):
+    """W untimed + K timed steps; returns (wall seconds, HIP-event seconds of the K launches)"""
+    dev = env.device
+    T = buf.T
+    for t in range(warmup):
+        buf.step_into(env, t % T)
+    if dist_on:
+        torch.distributed.barrier()
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(torch.cuda.current_stream(dev))  # the stream the step kernel is launched on
+    for t in range(steps):
+        buf.step_into(env, t % T)
+    ev1.record(torch.cuda.current_stream(dev))
+    if tail_gather:
+        buf.all_gather()  # collect boundary: one collective (no-op for a single rank)
+    if dist_on:
+        torch.distributed.barrier()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    return wall, ev0.elapsed_time(ev1) * 1e-3
+
+
+def cpu_baseline(kind_name, n_envs, seconds, seed):
+    """the oracle (kind "port") on this host, same workload shape, bounded time"""
+    import numpy as np
+    from oracle import OracleBatch
+    from tennisbot_rl_amd.params import ENV_SWING, ENV_TENNIS, F_AUTO_RESET, F_DEFAULT, default_params
+    kind = ENV_SWING if kind_name == "swing" else ENV_TENNIS
+    A = 6 if kind_name == "swing" else 2
+    rng = np.random.Generator(np.random.PCG64(seed))
+    acts = rng.uniform(-1.0, 1.0, (104, n_envs, A)).astype(np.float32)
+    # the GPU box gives one-GPU jobs a 16-CPU share of a much larger host: more threads than
+    # that only oversubscribe (measured: 256 threads -> 60x slower than 1)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("TB_CPU_THREADS", "16"))))
+    out = {}
+    for label, threads in (("1core", 1), ("allcores", cores)):
+        b = OracleBatch(default_params(flags=F_DEFAULT | F_AUTO_RESET), kind, n_envs, seed=seed, precision="f32", threads=threads)
+        b.reset()
+        done_steps, t0 = 0, time.perf_counter()
+        while True:
+            for t in range(26):  # whole Swing episodes so that the fast-forward share is the workload's
+                b.step(acts[(done_steps + t) % 104])
+            done_steps += 26
+            el = time.perf_counter() - t0
+            if el > seconds or done_steps >= 1040:
+                break
+        out[label] = {"steps_per_s": done_steps * n_envs / el, "agent_steps": done_steps, "seconds": el,
+                      "substeps_per_s": float(b.counters()[6]) / el, "threads": threads}
+        b.close()
+    return out
+
+
+def main():
+    args = parse()
+    import torch
+    from tennisbot_rl_amd.params import ENV_SWING, ENV_TENNIS, F_DEFAULT, F_NET, default_params
+    from tennisbot_rl_amd.rollout import RolloutBuffer
+    from tennisbot_rl_amd.stepper import BatchedEnv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("--gpus %d needs the torch.distributed launcher (one process per GPU)" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if dist_on:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group(backend="nccl", device_id=dev)
+
+    kind = ENV_SWING if args.env == "swing" else ENV_TENNIS
+    flags = F_NET if args.contact_off else F_DEFAULT
+    N = args.envs_per_gpu
+    env = BatchedEnv(kind, N, device=dev, seed=args.seed, env_id_base=rank * N, params=default_params(flags=flags),
+                     track_terminal_obs=False)
+    T_buf = min(args.steps, 1100)  # rollout length of the reference: n_steps = 1100 (train_swing.py:49-50)
+    buf = RolloutBuffer(kind, T_buf, N, dev)
+    fill_actions(buf.actions, args.seed + rank, torch)
+    env.reset()
+    env.counters_reset()
+    wall, ev_s = time_steps(env, buf, args.steps, args.warmup, torch, dist_on)
+    c = env.counters()
+
+    wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    sub_t = torch.tensor([float(c["substeps"])], dtype=torch.float64, device=dev)
+    if dist_on:
+        torch.distributed.all_reduce(wall_t, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(sub_t, op=torch.distributed.ReduceOp.SUM)
+    wall_max = float(wall_t.item())
+    # warm-up substeps are in the counter too: scale to the timed share
+    timed_substeps = float(sub_t.item()) * args.steps / (args.steps + args.warmup)
+
+    result = None
+    if rank == 0:
+        ab = ALGO_BYTES[args.env]
+        per_launch_bytes = (ab["read"] + ab["write"]) * N
+        launch_s = ev_s / args.steps
+        achieved = per_launch_bytes / launch_s / 1e9
+        result = {
+            "metric": "env steps/sec (whole node), SwingRacket-v0 @4096 envs/GPU" if args.env == "swing" and N == 4096
+                      else "env steps/sec (whole node), %s @%d envs/GPU" % ("SwingRacket-v0" if args.env == "swing" else "Tennisbot-v0", N),
+            "value": world * N * args.steps / wall_max,
+            "unit": "env steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall_max / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s, %d envs/GPU, %s, auto-reset, U(-1,1) actions, rollout buffer %d steps%s" % (
+                "SwingRacket-v0" if args.env == "swing" else "Tennisbot-v0", N,
+                "racket<->ball contact off (configs[1] bench mode)" if args.contact_off else "full contact semantics",
+                T_buf, ", 1 RCCL all-gather of rollouts at the collect boundary" if dist_on else ""),
+                "envs_per_gpu": N, "global_envs": world * N, "parallelism": "env-sharded x%d" % world},
+            "substeps_per_s": timed_substeps / wall_max,
+            "substeps_per_agent_step": timed_substeps / (world * N * args.steps),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "tb_step_kernel<%d>" % kind, "launch_us": launch_s * 1e6,
+                         "algorithmic_bytes_per_env_step": ab["read"] + ab["write"],
+                         "note": "latency-bound at this batch size, not bandwidth-bound (see sweep / DESIGN.md)"},
+            "parity": "vs CPU restatement (PyBullet parity unpinned: reference ships no tests or golden vectors, PyBullet not available offline)",
+        }
+    if args.sweep and not dist_on:
+        sweep = []
+        for n in (4096, 32768, 262144, 1048576, 4194304):
+            e2 = BatchedEnv(kind, n, device=dev, seed=args.seed, params=default_params(flags=flags), track_terminal_obs=False)
+            b2 = RolloutBuffer(kind, 26, n, dev)
+            fill_actions(b2.actions, args.seed, torch)
+            e2.reset()
+            k = 52 if n >= 1048576 else 104
+            w, evs = time_steps(e2, b2, k, 26, torch, False, tail_gather=False)
+            ab = ALGO_BYTES[args.env]
+            sweep.append({"envs": n, "steps_per_s": n * k / w, "launch_us": evs / k * 1e6,
+                          "achieved_GBs": (ab["read"] + ab["write"]) * n / (evs / k) / 1e9})
+            e2.close()
+            del b2
+            torch.cuda.empty_cache()
+        if result is not None:
+            result["sweep"] = sweep
+    if rank == 0 and not args.no_cpu_baseline:
+        cb = cpu_baseline(args.env, N, args.cpu_seconds, args.seed)
+        best = cb["allcores"]
+        result["cpu_baseline"] = {
+            "value": best["steps_per_s"], "unit": "env steps/s", "cores": best["threads"], "kind": "port",
+            "sample": "float32 CPU oracle (oracle/tb_oracle.c, OpenMP over envs), %d envs x %d agent steps (whole 26-step episodes incl. fast-forward), %.1f s"
+                      % (N, best["agent_steps"], best["seconds"]),
+            "value_1core": cb["1core"]["steps_per_s"], "substeps_per_s": best["substeps_per_s"],
+            "substeps_per_s_1core": cb["1core"]["substeps_per_s"],
+        }
+    if dist_on:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

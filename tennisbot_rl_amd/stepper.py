@@ -103,6 +103,7 @@ class BatchedEnv:
         self.kind, self.num_envs = env_kind, int(num_envs)
         self.obs_dim, self.act_dim, self.words = OBS_DIM[env_kind], ACT_DIM[env_kind], STATE_WORDS[env_kind]
         self.seed, self.env_id_base = int(seed), int(env_id_base)
+        self._row_align = 8 if env_kind == ENV_SWING else 16  # float2 / float4 row accesses
         p = (params or default_params()).copy()
         p.flags = (p.flags | F_AUTO_RESET) if auto_reset else (p.flags & ~F_AUTO_RESET)
         self.params = p
@@ -144,6 +145,8 @@ class BatchedEnv:
             raise ValueError("%s must have shape %s, got %s" % (name, tuple(shape), tuple(x.shape)))
         if not x.is_contiguous():
             raise ValueError("%s must be contiguous" % name)
+        if dtype == t.float32 and x.dim() >= 2 and x.data_ptr() % self._row_align:
+            raise ValueError("%s must be %d-byte aligned (the kernels use vector accesses per row)" % (name, self._row_align))
         return x
 
     def close(self):
@@ -169,10 +172,17 @@ class BatchedEnv:
         _check(self.L, self.L.tb_reset(self._h, None if mask is None else mask.data_ptr(), obs.data_ptr(), self._stream()), "tb_reset")
         return obs
 
-    def step(self, actions):
+    def step(self, actions, out=None):
+        """out: optional (obs, reward, done) tensors to write in place (e.g. slices of a
+        RolloutBuffer), shapes [N, O] f32, [N] f32, [N] u8, contiguous, on this device."""
         t = self.torch
         a = self._check_tensor(actions, (self.num_envs, self.act_dim), t.float32, "actions")
-        obs, rew, done = self._out()
+        if out is None:
+            obs, rew, done = self._out()
+        else:
+            obs = self._check_tensor(out[0], (self.num_envs, self.obs_dim), t.float32, "out[0]")
+            rew = self._check_tensor(out[1], (self.num_envs,), t.float32, "out[1]")
+            done = self._check_tensor(out[2], (self.num_envs,), t.uint8, "out[2]")
         _check(self.L, self.L.tb_step(self._h, a.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(),
                                       None if self._term is None else self._term.data_ptr(), self._substeps.data_ptr(),
                                       self._stream()), "tb_step")
