@@ -1,0 +1,91 @@
+"""The N > 1 path on CPU: two `gloo` ranks, each owning a contiguous block of global env
+ids, fill their RolloutBuffer shard and exchange it with ONE all-gather; the gathered
+rollout equals a single-process run over all envs. The stepping engine here
+is the CPU oracle (no GPU in this container); the sharding / packing / collective code is
+the product's (tennisbot_rl_amd/rollout.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+N_LOCAL, T, WORLD = 24, 30, 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _actions(kind_act_dim):
+    rng = np.random.default_rng(123)
+    return rng.uniform(-1, 1, (T, WORLD * N_LOCAL, kind_act_dim)).astype(np.float32)
+
+
+def _fill(buf, ref, acts_local, torch):
+    buf.actions.copy_(torch.from_numpy(acts_local))
+    ref.reset()
+    for t in range(T):
+        o, r, d, _ = ref.step(acts_local[t])
+        buf.obs[t].copy_(torch.from_numpy(o)); buf.rewards[t].copy_(torch.from_numpy(r)); buf.dones[t].copy_(torch.from_numpy(d))
+
+
+def _worker(rank, port, kind, out_dir):
+    import torch
+    import torch.distributed as dist
+    from oracle import OracleBatch
+    from tennisbot_rl_amd.params import ACT_DIM, F_AUTO_RESET, F_DEFAULT, default_params
+    from tennisbot_rl_amd.rollout import RolloutBuffer
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    acts = _actions(ACT_DIM[kind])[:, rank * N_LOCAL:(rank + 1) * N_LOCAL].copy()
+    ref = OracleBatch(default_params(flags=F_DEFAULT | F_AUTO_RESET), kind, N_LOCAL, seed=5, env_id_base=rank * N_LOCAL, precision="f32")
+    buf = RolloutBuffer(kind, T, N_LOCAL, "cpu")
+    _fill(buf, ref, acts, torch)
+    shards = buf.all_gather()
+    assert len(shards) == WORLD
+    obs, act, rew, done = buf.concatenated(shards)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), obs=obs.numpy(), act=act.numpy(), rew=rew.numpy(), done=done.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind_name", ["swing", "tennis"])
+def test_two_rank_gloo_all_gather_equals_single_process(tmp_path, kind_name):
+    import torch
+    import torch.multiprocessing as mp
+    from oracle import OracleBatch
+    from tennisbot_rl_amd.params import ACT_DIM, ENV_SWING, ENV_TENNIS, F_AUTO_RESET, F_DEFAULT, default_params
+    from tennisbot_rl_amd.rollout import RolloutBuffer
+    kind = ENV_SWING if kind_name == "swing" else ENV_TENNIS
+    mp.spawn(_worker, args=(_free_port(), kind, str(tmp_path)), nprocs=WORLD, join=True)
+    # single process over the whole global batch
+    acts = _actions(ACT_DIM[kind])
+    ref = OracleBatch(default_params(flags=F_DEFAULT | F_AUTO_RESET), kind, WORLD * N_LOCAL, seed=5, precision="f32")
+    whole = RolloutBuffer(kind, T, WORLD * N_LOCAL, "cpu")
+    _fill(whole, ref, acts, torch)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for k, want in (("obs", whole.obs), ("act", whole.actions), ("rew", whole.rewards), ("done", whole.dones)):
+        assert np.array_equal(r0[k], r1[k])               # every rank holds the same gathered rollout
+        assert np.array_equal(r0[k], want.numpy()), k     # ... equal to the unsharded run, in global env order
+    assert r0["done"].any() or kind == ENV_TENNIS  # every Swing episode ends at agent step 26
+
+
+def test_rollout_buffer_layout_and_reference_message_size():
+    """one packed byte buffer per rank => a single collective; at the reference's n_steps=1100
+    and 4096 envs the Swing shard is ~239 MB"""
+    from tennisbot_rl_amd.params import ENV_SWING, ENV_TENNIS
+    from tennisbot_rl_amd.rollout import RolloutBuffer
+    b = RolloutBuffer(ENV_SWING, 7, 5, "cpu")
+    assert b.obs.shape == (7, 5, 6) and b.actions.shape == (7, 5, 6) and b.rewards.shape == (7, 5) and b.dones.shape == (7, 5)
+    assert all(int(o) % 16 == 0 for o in b.offsets)
+    b.obs.fill_(1.5); b.actions.fill_(-2.0); b.rewards.fill_(3.0); b.dones.fill_(1)
+    o, a, r, d = b.views(b.raw.clone())
+    assert float(o.min()) == 1.5 and float(a.max()) == -2.0 and float(r.mean()) == 3.0 and int(d.sum()) == 35
+    sizes = lambda T, N, O, A: T * N * (O + A + 1) * 4 + T * N  # noqa: E731
+    assert abs(sizes(1100, 4096, 6, 6) - 238.8e6) / 238.8e6 < 0.01
+    t = RolloutBuffer(ENV_TENNIS, 3, 4, "cpu")
+    assert t.obs.shape == (3, 4, 12) and t.actions.shape == (3, 4, 2)
