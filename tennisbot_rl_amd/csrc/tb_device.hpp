@@ -101,6 +101,7 @@ struct KParams {
   float ball_inv_mass, ball_inv_inertia, ball_radius, magnus_k, ball_spin_max;
   float rest_racket, rest_court, rest_goal, fric_racket, fric_court, fric_goal;
   float ground_half[3], net_half[3], goal_radius, goal_half_len;
+  float static_top;  // highest point of any enabled static shape (host-derived)
   int n_hull;
 };
 
@@ -120,12 +121,15 @@ constexpr int CT_RACKET = 1, CT_GROUND = 2, CT_NET = 4, CT_GOAL = 8;
 // sphere vs racket: prism over the convex (y, z) outline of racket.stl in the COM frame,
 // inflated by the URDF hull margin (racket.urdf:12-16).
 // `hull` points at the LDS copy of the edge records {a.y a.z e.y e.z | 1/|e|^2 1/|e| - -}.
-TB_DEV Hit sphere_vs_racket(const KParams& P, const float4* hull, const Racket& rk, vec3 c) {
-  Hit h; h.hit = false; h.dist = 0.0f; h.n = mk(0, 0, 0); h.rr = mk(0, 0, 0);
+// The bounding-sphere cull is done by the caller (substep) so that a whole wave can skip
+// the sweep with one ballot; `d` = ball centre - racket COM.
+TB_DEV bool racket_in_reach(const KParams& P, vec3 d) {
+  float reach = (P.hull_bound_radius + P.ball_radius) + P.contact_threshold;
+  return !(dot(d, d) > reach * reach);
+}
+TB_DEV Hit sphere_vs_racket_sweep(const KParams& P, const float4* hull, const Racket& rk, vec3 d) {
+  Hit h;
   const float r = P.ball_radius, thr = P.contact_threshold;
-  vec3 d = c - rk.p;
-  float reach = (P.hull_bound_radius + r) + thr;
-  if (dot(d, d) > reach * reach) return h;
   vec3 l = rotate_inv(rk.q, d);
   float ax = fabsf(l.x) - P.racket_half_thick;
   float sx = l.x < 0.0f ? -1.0f : 1.0f;
@@ -287,37 +291,52 @@ TB_DEV void setup_row(const KParams& P, Row& c, const Hit& h, bool racket, float
   float pos = h.dist > 0.0f ? -(h.dist * P.inv_dt) : -(h.dist * P.erp) * P.inv_dt;
   c.target = rest + pos;
 }
-TB_DEV void solve_contacts(const KParams& P, Row* rows, int nrows, Racket& rk, Ball& b) {
-  const float r = P.ball_radius;
+// rows live in registers: slots are indexed statically (0 racket, 1 ground, 2 net, 3 goal)
+// and skipped when inactive, which visits the active rows in the same order as a compacted list
+struct Rows { Row r[4]; bool on[4]; };
+
+TB_DEV bool solve_normal(const KParams& P, Row& c, Racket& rk, Ball& b) {
+  vec3 rb = (-P.ball_radius) * c.n;
+  float vn = dot(c.n, rel_vel(c, rk, b, rb));
+  float jn = FMA(c.target - vn, c.kn, c.jn);
+  if (jn < 0.0f) jn = 0.0f;
+  float d = jn - c.jn;
+  c.jn = jn;
+  if (d != 0.0f) { apply_impulse(P, c, rk, b, rb, c.n, d, false); return true; }
+  return false;
+}
+TB_DEV bool solve_friction(const KParams& P, Row& c, Racket& rk, Ball& b) {
+  float lim = c.mu * c.jn;
+  if (!(lim > 0.0f)) return false;
+  bool moved = false;
+  vec3 rb = (-P.ball_radius) * c.n;
+  {
+    float vt = dot(c.t1, rel_vel(c, rk, b, rb));
+    float jt = FMA(-vt, c.kt1, c.jt1);
+    jt = jt < -lim ? -lim : (jt > lim ? lim : jt);
+    float d = jt - c.jt1;
+    c.jt1 = jt;
+    if (d != 0.0f) { moved = true; apply_impulse(P, c, rk, b, rb, c.t1, d, true); }
+  }
+  {
+    float vt = dot(c.t2, rel_vel(c, rk, b, rb));
+    float jt = FMA(-vt, c.kt2, c.jt2);
+    jt = jt < -lim ? -lim : (jt > lim ? lim : jt);
+    float d = jt - c.jt2;
+    c.jt2 = jt;
+    if (d != 0.0f) { moved = true; apply_impulse(P, c, rk, b, rb, c.t2, d, true); }
+  }
+  return moved;
+}
+TB_DEV void solve_contacts(const KParams& P, Rows& R, Racket& rk, Ball& b) {
   for (int it = 0; it < P.solver_iters; ++it) {
     bool moved = false;
-    for (int i = 0; i < nrows; ++i) {
-      Row& c = rows[i];
-      vec3 rb = (-r) * c.n;
-      float vn = dot(c.n, rel_vel(c, rk, b, rb));
-      float jn = FMA(c.target - vn, c.kn, c.jn);
-      if (jn < 0.0f) jn = 0.0f;
-      float d = jn - c.jn;
-      c.jn = jn;
-      if (d != 0.0f) { moved = true; apply_impulse(P, c, rk, b, rb, c.n, d, false); }
-    }
-    for (int i = 0; i < nrows; ++i) {
-      Row& c = rows[i];
-      float lim = c.mu * c.jn;
-      if (!(lim > 0.0f)) continue;
-      vec3 rb = (-r) * c.n;
-      for (int k = 0; k < 2; ++k) {
-        vec3 t = k ? c.t2 : c.t1;
-        float acc = k ? c.jt2 : c.jt1;
-        float kt = k ? c.kt2 : c.kt1;
-        float vt = dot(t, rel_vel(c, rk, b, rb));
-        float jt = FMA(-vt, kt, acc);
-        jt = jt < -lim ? -lim : (jt > lim ? lim : jt);
-        float d = jt - acc;
-        if (k) c.jt2 = jt; else c.jt1 = jt;
-        if (d != 0.0f) { moved = true; apply_impulse(P, c, rk, b, rb, t, d, true); }
-      }
-    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (R.on[i]) moved |= solve_normal(P, R.r[i], rk, b);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (R.on[i]) moved |= solve_friction(P, R.r[i], rk, b);
     if (!moved) break;
   }
 }
@@ -377,16 +396,32 @@ TB_DEV void integrate_pose(const KParams& P, Racket& rk, Ball& b) {
 }
 
 // returns the contact bits of this substep's manifold (the `len(getContactPoints) > 0` tests)
+//
+// Free flight is the common case (a SwingRacket fast-forward is <= 775 substeps of it), so
+// the narrowphase is arranged as cheap per-lane culls + wave votes: a wave runs the outline
+// sweep / the static tests / the impulse solver only if __any lane needs them, and those
+// branches are wave-uniform (s_cbranch on the ballot), never if-converted into the hot path.
 template <int KIND>
 TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, vec3 Fr, vec3 Tr, vec3 Fb, float goal_x, float goal_y) {
   int bits = 0;
-  Hit hr; hr.hit = false;
-  if (P.flags & TB_F_RACKET_BALL) hr = sphere_vs_racket(P, hull, rk, b.p);
-  Hit hg = sphere_vs_box(P, P.ground_half[0], P.ground_half[1], P.ground_half[2], b.p);
-  Hit hn; hn.hit = false;
-  if (P.flags & TB_F_NET) hn = sphere_vs_box(P, P.net_half[0], P.net_half[1], P.net_half[2], b.p);
-  Hit hc; hc.hit = false;
-  if (KIND == TB_ENV_SWING) hc = sphere_vs_goal(P, goal_x, goal_y, b.p);
+  Hit hr, hg, hn, hc;
+  hr.hit = false; hg.hit = false; hn.hit = false; hc.hit = false;
+
+  vec3 d = b.p - rk.p;
+  bool near_racket = (P.flags & TB_F_RACKET_BALL) && racket_in_reach(P, d);
+  if (__any(near_racket)) {
+    if (near_racket) hr = sphere_vs_racket_sweep(P, hull, rk, d);
+  }
+  // every static shape lies below static_top: a ball whose lowest point clears it by the
+  // manifold threshold (+1 mm of slack against rounding) is culled by each exact test as well
+  bool near_static = !(((b.p.z - P.ball_radius) - P.contact_threshold) >= P.static_top + 1.0e-3f);
+  if (__any(near_static)) {
+    if (near_static) {
+      hg = sphere_vs_box(P, P.ground_half[0], P.ground_half[1], P.ground_half[2], b.p);
+      if (P.flags & TB_F_NET) hn = sphere_vs_box(P, P.net_half[0], P.net_half[1], P.net_half[2], b.p);
+      if (KIND == TB_ENV_SWING) hc = sphere_vs_goal(P, goal_x, goal_y, b.p);
+    }
+  }
   if (hr.hit) bits |= CT_RACKET;
   if (hg.hit) bits |= CT_GROUND;
   if (hn.hit) bits |= CT_NET;
@@ -394,14 +429,16 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, ve
 
   integrate_velocities(P, rk, b, Fr, Tr, Fb);
 
-  if (bits) {  // rare: only lanes whose ball touches something enter the solver
-    Row rows[4];
-    int nrows = 0;
-    if (bits & CT_RACKET) setup_row(P, rows[nrows++], hr, true, P.rest_racket, P.fric_racket, rk, b);
-    if (bits & CT_GROUND) setup_row(P, rows[nrows++], hg, false, P.rest_court, P.fric_court, rk, b);
-    if (bits & CT_NET) setup_row(P, rows[nrows++], hn, false, P.rest_court, P.fric_court, rk, b);
-    if (bits & CT_GOAL) setup_row(P, rows[nrows++], hc, false, P.rest_goal, P.fric_goal, rk, b);
-    solve_contacts(P, rows, nrows, rk, b);
+  if (__any(bits != 0)) {
+    if (bits) {  // only lanes whose ball touches something enter the solver
+      Rows R;
+      R.on[0] = bits & CT_RACKET; R.on[1] = bits & CT_GROUND; R.on[2] = bits & CT_NET; R.on[3] = bits & CT_GOAL;
+      if (R.on[0]) setup_row(P, R.r[0], hr, true, P.rest_racket, P.fric_racket, rk, b);
+      if (R.on[1]) setup_row(P, R.r[1], hg, false, P.rest_court, P.fric_court, rk, b);
+      if (R.on[2]) setup_row(P, R.r[2], hn, false, P.rest_court, P.fric_court, rk, b);
+      if (R.on[3]) setup_row(P, R.r[3], hc, false, P.rest_goal, P.fric_goal, rk, b);
+      solve_contacts(P, R, rk, b);
+    }
   }
   integrate_pose(P, rk, b);
   return bits;

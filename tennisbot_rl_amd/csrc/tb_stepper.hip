@@ -404,6 +404,9 @@ void to_kparams(const TbParams* p, KParams* k) {
   k->fric_racket = p->fric_racket; k->fric_court = p->fric_court; k->fric_goal = p->fric_goal;
   k->goal_radius = p->goal_radius; k->goal_half_len = p->goal_half_len;
   k->n_hull = p->n_hull;
+  float top = p->ground_half[2] > p->goal_half_len ? p->ground_half[2] : p->goal_half_len;
+  if ((p->flags & TB_F_NET) && p->net_half[2] > top) top = p->net_half[2];
+  k->static_top = top;
 }
 
 }  // namespace
