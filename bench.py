@@ -36,6 +36,24 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 ALGO_BYTES = {"swing": {"read": 145, "write": 122}, "tennis": {"read": 117, "write": 146}}  # SURVEY.md 8d / DESIGN.md
 
 
+def pmc_traffic(env_name, n_envs):
+    """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC summary
+    (profiles/*_pmc_traffic.json, produced by tools/run_pmc.sh + tools/summarize_pmc.py:
+    separate --pmc passes, gfx950 FETCH_SIZE correction calibrated on this access pattern).
+    PMC counters cannot be read from inside this process, so the figure is the latest
+    profiled one for the same workload, or None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json"))):
+        try:
+            w = json.load(open(f))["workloads"].get("%s_%d" % (env_name, n_envs))
+        except Exception:
+            w = None
+        if w:
+            best = (w["traffic_bytes_per_launch"], os.path.basename(f))
+    return best
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,6 +188,7 @@ def main():
         per_launch_bytes = (ab["read"] + ab["write"]) * N
         launch_s = ev_s / args.steps
         achieved = per_launch_bytes / launch_s / 1e9
+        traffic = None if args.contact_off else pmc_traffic(args.env, N)
         result = {
             "metric": "env steps/sec (whole node), SwingRacket-v0 @4096 envs/GPU" if args.env == "swing" and N == 4096
                       else "env steps/sec (whole node), %s @%d envs/GPU" % ("SwingRacket-v0" if args.env == "swing" else "Tennisbot-v0", N),
@@ -187,7 +206,9 @@ def main():
             "substeps_per_s": timed_substeps / wall_max,
             "substeps_per_agent_step": timed_substeps / (world * N * args.steps),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
+                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic[1] if traffic else None,
+                         "algorithmic_bytes_per_launch": per_launch_bytes,
                          "kernel": "tb_step_kernel<%d>" % kind, "launch_us": launch_s * 1e6,
                          "algorithmic_bytes_per_env_step": ab["read"] + ab["write"],
                          "note": "latency-bound at this batch size, not bandwidth-bound (see sweep / DESIGN.md)"},

@@ -206,6 +206,12 @@ int tb_set_state(TbHandle *h, const uint32_t *words, const uint8_t *done, int on
 int tb_counters(TbHandle *h, uint64_t *out, void *stream);
 int tb_counters_reset(TbHandle *h, void *stream);
 
+/* Diagnostics (not part of the env surface): copies `rows` SoA rows of n 32-bit words,
+ * src[r*n + i] -> dst[r*n + i], one dword per lane exactly like the step kernel's state
+ * accesses. A known byte count in the kernel's own access pattern, used to calibrate the
+ * rocprofv3 FETCH_SIZE / WRITE_SIZE counters (MI355X_MICROARCH.md, HBM section). */
+int tb_diag_stream_copy(const uint32_t *src_dev, uint32_t *dst_dev, int n, int rows, int device, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -349,6 +349,13 @@ __global__ void tb_init_kernel(uint32_t* words, uint8_t* done, int n, int nwords
   done[i] = TB_DONE_NO;
 }
 
+// diagnostics: SoA dword copy with the step kernel's access pattern (PMC calibration)
+__global__ void __launch_bounds__(256) tb_diag_copy_kernel(const uint32_t* src, uint32_t* dst, int n, int rows) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int r = 0; r < rows; ++r) dst[(size_t)r * n + i] = src[(size_t)r * n + i];
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 thread_local char g_err[512] = "";
@@ -589,6 +596,15 @@ int tb_counters(TbHandle* h, uint64_t* out, void* stream) {
   DeviceGuard g(h->device);
   HIP_TRY(hipMemcpyAsync(out, h->d_counters, sizeof(uint64_t) * TB_N_COUNTERS, hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return TB_OK;
+}
+
+int tb_diag_stream_copy(const uint32_t* src_dev, uint32_t* dst_dev, int n, int rows, int device, void* stream) {
+  if (!src_dev || !dst_dev || n <= 0 || rows <= 0) return fail(TB_E_INVAL, "tb_diag_stream_copy: bad argument");
+  DeviceGuard g(device);
+  if (g.err != hipSuccess) return fail((int)g.err, "hipSetDevice");
+  hipLaunchKernelGGL(tb_diag_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src_dev, dst_dev, n, rows);
+  HIP_TRY(hipGetLastError());
   return TB_OK;
 }
 

@@ -57,6 +57,8 @@ def load_library():
     L.tb_set_state.argtypes = [vp, vp, vp, i32, vp]
     L.tb_counters.argtypes = [vp, vp, vp]
     L.tb_counters_reset.argtypes = [vp, vp]
+    L.tb_diag_stream_copy.argtypes = [vp, vp, i32, i32, i32, vp]
+    L.tb_diag_stream_copy.restype = i32
     for f in ("tb_create", "tb_destroy", "tb_set_params", "tb_reset", "tb_step", "tb_rollout", "tb_get_state",
               "tb_set_state", "tb_counters", "tb_counters_reset", "tb_obs_dim", "tb_act_dim", "tb_state_words"):
         getattr(L, f).restype = i32

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 --pmc CSVs of tools/run_pmc.sh into the per-launch HBM traffic figure
+that bench.py reports as roofline.traffic.
+
+Corrections follow MI355X_MICROARCH.md (HBM section) and are CHECKED against this kernel's
+own access pattern by the calibration launches (tools/pmc_calibrate.py): FETCH_SIZE and
+WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of a coalesced stream
+(measured here for one-dword-per-lane rows: ratio printed as `fetch_calibration`), WRITE_SIZE
+reads exact."""
+import collections
+import csv
+import json
+import os
+import sys
+
+
+def per_kernel(path, counter, needle):
+    vals = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter and needle in r["Kernel_Name"]:
+            vals[int(r["Grid_Size"])].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in vals.items()}, {k: len(v) for k, v in vals.items()}
+
+
+def main(d, out):
+    cal_f, _ = per_kernel(os.path.join(d, "calib_FETCH_SIZE_counter_collection.csv"), "FETCH_SIZE", "tb_diag_copy_kernel")
+    cal_w, _ = per_kernel(os.path.join(d, "calib_WRITE_SIZE_counter_collection.csv"), "WRITE_SIZE", "tb_diag_copy_kernel")
+    rows = 30
+    big = max(cal_f)
+    truth_kib = rows * big * 4 / 1024.0
+    fetch_ratio = cal_f[big] / truth_kib
+    write_ratio = cal_w[big] / truth_kib
+    res = {"source": os.path.basename(d.rstrip("/")), "fetch_calibration": fetch_ratio, "write_calibration": write_ratio,
+           "fetch_correction": 1.0 / fetch_ratio, "workloads": {}}
+    for tag in ("swing4096", "swing1m"):
+        f, nf = per_kernel(os.path.join(d, "%s_FETCH_SIZE_counter_collection.csv" % tag), "FETCH_SIZE", "tb_step_kernel")
+        w, _ = per_kernel(os.path.join(d, "%s_WRITE_SIZE_counter_collection.csv" % tag), "WRITE_SIZE", "tb_step_kernel")
+        for n in f:
+            fb = f[n] * 1024.0 / fetch_ratio
+            wb = w[n] * 1024.0 / write_ratio
+            res["workloads"]["swing_%d" % n] = {
+                "launches": nf[n], "FETCH_SIZE_KiB_raw": f[n], "WRITE_SIZE_KiB_raw": w[n],
+                "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "traffic_bytes_per_launch": fb + wb,
+                "traffic_bytes_per_env_step": (fb + wb) / n, "algorithmic_bytes_per_env_step": 267}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
