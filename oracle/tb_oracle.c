@@ -24,7 +24,7 @@
  *
  * Arithmetic contract shared with the HIP kernels (DESIGN.md "Arithmetic contract"):
  * no implicit contraction; dot3 = fma(az,bz, fma(ay,by, ax*bx)); cross component
- * = fma(a1,b2, -(a2*b1)); IEEE sqrt and divide; sin/cos of the half rotation angle by
+ * = fma(a1,b2, -(a2*b1)); IEEE sqrt and divide; sinc/cos of the half rotation angle by
  * the fixed polynomials below (f32 build) or libm (f64 build).
  */
 #include "tb_oracle.h"
@@ -81,24 +81,26 @@ static inline q4 qmul(q4 a, q4 b) {
   return r;
 }
 
-/* sin/cos on [0, pi/8] (the half rotation angle is clamped to pi/8, see integrate_pose) */
-static inline real sin_small(real x) {
+/* Orientation step in terms of z = x^2, x = half the rotation angle of the substep (clamped
+ * to pi/8 by the pi/4 per-substep limit): sinc_half(z) = sin(x)/x, cos_half(z) = cos(x).
+ * Writing both as functions of z removes the square root and the division of the textbook
+ * form sin(x)/|w| (and with them Bullet's separate small-angle Taylor branch).
+ * f32 build: fixed Taylor polynomials, truncation < 1e-11 on [0, (pi/8)^2]. f64: libm. */
+static inline real sinc_half(real z) {
 #ifdef TBO_F64
-  return sin(x);
+  real x = sqrt(z);
+  return x > 1e-4 ? sin(x) / x : 1.0 - z / 6.0;
 #else
-  real z = x * x;
   real p = FMA(z, R(1.0 / 362880.0), R(-1.0 / 5040.0));
   p = FMA(z, p, R(1.0 / 120.0));
   p = FMA(z, p, R(-1.0 / 6.0));
-  p = FMA(z, p, R(1.0));
-  return x * p;
+  return FMA(z, p, R(1.0));
 #endif
 }
-static inline real cos_small(real x) {
+static inline real cos_half(real z) {
 #ifdef TBO_F64
-  return cos(x);
+  return cos(sqrt(z));
 #else
-  real z = x * x;
   real p = FMA(z, R(-1.0 / 3628800.0), R(1.0 / 40320.0));
   p = FMA(z, p, R(-1.0 / 720.0));
   p = FMA(z, p, R(1.0 / 24.0));
@@ -458,7 +460,8 @@ static void integrate_velocities(const Prm *P, Racket *rk, Ball *b, v3 Fr, v3 Tr
      * spins nor is torqued has zero angular acceleration and is left untouched */
     int active = (rk->w.x != R(0)) | (rk->w.y != R(0)) | (rk->w.z != R(0)) | (Tr.x != R(0)) | (Tr.y != R(0)) | (Tr.z != R(0));
     if (active) {
-      v3 wb = qrot_inv(rk->q, rk->w), Tb = qrot_inv(rk->q, Tr);
+      int torqued = (Tr.x != R(0)) | (Tr.y != R(0)) | (Tr.z != R(0));
+      v3 wb = qrot_inv(rk->q, rk->w), Tb = torqued ? qrot_inv(rk->q, Tr) : V3(R(0), R(0), R(0));
       v3 L = V3(P->racket_inertia[0] * wb.x, P->racket_inertia[1] * wb.y, P->racket_inertia[2] * wb.z);
       v3 gy = cross3(wb, L);
       real ka = FMA(P->ang_damp, SQRT(dot3(wb, wb)), P->ang_damp);
@@ -481,19 +484,25 @@ static void integrate_velocities(const Prm *P, Racket *rk, Ball *b, v3 Fr, v3 Tr
   }
 }
 
+/* Appendix B.1 step 4. Bullet's exponential map: q' = normalize((w s, c) (x) q) with
+ * s = sin(x)/|w|, c = cos(x), x = |w| dt / 2, and |w| dt clamped to max_ang_step WITHOUT
+ * rescaling w (the quirk is kept: s = (dt/2) sinc(x) in both cases, only z = x^2 is clamped).
+ * Unclamped, |q'|^2 = 1 + O(eps), so one Newton step of 1/sqrt at 1 normalises to O(eps^2). */
 static void integrate_pose(const Prm *P, Racket *rk, Ball *b) {
   const real dt = P->dt;
   rk->p = axpy3(dt, rk->v, rk->p);
   b->p = axpy3(dt, b->v, b->p);
-  real ang = SQRT(dot3(rk->w, rk->w));
-  if (ang > R(0)) {
-    if (ang * dt > P->max_ang_step) ang = P->max_ang_step * P->inv_dt;
-    real s;
-    if (ang < R(0.001)) s = FMA(-(((dt * dt) * dt) * R(0.020833333333)), ang * ang, R(0.5) * dt);
-    else s = sin_small((R(0.5) * ang) * dt) / ang;
-    q4 dq = {rk->w.x * s, rk->w.y * s, rk->w.z * s, cos_small((R(0.5) * ang) * dt)};
+  real w2 = dot3(rk->w, rk->w);
+  if (w2 > R(0)) {
+    real h = R(0.5) * dt, hm = R(0.5) * P->max_ang_step;
+    real z = (h * h) * w2, zc = hm * hm;
+    int clamped = z > zc;
+    if (clamped) z = zc;
+    real s = h * sinc_half(z);
+    q4 dq = {rk->w.x * s, rk->w.y * s, rk->w.z * s, cos_half(z)};
     q4 q = qmul(dq, rk->q);
-    real inv = R(1) / SQRT(FMA(q.w, q.w, FMA(q.z, q.z, FMA(q.y, q.y, q.x * q.x))));
+    real n2 = FMA(q.w, q.w, FMA(q.z, q.z, FMA(q.y, q.y, q.x * q.x)));
+    real inv = clamped ? R(1) / SQRT(n2) : FMA(R(-0.5), n2, R(1.5));
     rk->q.x = q.x * inv; rk->q.y = q.y * inv; rk->q.z = q.z * inv; rk->q.w = q.w * inv;
   }
 }

@@ -57,17 +57,15 @@ TB_DEV quat qmul(quat a, quat b) {
   r.z = FMA(a.z, b.w, FMA(-a.y, b.x, FMA(a.x, b.y, a.w * b.z)));
   return r;
 }
-// half rotation angle is clamped to pi/8: degree-9 / degree-10 Taylor is below 1 ulp there
-TB_DEV float sin_small(float x) {
-  float z = x * x;
+// orientation step as functions of z = x^2 (x = half the substep rotation angle, <= pi/8):
+// sinc_half(z) = sin(x)/x, cos_half(z) = cos(x); no sqrt, no divide, no small-angle branch
+TB_DEV float sinc_half(float z) {
   float p = FMA(z, (float)(1.0 / 362880.0), (float)(-1.0 / 5040.0));
   p = FMA(z, p, (float)(1.0 / 120.0));
   p = FMA(z, p, (float)(-1.0 / 6.0));
-  p = FMA(z, p, 1.0f);
-  return x * p;
+  return FMA(z, p, 1.0f);
 }
-TB_DEV float cos_small(float x) {
-  float z = x * x;
+TB_DEV float cos_half(float z) {
   float p = FMA(z, (float)(-1.0 / 3628800.0), (float)(1.0 / 40320.0));
   p = FMA(z, p, (float)(-1.0 / 720.0));
   p = FMA(z, p, (float)(1.0 / 24.0));
@@ -102,6 +100,7 @@ struct KParams {
   float rest_racket, rest_court, rest_goal, fric_racket, fric_court, fric_goal;
   float ground_half[3], net_half[3], goal_radius, goal_half_len;
   float static_top;  // highest point of any enabled static shape (host-derived)
+  float hull_box[4]; // outline bounding box in the COM frame: ymin, ymax, zmin, zmax (host-derived)
   int n_hull;
 };
 
@@ -129,9 +128,20 @@ TB_DEV bool racket_in_reach(const KParams& P, vec3 d) {
 }
 TB_DEV Hit sphere_vs_racket_sweep(const KParams& P, const float4* hull, const Racket& rk, vec3 d) {
   Hit h;
+  h.hit = false; h.dist = 0.0f; h.n = mk(0, 0, 0); h.rr = mk(0, 0, 0);
   const float r = P.ball_radius, thr = P.contact_threshold;
   vec3 l = rotate_inv(rk.q, d);
   float ax = fabsf(l.x) - P.racket_half_thick;
+  // Local-frame culls before the 38-edge sweep. In a SwingRacket episode the ball starts
+  // 0.47 m in FRONT of the face, inside the bounding sphere, and falls alongside the racket:
+  // without these every substep of every lane would sweep the outline.
+  //  (1) slab: the distance to the prism is >= ax (its x separation), and the sweep's own
+  //      result is monotone in it, so (ax - margin) - r >= thr implies "no hit" exactly;
+  //  (2) outline bounding box: the 2-D distance is >= the box separation; 0.1 mm of slack
+  //      covers the sweep's rounding, lanes inside the slack just run the exact sweep.
+  if ((ax - P.hull_margin) - r >= thr) return h;
+  float ay = fmaxf(l.y - P.hull_box[1], P.hull_box[0] - l.y), az = fmaxf(l.z - P.hull_box[3], P.hull_box[2] - l.z);
+  if ((fmaxf(ay, az) - P.hull_margin) - r >= thr + 1.0e-4f) return h;
   float sx = l.x < 0.0f ? -1.0f : 1.0f;
   bool inside = true;
   int deep_edge = 0;
@@ -353,8 +363,13 @@ TB_DEV void integrate_velocities(const KParams& P, Racket& rk, Ball& b, vec3 Fr,
     // body-frame round trip (Tennisbot rackets until they are hit; every fast-forward substep
     // of a racket that was never torqued)
     bool active = (rk.w.x != 0.0f) | (rk.w.y != 0.0f) | (rk.w.z != 0.0f) | (Tr.x != 0.0f) | (Tr.y != 0.0f) | (Tr.z != 0.0f);
+#ifdef TB_DIAG_NO_ANGULAR  // timing-only ablation builds (tools/diag_substep.py); results are wrong
+    active = false;
+#endif
     if (active) {
-      vec3 wb = rotate_inv(rk.q, rk.w), Tb = rotate_inv(rk.q, Tr);
+      bool torqued = (Tr.x != 0.0f) | (Tr.y != 0.0f) | (Tr.z != 0.0f);
+      vec3 wb = rotate_inv(rk.q, rk.w), Tb = mk(0.0f, 0.0f, 0.0f);
+      if (torqued) Tb = rotate_inv(rk.q, Tr);
       vec3 L = mk(P.racket_inertia[0] * wb.x, P.racket_inertia[1] * wb.y, P.racket_inertia[2] * wb.z);
       vec3 gy = cross(wb, L);
       float ka = FMA(P.ang_damp, sqrtf(dot(wb, wb)), P.ang_damp);
@@ -378,19 +393,28 @@ TB_DEV void integrate_velocities(const KParams& P, Racket& rk, Ball& b, vec3 Fr,
   }
 }
 
+// exponential-map orientation update with Bullet's pi/4 clamp quirk (w is not rescaled, only
+// z = x^2 is clamped); unclamped |q'|^2 = 1 + O(eps): one Newton step of 1/sqrt normalises
 TB_DEV void integrate_pose(const KParams& P, Racket& rk, Ball& b) {
   const float dt = P.dt;
   rk.p = fma3(dt, rk.v, rk.p);
   b.p = fma3(dt, b.v, b.p);
-  float ang = sqrtf(dot(rk.w, rk.w));
-  if (ang > 0.0f) {
-    if (ang * dt > P.max_ang_step) ang = P.max_ang_step * P.inv_dt;
-    float s;
-    if (ang < 0.001f) s = FMA(-(((dt * dt) * dt) * 0.020833333333f), ang * ang, 0.5f * dt);
-    else s = sin_small((0.5f * ang) * dt) / ang;
-    quat dq; dq.x = rk.w.x * s; dq.y = rk.w.y * s; dq.z = rk.w.z * s; dq.w = cos_small((0.5f * ang) * dt);
+  float w2 = dot(rk.w, rk.w);
+#ifdef TB_DIAG_NO_ORIENT
+  w2 = 0.0f;
+#endif
+  if (w2 > 0.0f) {
+    float h = 0.5f * dt, hm = 0.5f * P.max_ang_step;
+    float z = (h * h) * w2, zc = hm * hm;
+    bool clamped = z > zc;
+    if (clamped) z = zc;
+    float s = h * sinc_half(z);
+    quat dq; dq.x = rk.w.x * s; dq.y = rk.w.y * s; dq.z = rk.w.z * s; dq.w = cos_half(z);
     quat q = qmul(dq, rk.q);
-    float inv = 1.0f / sqrtf(FMA(q.w, q.w, FMA(q.z, q.z, FMA(q.y, q.y, q.x * q.x))));
+    float n2 = FMA(q.w, q.w, FMA(q.z, q.z, FMA(q.y, q.y, q.x * q.x)));
+    float inv;
+    if (__builtin_expect(clamped, 0)) inv = 1.0f / sqrtf(n2);
+    else inv = FMA(-0.5f, n2, 1.5f);
     rk.q.x = q.x * inv; rk.q.y = q.y * inv; rk.q.z = q.z * inv; rk.q.w = q.w * inv;
   }
 }
@@ -409,12 +433,18 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, ve
 
   vec3 d = b.p - rk.p;
   bool near_racket = (P.flags & TB_F_RACKET_BALL) && racket_in_reach(P, d);
+#ifdef TB_DIAG_NO_NARROW
+  near_racket = false;
+#endif
   if (__any(near_racket)) {
     if (near_racket) hr = sphere_vs_racket_sweep(P, hull, rk, d);
   }
   // every static shape lies below static_top: a ball whose lowest point clears it by the
   // manifold threshold (+1 mm of slack against rounding) is culled by each exact test as well
   bool near_static = !(((b.p.z - P.ball_radius) - P.contact_threshold) >= P.static_top + 1.0e-3f);
+#ifdef TB_DIAG_NO_NARROW
+  near_static = false;
+#endif
   if (__any(near_static)) {
     if (near_static) {
       hg = sphere_vs_box(P, P.ground_half[0], P.ground_half[1], P.ground_half[2], b.p);

@@ -414,6 +414,12 @@ void to_kparams(const TbParams* p, KParams* k) {
   float top = p->ground_half[2] > p->goal_half_len ? p->ground_half[2] : p->goal_half_len;
   if ((p->flags & TB_F_NET) && p->net_half[2] > top) top = p->net_half[2];
   k->static_top = top;
+  float ymin = p->hull_edges[0][0], ymax = ymin, zmin = p->hull_edges[0][1], zmax = zmin;
+  for (int i = 1; i < p->n_hull; ++i) {
+    float y = p->hull_edges[i][0], z = p->hull_edges[i][1];
+    ymin = y < ymin ? y : ymin; ymax = y > ymax ? y : ymax; zmin = z < zmin ? z : zmin; zmax = z > zmax ? z : zmax;
+  }
+  k->hull_box[0] = ymin; k->hull_box[1] = ymax; k->hull_box[2] = zmin; k->hull_box[3] = zmax;
 }
 
 }  // namespace
