@@ -103,7 +103,9 @@ typedef struct TbParams {
   float rest_vel_threshold; /* 0.2 m/s: below it restitution is 0 */
   float erp;                /* 0.2 Baumgarte */
   float contact_threshold;  /* 0.02 * ball radius: manifold keeps points closer than this */
-  int32_t solver_iters;     /* sequential-impulse iterations (Bullet default 50) */
+  int32_t solver_iters;     /* sequential-impulse iteration cap (Bullet default 50) */
+  float solver_tol;         /* stop early once every impulse update of a sweep is <= tol * |impulse|
+                             * (float32 PGS otherwise oscillates by a few ulp and always runs to the cap) */
   uint32_t flags;           /* TB_F_* */
   /* racket: racket.urdf:17-21, racket.py:43-45 */
   float racket_mass, racket_inv_mass;

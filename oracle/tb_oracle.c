@@ -138,7 +138,7 @@ static inline real uniform(real lo, real span, uint32_t u) { return lo + span * 
  * reference's float64 PyBullet build. */
 typedef struct {
   real dt, inv_dt, gravity, lin_damp, ang_damp, max_ang_step, rest_vel_threshold, erp, contact_threshold;
-  int solver_iters; uint32_t flags;
+  int solver_iters; uint32_t flags; real solver_tol;
   real racket_inv_mass, racket_inertia[3], racket_inv_inertia[3], racket_com[3], racket_half_thick, hull_margin, hull_bound_radius;
   real ball_inv_mass, ball_inv_inertia, ball_radius, magnus_k, ball_spin_max;
   real rest_racket, rest_court, rest_goal, fric_racket, fric_court, fric_goal;
@@ -168,7 +168,7 @@ static void prm_from(Prm *Q, const TbParams *P) {
   Q->dt = W(P->dt);
   Q->gravity = W(P->gravity); Q->lin_damp = W(P->lin_damp); Q->ang_damp = W(P->ang_damp);
   Q->max_ang_step = W(P->max_ang_step); Q->rest_vel_threshold = W(P->rest_vel_threshold); Q->erp = W(P->erp);
-  Q->contact_threshold = W(P->contact_threshold); Q->solver_iters = P->solver_iters; Q->flags = P->flags;
+  Q->contact_threshold = W(P->contact_threshold); Q->solver_iters = P->solver_iters; Q->flags = P->flags; Q->solver_tol = W(P->solver_tol);
   Q->racket_inv_mass = W(P->racket_inv_mass);
   for (int i = 0; i < 3; ++i) {
     Q->racket_inertia[i] = W(P->racket_inertia[i]); Q->racket_inv_inertia[i] = W(P->racket_inv_inertia[i]);
@@ -347,7 +347,9 @@ static Hit sphere_vs_goal(const Prm *P, real gx, real gy, v3 c) {
  * Sequential impulses as in Bullet's multibody solver:
  * normal row with restitution (product rule, velocity threshold), Baumgarte ERP on
  * penetration, speculative margin on positive distance; two friction rows along
- * btPlaneSpace1(n), each boxed by mu * normal impulse. No warm start. */
+ * btPlaneSpace1(n), each boxed by mu * normal impulse. No warm start. Bullet always runs its
+ * iteration cap; here a sweep whose every update is <= solver_tol * |impulse| ends the solve
+ * (converged to ~1e-6 relative; in float32 the updates otherwise oscillate by ulps forever). */
 typedef struct {
   int racket; /* 1: other body is the racket, 0: static */
   v3 n, rr, t1, t2;
@@ -417,7 +419,7 @@ static void solve_contacts(const Prm *P, Row *rows, int nrows, Racket *rk, Ball 
       if (jn < R(0)) jn = R(0);
       real d = jn - c->jn;
       c->jn = jn;
-      if (d != R(0)) { moved = 1; apply_impulse(P, c, rk, b, rb, c->n, d, 0); }
+      if (d != R(0)) { apply_impulse(P, c, rk, b, rb, c->n, d, 0); if (FABS(d) > P->solver_tol * FABS(jn)) moved = 1; }
     }
     for (int i = 0; i < nrows; ++i) {
       Row *c = &rows[i];
@@ -433,7 +435,7 @@ static void solve_contacts(const Prm *P, Row *rows, int nrows, Racket *rk, Ball 
         jt = jt < -lim ? -lim : (jt > lim ? lim : jt);
         real d = jt - *acc;
         *acc = jt;
-        if (d != R(0)) { moved = 1; apply_impulse(P, c, rk, b, rb, t, d, 1); }
+        if (d != R(0)) { apply_impulse(P, c, rk, b, rb, t, d, 1); if (FABS(d) > P->solver_tol * FABS(jt)) moved = 1; }
       }
     }
     if (!moved) break;

@@ -94,7 +94,7 @@ TB_DEV float uniform(float lo, float span, uint32_t u) { return lo + span * ((fl
 // the outline table goes through LDS
 struct KParams {
   float dt, inv_dt, gravity, lin_damp, ang_damp, max_ang_step, rest_vel_threshold, erp, contact_threshold;
-  int solver_iters; uint32_t flags;
+  int solver_iters; uint32_t flags; float solver_tol;
   float racket_inv_mass, racket_inertia[3], racket_inv_inertia[3], racket_com[3], racket_half_thick, hull_margin, hull_bound_radius;
   float ball_inv_mass, ball_inv_inertia, ball_radius, magnus_k, ball_spin_max;
   float rest_racket, rest_court, rest_goal, fric_racket, fric_court, fric_goal;
@@ -312,7 +312,7 @@ TB_DEV bool solve_normal(const KParams& P, Row& c, Racket& rk, Ball& b) {
   if (jn < 0.0f) jn = 0.0f;
   float d = jn - c.jn;
   c.jn = jn;
-  if (d != 0.0f) { apply_impulse(P, c, rk, b, rb, c.n, d, false); return true; }
+  if (d != 0.0f) { apply_impulse(P, c, rk, b, rb, c.n, d, false); return fabsf(d) > P.solver_tol * fabsf(jn); }
   return false;
 }
 TB_DEV bool solve_friction(const KParams& P, Row& c, Racket& rk, Ball& b) {
@@ -326,7 +326,7 @@ TB_DEV bool solve_friction(const KParams& P, Row& c, Racket& rk, Ball& b) {
     jt = jt < -lim ? -lim : (jt > lim ? lim : jt);
     float d = jt - c.jt1;
     c.jt1 = jt;
-    if (d != 0.0f) { moved = true; apply_impulse(P, c, rk, b, rb, c.t1, d, true); }
+    if (d != 0.0f) { apply_impulse(P, c, rk, b, rb, c.t1, d, true); moved |= fabsf(d) > P.solver_tol * fabsf(jt); }
   }
   {
     float vt = dot(c.t2, rel_vel(c, rk, b, rb));
@@ -334,7 +334,7 @@ TB_DEV bool solve_friction(const KParams& P, Row& c, Racket& rk, Ball& b) {
     jt = jt < -lim ? -lim : (jt > lim ? lim : jt);
     float d = jt - c.jt2;
     c.jt2 = jt;
-    if (d != 0.0f) { moved = true; apply_impulse(P, c, rk, b, rb, c.t2, d, true); }
+    if (d != 0.0f) { apply_impulse(P, c, rk, b, rb, c.t2, d, true); moved |= fabsf(d) > P.solver_tol * fabsf(jt); }
   }
   return moved;
 }

@@ -392,13 +392,14 @@ int validate_params(const TbParams* p) {
     if (!(p->racket_inertia[i] > 0.0f) || !(p->racket_inv_inertia[i] > 0.0f)) return fail(TB_E_PARAMS, "TbParams.racket_inertia must be positive");
   if (!(p->ball_radius > 0.0f) || !(p->contact_threshold >= 0.0f)) return fail(TB_E_PARAMS, "TbParams.ball_radius / contact_threshold invalid");
   if (p->solver_iters < 1 || p->solver_iters > 1000) return fail(TB_E_PARAMS, "TbParams.solver_iters must be in [1, 1000]");
+  if (!(p->solver_tol >= 0.0f)) return fail(TB_E_PARAMS, "TbParams.solver_tol must be >= 0");
   return TB_OK;
 }
 
 void to_kparams(const TbParams* p, KParams* k) {
   k->dt = p->dt; k->inv_dt = p->inv_dt; k->gravity = p->gravity; k->lin_damp = p->lin_damp; k->ang_damp = p->ang_damp;
   k->max_ang_step = p->max_ang_step; k->rest_vel_threshold = p->rest_vel_threshold; k->erp = p->erp;
-  k->contact_threshold = p->contact_threshold; k->solver_iters = p->solver_iters; k->flags = p->flags;
+  k->contact_threshold = p->contact_threshold; k->solver_iters = p->solver_iters; k->flags = p->flags; k->solver_tol = p->solver_tol;
   k->racket_inv_mass = p->racket_inv_mass;
   for (int i = 0; i < 3; ++i) {
     k->racket_inertia[i] = p->racket_inertia[i]; k->racket_inv_inertia[i] = p->racket_inv_inertia[i];

@@ -49,7 +49,7 @@ class TbParams(ctypes.Structure):
         ("dt", ctypes.c_float), ("inv_dt", ctypes.c_float), ("gravity", ctypes.c_float),
         ("lin_damp", ctypes.c_float), ("ang_damp", ctypes.c_float), ("max_ang_step", ctypes.c_float),
         ("rest_vel_threshold", ctypes.c_float), ("erp", ctypes.c_float), ("contact_threshold", ctypes.c_float),
-        ("solver_iters", ctypes.c_int32), ("flags", ctypes.c_uint32),
+        ("solver_iters", ctypes.c_int32), ("solver_tol", ctypes.c_float), ("flags", ctypes.c_uint32),
         ("racket_mass", ctypes.c_float), ("racket_inv_mass", ctypes.c_float),
         ("racket_inertia", ctypes.c_float * 3), ("racket_inv_inertia", ctypes.c_float * 3),
         ("racket_com", ctypes.c_float * 3), ("racket_half_thick", ctypes.c_float),
@@ -111,7 +111,7 @@ def default_params(racket_scale=1.0, flags=F_DEFAULT, scene=None, **overrides):
         max_ang_step=0.25 * math.pi,
         rest_vel_threshold=0.2, erp=0.2,
         contact_threshold=0.02 * bl["radius"],
-        solver_iters=50,
+        solver_iters=50, solver_tol=4e-6,
         racket_mass=rk["mass"], racket_inertia=tuple(rk["inertia_diag"]),
         hull_margin=0.001,
         ball_mass=bl["mass"], ball_inertia=bl["inertia_diag"][0], ball_radius=bl["radius"],
@@ -131,7 +131,7 @@ def default_params(racket_scale=1.0, flags=F_DEFAULT, scene=None, **overrides):
 
     p = TbParams()
     for k in ("dt", "gravity", "lin_damp", "ang_damp", "max_ang_step", "rest_vel_threshold", "erp",
-              "contact_threshold", "racket_mass", "hull_margin", "ball_mass", "ball_radius", "magnus_k",
+              "contact_threshold", "solver_tol", "racket_mass", "hull_margin", "ball_mass", "ball_radius", "magnus_k",
               "ball_spin_max", "rest_racket", "rest_court", "rest_goal", "fric_racket", "fric_court",
               "fric_goal", "goal_radius", "goal_half_len"):
         setattr(p, k, float(prim[k]))
