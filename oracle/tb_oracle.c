@@ -250,14 +250,18 @@ static Hit sphere_vs_racket(const Prm *P, const Racket *rk, v3 c) {
     real ay = E[0], az = E[1], ey = E[2], ez = E[3], il2 = E[4], il = E[5];
     real wy = l.y - ay, wz = l.z - az;
     real cr = FMA(ey, wz, -(ez * wy));
-    if (cr < R(0)) inside = 0;
     real sd = -(cr * il);
     if (sd > max_sd) { max_sd = sd; deep_edge = i; }
-    real t = FMA(wy, ey, wz * ez) * il2;
-    t = t < R(0) ? R(0) : (t > R(1) ? R(1) : t);
-    real ry = FMA(-t, ey, wy), rz = FMA(-t, ez, wz);
-    real d2 = FMA(ry, ry, rz * rz);
-    if (d2 < best_d2) { best_d2 = d2; best_ry = ry; best_rz = rz; }
+    /* the closest boundary point of a convex outline lies on an edge that faces the point
+     * (cr < 0): edges seen from behind cannot hold it and are skipped */
+    if (cr < R(0)) {
+      inside = 0;
+      real t = FMA(wy, ey, wz * ez) * il2;
+      t = t < R(0) ? R(0) : (t > R(1) ? R(1) : t);
+      real ry = FMA(-t, ey, wy), rz = FMA(-t, ez, wz);
+      real d2 = FMA(ry, ry, rz * rz);
+      if (d2 < best_d2) { best_d2 = d2; best_ry = ry; best_rz = rz; }
+    }
   }
   real dist_hull; v3 nl;
   if (inside) {

@@ -24,6 +24,7 @@
 #include "../../include/tb_stepper.h"
 
 #define TB_DEV __device__ __forceinline__
+#define TB_N_CULL 12
 #define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 
 namespace tb {
@@ -100,7 +101,10 @@ struct KParams {
   float rest_racket, rest_court, rest_goal, fric_racket, fric_court, fric_goal;
   float ground_half[3], net_half[3], goal_radius, goal_half_len;
   float static_top;  // highest point of any enabled static shape (host-derived)
-  float hull_box[4]; // outline bounding box in the COM frame: ymin, ymax, zmin, zmax (host-derived)
+  // conservative convex superset of the outline (host-derived): half-planes n.p <= h in the COM
+  // (y, z) frame -- 8 fixed directions + the longest edges. dist(p, outline) >= max(n.p - h).
+  float cull_planes[TB_N_CULL][3];
+  float ball_kn, ball_kt;  // 1/inv_mass and 1/(inv_mass + inv_inertia r^2): ball-only effective masses (host-derived)
   int n_hull;
 };
 
@@ -115,6 +119,28 @@ struct Hit {
 };
 
 constexpr int CT_RACKET = 1, CT_GROUND = 2, CT_NET = 4, CT_GOAL = 8;
+
+// In-kernel stamps for the diagnostic build only (-DTB_DIAG_STAMPS, tools/diag_stamps.py):
+// cycles per substep segment, summed per wave into g_diag_cycles. Never compiled into the product.
+#ifdef TB_DIAG_STAMPS
+__device__ unsigned long long g_diag_cycles[16];
+struct Stamps { unsigned long long t; unsigned int acc[8]; };
+__device__ Stamps g_unused_stamps;
+TB_DEV unsigned long long stamp_now() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define TB_STAMP(st, k) do { unsigned long long _n = stamp_now(); (st).acc[k] += (unsigned int)(_n - (st).t); (st).t = _n; } while (0)
+#define TB_STAMP_ARG , Stamps& st
+#define TB_STAMP_PASS , st
+#else
+#define TB_STAMP(st, k) do { } while (0)
+#define TB_STAMP_ARG
+#define TB_STAMP_PASS
+#endif
 
 // ---------------------------------------------------------------- narrowphase
 // sphere vs racket: prism over the convex (y, z) outline of racket.stl in the COM frame,
@@ -137,11 +163,22 @@ TB_DEV Hit sphere_vs_racket_sweep(const KParams& P, const float4* hull, const Ra
   // without these every substep of every lane would sweep the outline.
   //  (1) slab: the distance to the prism is >= ax (its x separation), and the sweep's own
   //      result is monotone in it, so (ax - margin) - r >= thr implies "no hit" exactly;
-  //  (2) outline bounding box: the 2-D distance is >= the box separation; 0.1 mm of slack
-  //      covers the sweep's rounding, lanes inside the slack just run the exact sweep.
+  //  (2) a 12-plane convex superset of the outline: the 2-D distance is >= the largest plane
+  //      separation; 0.1 mm of slack covers all rounding, lanes inside the slack just run the
+  //      exact sweep. (A plain bounding box is too loose next to the handle, where the outline
+  //      is a narrow wedge: a tumbling racket's ball spends many substeps there.)
   if ((ax - P.hull_margin) - r >= thr) return h;
-  float ay = fmaxf(l.y - P.hull_box[1], P.hull_box[0] - l.y), az = fmaxf(l.z - P.hull_box[3], P.hull_box[2] - l.z);
-  if ((fmaxf(ay, az) - P.hull_margin) - r >= thr + 1.0e-4f) return h;
+  float sep = -3.0e38f;
+#pragma unroll
+  for (int k = 0; k < TB_N_CULL; ++k) sep = fmaxf(sep, FMA(P.cull_planes[k][1], l.z, P.cull_planes[k][0] * l.y) - P.cull_planes[k][2]);
+  if ((sep - P.hull_margin) - r >= thr + 1.0e-4f) return h;
+#ifdef TB_DIAG_STAMPS
+  {
+    unsigned long long m = __ballot(1);
+    atomicAdd(&g_diag_cycles[10], 1ull);                                              // lane-sweeps
+    if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)m) - 1u) atomicAdd(&g_diag_cycles[11], 1ull);  // wave-sweeps
+  }
+#endif
   float sx = l.x < 0.0f ? -1.0f : 1.0f;
   bool inside = true;
   int deep_edge = 0;
@@ -151,14 +188,18 @@ TB_DEV Hit sphere_vs_racket_sweep(const KParams& P, const float4* hull, const Ra
     float4 e1 = hull[2 * i + 1];
     float wy = l.y - e0.x, wz = l.z - e0.y;
     float cr = FMA(e0.z, wz, -(e0.w * wy));
-    if (cr < 0.0f) inside = false;
     float sd = -(cr * e1.y);
     if (sd > max_sd) { max_sd = sd; deep_edge = i; }
-    float t = FMA(wy, e0.z, wz * e0.w) * e1.x;
-    t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
-    float ry = FMA(-t, e0.z, wy), rz = FMA(-t, e0.w, wz);
-    float d2 = FMA(ry, ry, rz * rz);
-    if (d2 < best_d2) { best_d2 = d2; best_ry = ry; best_rz = rz; }
+    // the closest boundary point of a convex outline lies on an edge that faces the point
+    // (cr < 0); edges seen from behind cannot hold it and are skipped
+    if (cr < 0.0f) {
+      inside = false;
+      float t = FMA(wy, e0.z, wz * e0.w) * e1.x;
+      t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+      float ry = FMA(-t, e0.z, wy), rz = FMA(-t, e0.w, wz);
+      float d2 = FMA(ry, ry, rz * rz);
+      if (d2 < best_d2) { best_d2 = d2; best_ry = ry; best_rz = rz; }
+    }
   }
   float dist_hull; vec3 nl;
   if (inside) {
@@ -244,9 +285,20 @@ TB_DEV Hit sphere_vs_goal(const KParams& P, float gx, float gy, vec3 c) {
 }
 
 // ---------------------------------------------------------------- sequential-impulse contact rows
-struct Row {
-  bool racket;
-  vec3 n, rr, t1, t2;
+// Sequential impulses as in Bullet's multibody solver: normal
+// row with restitution / ERP / speculative margin, two friction rows along btPlaneSpace1(n)
+// boxed by mu * j_n. Rows live in registers and are indexed statically: slot 0 = racket pair,
+// slots 1..3 = ground, net, goal (visited in that order, inactive ones skipped = the order of a
+// compacted list). What does not change during a solve is computed once per row: the racket's
+// angular responses I_w^-1 (rr x dir) and, for static pairs, the ball-only effective masses
+// (host-derived constants). Same arithmetic as recomputing them every time, fewer instructions.
+struct RowS {  // ball vs static shape
+  vec3 n, t1, t2;
+  float mu, target, jn, jt1, jt2;
+};
+struct RowR {  // ball vs racket
+  vec3 n, t1, t2, rr;
+  vec3 an, at1, at2;  // I_w^-1 (rr x n), I_w^-1 (rr x t1), I_w^-1 (rr x t2)
   float mu, target, kn, kt1, kt2, jn, jt1, jt2;
 };
 
@@ -254,11 +306,6 @@ TB_DEV vec3 racket_invI(const KParams& P, quat q, vec3 x) {
   vec3 b = rotate_inv(q, x);
   b = mk(b.x * P.racket_inv_inertia[0], b.y * P.racket_inv_inertia[1], b.z * P.racket_inv_inertia[2]);
   return rotate(q, b);
-}
-TB_DEV vec3 rel_vel(const Row& c, const Racket& rk, const Ball& b, vec3 rb) {
-  vec3 pv = b.v + cross(b.w, rb);
-  if (c.racket) pv = pv - (rk.v + cross(rk.w, c.rr));
-  return pv;
 }
 TB_DEV void plane_space(vec3 n, vec3& p, vec3& q) {
   if (fabsf(n.z) > 0.7071067811865475244f) {
@@ -273,80 +320,115 @@ TB_DEV void plane_space(vec3 n, vec3& p, vec3& q) {
     q = mk(-(n.z * p.y), n.z * p.x, a * k);
   }
 }
-TB_DEV void apply_impulse(const KParams& P, const Row& c, Racket& rk, Ball& b, vec3 rb, vec3 dir, float j, bool angular_ball) {
-  b.v = fma3(j * P.ball_inv_mass, dir, b.v);
-  if (angular_ball) b.w = fma3(j * P.ball_inv_inertia, cross(rb, dir), b.w);
-  if (c.racket) {
-    rk.v = fma3(-(j * P.racket_inv_mass), dir, rk.v);
-    rk.w = fma3(-j, racket_invI(P, rk.q, cross(c.rr, dir)), rk.w);
-  }
-}
-TB_DEV void setup_row(const KParams& P, Row& c, const Hit& h, bool racket, float e, float mu, const Racket& rk, const Ball& b) {
-  const float r = P.ball_radius;
-  c.racket = racket; c.n = h.n; c.rr = h.rr; c.mu = mu;
-  c.jn = 0.0f; c.jt1 = 0.0f; c.jt2 = 0.0f;
-  plane_space(c.n, c.t1, c.t2);
-  vec3 rb = (-r) * c.n;
-  float kn = P.ball_inv_mass, kt1 = FMA(P.ball_inv_inertia, r * r, P.ball_inv_mass), kt2 = kt1;
-  if (racket) {
-    vec3 a;
-    a = cross(c.rr, c.n);  kn = (kn + P.racket_inv_mass) + dot(a, racket_invI(P, rk.q, a));
-    a = cross(c.rr, c.t1); kt1 = (kt1 + P.racket_inv_mass) + dot(a, racket_invI(P, rk.q, a));
-    a = cross(c.rr, c.t2); kt2 = (kt2 + P.racket_inv_mass) + dot(a, racket_invI(P, rk.q, a));
-  }
-  c.kn = 1.0f / kn; c.kt1 = 1.0f / kt1; c.kt2 = 1.0f / kt2;
-  float vn = dot(c.n, rel_vel(c, rk, b, rb));
+TB_DEV float contact_target(const KParams& P, float vn, float dist, float e) {
   float rest = fabsf(vn) < P.rest_vel_threshold ? 0.0f : e * (-vn);
   if (rest < 0.0f) rest = 0.0f;
-  float pos = h.dist > 0.0f ? -(h.dist * P.inv_dt) : -(h.dist * P.erp) * P.inv_dt;
-  c.target = rest + pos;
+  float pos = dist > 0.0f ? -(dist * P.inv_dt) : -(dist * P.erp) * P.inv_dt;
+  return rest + pos;
 }
-// rows live in registers: slots are indexed statically (0 racket, 1 ground, 2 net, 3 goal)
-// and skipped when inactive, which visits the active rows in the same order as a compacted list
-struct Rows { Row r[4]; bool on[4]; };
+// velocity of the ball's contact point (relative to the static world)
+TB_DEV vec3 ball_point_vel(const Ball& b, vec3 rb) { return b.v + cross(b.w, rb); }
+TB_DEV vec3 rel_vel_racket(const RowR& c, const Racket& rk, const Ball& b, vec3 rb) {
+  return ball_point_vel(b, rb) - (rk.v + cross(rk.w, c.rr));
+}
 
-TB_DEV bool solve_normal(const KParams& P, Row& c, Racket& rk, Ball& b) {
+TB_DEV void setup_static(const KParams& P, RowS& c, const Hit& h, float e, float mu, const Ball& b) {
+  c.n = h.n; c.mu = mu; c.jn = 0.0f; c.jt1 = 0.0f; c.jt2 = 0.0f;
+  plane_space(c.n, c.t1, c.t2);
   vec3 rb = (-P.ball_radius) * c.n;
-  float vn = dot(c.n, rel_vel(c, rk, b, rb));
-  float jn = FMA(c.target - vn, c.kn, c.jn);
+  c.target = contact_target(P, dot(c.n, ball_point_vel(b, rb)), h.dist, e);
+}
+TB_DEV void setup_racket(const KParams& P, RowR& c, const Hit& h, const Racket& rk, const Ball& b) {
+  const float r = P.ball_radius;
+  c.n = h.n; c.rr = h.rr; c.mu = P.fric_racket; c.jn = 0.0f; c.jt1 = 0.0f; c.jt2 = 0.0f;
+  plane_space(c.n, c.t1, c.t2);
+  float kt = FMA(P.ball_inv_inertia, r * r, P.ball_inv_mass);
+  vec3 a;
+  a = cross(c.rr, c.n);  c.an = racket_invI(P, rk.q, a);  c.kn = 1.0f / ((P.ball_inv_mass + P.racket_inv_mass) + dot(a, c.an));
+  a = cross(c.rr, c.t1); c.at1 = racket_invI(P, rk.q, a); c.kt1 = 1.0f / ((kt + P.racket_inv_mass) + dot(a, c.at1));
+  a = cross(c.rr, c.t2); c.at2 = racket_invI(P, rk.q, a); c.kt2 = 1.0f / ((kt + P.racket_inv_mass) + dot(a, c.at2));
+  vec3 rb = (-r) * c.n;
+  c.target = contact_target(P, dot(c.n, rel_vel_racket(c, rk, b, rb)), h.dist, P.rest_racket);
+}
+
+TB_DEV bool clamp_friction(float vt, float kt, float lim, float tol, float& acc, float& d) {
+  float jt = FMA(-vt, kt, acc);
+  jt = jt < -lim ? -lim : (jt > lim ? lim : jt);
+  d = jt - acc;
+  acc = jt;
+  return fabsf(d) > tol * fabsf(jt);
+}
+
+TB_DEV bool normal_static(const KParams& P, RowS& c, Ball& b) {
+  vec3 rb = (-P.ball_radius) * c.n;
+  float vn = dot(c.n, ball_point_vel(b, rb));
+  float jn = FMA(c.target - vn, P.ball_kn, c.jn);
   if (jn < 0.0f) jn = 0.0f;
   float d = jn - c.jn;
   c.jn = jn;
-  if (d != 0.0f) { apply_impulse(P, c, rk, b, rb, c.n, d, false); return fabsf(d) > P.solver_tol * fabsf(jn); }
-  return false;
+  if (d == 0.0f) return false;
+  b.v = fma3(d * P.ball_inv_mass, c.n, b.v);
+  return fabsf(d) > P.solver_tol * fabsf(jn);
 }
-TB_DEV bool solve_friction(const KParams& P, Row& c, Racket& rk, Ball& b) {
+TB_DEV bool friction_static(const KParams& P, RowS& c, Ball& b) {
   float lim = c.mu * c.jn;
   if (!(lim > 0.0f)) return false;
   bool moved = false;
   vec3 rb = (-P.ball_radius) * c.n;
-  {
-    float vt = dot(c.t1, rel_vel(c, rk, b, rb));
-    float jt = FMA(-vt, c.kt1, c.jt1);
-    jt = jt < -lim ? -lim : (jt > lim ? lim : jt);
-    float d = jt - c.jt1;
-    c.jt1 = jt;
-    if (d != 0.0f) { apply_impulse(P, c, rk, b, rb, c.t1, d, true); moved |= fabsf(d) > P.solver_tol * fabsf(jt); }
+  float d;
+  bool m = clamp_friction(dot(c.t1, ball_point_vel(b, rb)), P.ball_kt, lim, P.solver_tol, c.jt1, d);
+  if (d != 0.0f) { moved |= m; b.v = fma3(d * P.ball_inv_mass, c.t1, b.v); b.w = fma3(d * P.ball_inv_inertia, cross(rb, c.t1), b.w); }
+  m = clamp_friction(dot(c.t2, ball_point_vel(b, rb)), P.ball_kt, lim, P.solver_tol, c.jt2, d);
+  if (d != 0.0f) { moved |= m; b.v = fma3(d * P.ball_inv_mass, c.t2, b.v); b.w = fma3(d * P.ball_inv_inertia, cross(rb, c.t2), b.w); }
+  return moved;
+}
+TB_DEV bool normal_racket(const KParams& P, RowR& c, Racket& rk, Ball& b) {
+  vec3 rb = (-P.ball_radius) * c.n;
+  float vn = dot(c.n, rel_vel_racket(c, rk, b, rb));
+  float jn = FMA(c.target - vn, c.kn, c.jn);
+  if (jn < 0.0f) jn = 0.0f;
+  float d = jn - c.jn;
+  c.jn = jn;
+  if (d == 0.0f) return false;
+  b.v = fma3(d * P.ball_inv_mass, c.n, b.v);
+  rk.v = fma3(-(d * P.racket_inv_mass), c.n, rk.v);
+  rk.w = fma3(-d, c.an, rk.w);
+  return fabsf(d) > P.solver_tol * fabsf(jn);
+}
+TB_DEV bool friction_racket(const KParams& P, RowR& c, Racket& rk, Ball& b) {
+  float lim = c.mu * c.jn;
+  if (!(lim > 0.0f)) return false;
+  bool moved = false;
+  vec3 rb = (-P.ball_radius) * c.n;
+  float d;
+  bool m = clamp_friction(dot(c.t1, rel_vel_racket(c, rk, b, rb)), c.kt1, lim, P.solver_tol, c.jt1, d);
+  if (d != 0.0f) {
+    moved |= m;
+    b.v = fma3(d * P.ball_inv_mass, c.t1, b.v); b.w = fma3(d * P.ball_inv_inertia, cross(rb, c.t1), b.w);
+    rk.v = fma3(-(d * P.racket_inv_mass), c.t1, rk.v); rk.w = fma3(-d, c.at1, rk.w);
   }
-  {
-    float vt = dot(c.t2, rel_vel(c, rk, b, rb));
-    float jt = FMA(-vt, c.kt2, c.jt2);
-    jt = jt < -lim ? -lim : (jt > lim ? lim : jt);
-    float d = jt - c.jt2;
-    c.jt2 = jt;
-    if (d != 0.0f) { apply_impulse(P, c, rk, b, rb, c.t2, d, true); moved |= fabsf(d) > P.solver_tol * fabsf(jt); }
+  m = clamp_friction(dot(c.t2, rel_vel_racket(c, rk, b, rb)), c.kt2, lim, P.solver_tol, c.jt2, d);
+  if (d != 0.0f) {
+    moved |= m;
+    b.v = fma3(d * P.ball_inv_mass, c.t2, b.v); b.w = fma3(d * P.ball_inv_inertia, cross(rb, c.t2), b.w);
+    rk.v = fma3(-(d * P.racket_inv_mass), c.t2, rk.v); rk.w = fma3(-d, c.at2, rk.w);
   }
   return moved;
 }
+
+struct Rows { RowR rk; RowS st[3]; bool on[4]; };
+
 TB_DEV void solve_contacts(const KParams& P, Rows& R, Racket& rk, Ball& b) {
   for (int it = 0; it < P.solver_iters; ++it) {
     bool moved = false;
+    if (R.on[0]) moved |= normal_racket(P, R.rk, rk, b);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (R.on[i]) moved |= solve_normal(P, R.r[i], rk, b);
+    for (int i = 0; i < 3; ++i)
+      if (R.on[i + 1]) moved |= normal_static(P, R.st[i], b);
+    if (R.on[0]) moved |= friction_racket(P, R.rk, rk, b);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (R.on[i]) moved |= solve_friction(P, R.r[i], rk, b);
+    for (int i = 0; i < 3; ++i)
+      if (R.on[i + 1]) moved |= friction_static(P, R.st[i], b);
     if (!moved) break;
   }
 }
@@ -426,8 +508,9 @@ TB_DEV void integrate_pose(const KParams& P, Racket& rk, Ball& b) {
 // sweep / the static tests / the impulse solver only if __any lane needs them, and those
 // branches are wave-uniform (s_cbranch on the ballot), never if-converted into the hot path.
 template <int KIND>
-TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, vec3 Fr, vec3 Tr, vec3 Fb, float goal_x, float goal_y) {
+TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, vec3 Fr, vec3 Tr, vec3 Fb, float goal_x, float goal_y TB_STAMP_ARG) {
   int bits = 0;
+  TB_STAMP(st, 0);  // everything between two substeps (loop control, env logic)
   Hit hr, hg, hn, hc;
   hr.hit = false; hg.hit = false; hn.hit = false; hc.hit = false;
 
@@ -437,8 +520,15 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, ve
   near_racket = false;
 #endif
   if (__any(near_racket)) {
+#ifdef TB_DIAG_STAMPS
+    if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)__ballot(1)) - 1u) atomicAdd(&g_diag_cycles[12], 1ull);  // wave-substeps with a lane in reach
+#endif
     if (near_racket) hr = sphere_vs_racket_sweep(P, hull, rk, d);
   }
+#ifdef TB_DIAG_STAMPS
+  if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)__ballot(1)) - 1u) atomicAdd(&g_diag_cycles[13], 1ull);  // wave-substeps
+#endif
+  TB_STAMP(st, 1);  // racket narrowphase
   // every static shape lies below static_top: a ball whose lowest point clears it by the
   // manifold threshold (+1 mm of slack against rounding) is culled by each exact test as well
   bool near_static = !(((b.p.z - P.ball_radius) - P.contact_threshold) >= P.static_top + 1.0e-3f);
@@ -452,25 +542,29 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, ve
       if (KIND == TB_ENV_SWING) hc = sphere_vs_goal(P, goal_x, goal_y, b.p);
     }
   }
+  TB_STAMP(st, 2);  // static narrowphase
   if (hr.hit) bits |= CT_RACKET;
   if (hg.hit) bits |= CT_GROUND;
   if (hn.hit) bits |= CT_NET;
   if (hc.hit) bits |= CT_GOAL;
 
   integrate_velocities(P, rk, b, Fr, Tr, Fb);
+  TB_STAMP(st, 3);  // velocity update
 
   if (__any(bits != 0)) {
     if (bits) {  // only lanes whose ball touches something enter the solver
       Rows R;
       R.on[0] = bits & CT_RACKET; R.on[1] = bits & CT_GROUND; R.on[2] = bits & CT_NET; R.on[3] = bits & CT_GOAL;
-      if (R.on[0]) setup_row(P, R.r[0], hr, true, P.rest_racket, P.fric_racket, rk, b);
-      if (R.on[1]) setup_row(P, R.r[1], hg, false, P.rest_court, P.fric_court, rk, b);
-      if (R.on[2]) setup_row(P, R.r[2], hn, false, P.rest_court, P.fric_court, rk, b);
-      if (R.on[3]) setup_row(P, R.r[3], hc, false, P.rest_goal, P.fric_goal, rk, b);
+      if (R.on[0]) setup_racket(P, R.rk, hr, rk, b);
+      if (R.on[1]) setup_static(P, R.st[0], hg, P.rest_court, P.fric_court, b);
+      if (R.on[2]) setup_static(P, R.st[1], hn, P.rest_court, P.fric_court, b);
+      if (R.on[3]) setup_static(P, R.st[2], hc, P.rest_goal, P.fric_goal, b);
       solve_contacts(P, R, rk, b);
     }
   }
+  TB_STAMP(st, 4);  // contact solve
   integrate_pose(P, rk, b);
+  TB_STAMP(st, 5);  // pose update
   return bits;
 }
 

@@ -13,6 +13,7 @@
 // reductions; no inter-workgroup communication at all, so blockIdx -> XCD placement does
 // not matter for correctness or reuse (there is no shared tile to keep in one L2).
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -178,7 +179,7 @@ TB_DEV vec3 restoring_force(const EnvRegs& e) {  // swingracket_env.py:135-141
 }
 
 // swingracket_env.py:75-145
-TB_DEV float swing_step(const KParams& P, const float4* hull, EnvRegs& e, const float* a, int& ns, uint32_t* cnt) {
+TB_DEV float swing_step(const KParams& P, const float4* hull, EnvRegs& e, const float* a, int& ns, uint32_t* cnt TB_STAMP_ARG) {
   vec3 F = mk(a[0] * 400.0f, a[1] * 400.0f, FMA(a[2], 400.0f, 4.0f * 9.81f));  // :76-77
   vec3 T = mk(a[3] * 5.0f, a[4] * 5.0f, a[5] * 5.0f);                          // :78
   const vec3 zero = mk(0.0f, 0.0f, 0.0f);
@@ -186,7 +187,7 @@ TB_DEV float swing_step(const KParams& P, const float4* hull, EnvRegs& e, const 
     F = F + restoring_force(e);
     e.done = TB_DONE_YES;
   }
-  int bits = substep<TB_ENV_SWING>(P, hull, e.r, e.b, F, T, zero, e.aux[0], e.aux[1]);  // :82
+  int bits = substep<TB_ENV_SWING>(P, hull, e.r, e.b, F, T, zero, e.aux[0], e.aux[1] TB_STAMP_PASS);  // :82
   e.step_count += 1;                                                                      // :83
   ns = 1;
   float reward = 0.0f;
@@ -195,7 +196,7 @@ TB_DEV float swing_step(const KParams& P, const float4* hull, EnvRegs& e, const 
   if (e.step_count > 25) {                                      // :105
     vec3 Fp = zero;  // the substep above cleared the accumulated forces
     while (!e.done) {  // :106 -- per-lane loop; the wave leaves when its last lane is done
-      bits = substep<TB_ENV_SWING>(P, hull, e.r, e.b, Fp, zero, zero, e.aux[0], e.aux[1]);  // :107
+      bits = substep<TB_ENV_SWING>(P, hull, e.r, e.b, Fp, zero, zero, e.aux[0], e.aux[1] TB_STAMP_PASS);  // :107
       e.step_count += 1; ns++;
       if (bits & CT_RACKET) cnt[0]++;
       if (bits & (CT_GROUND | CT_NET)) { e.done = TB_DONE_PENDING_FORCE; reward += moved_dist_to_goal(e); cnt[1]++; }  // :111-114
@@ -213,12 +214,12 @@ TB_DEV float dist_to_reward(float d) {
 }
 
 // tennisbot_env.py:104-207 (the DELAY_MODE sleep at :124-126 is dropped on purpose)
-TB_DEV float tennis_step(const KParams& P, const float4* hull, EnvRegs& e, const float* a, float* obs, bool& ret_done, uint32_t* cnt) {
+TB_DEV float tennis_step(const KParams& P, const float4* hull, EnvRegs& e, const float* a, float* obs, bool& ret_done, uint32_t* cnt TB_STAMP_ARG) {
   const vec3 zero = mk(0.0f, 0.0f, 0.0f);
   vec3 F = mk(a[0] * 10.0f, a[1] * 10.0f, 4.0f * 9.81f);  // :112-115
   vec3 Fb = zero;
   if (e.step_count < 5) Fb = mk(e.aux[0], e.aux[1], e.aux[2]);  // :118-119
-  int bits = substep<TB_ENV_TENNIS>(P, hull, e.r, e.b, F, zero, Fb, 0.0f, 0.0f);  // :121
+  int bits = substep<TB_ENV_TENNIS>(P, hull, e.r, e.b, F, zero, Fb, 0.0f, 0.0f TB_STAMP_PASS);  // :121
   e.step_count += 1;                                                                // :122
   if (bits & CT_RACKET) cnt[0]++;
   make_obs<TB_ENV_TENNIS>(e, obs);  // :134-136
@@ -274,6 +275,12 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
 #pragma unroll
   for (int k = 0; k < TB_N_COUNTERS; ++k) cnt[k] = 0u;
 
+#ifdef TB_DIAG_STAMPS
+  Stamps st;
+  for (int k = 0; k < 8; ++k) st.acc[k] = 0u;
+  st.t = stamp_now();
+  const unsigned long long t_kernel0 = st.t;
+#endif
   if (live) {
     bool any_reset = false;
     int ns_total = 0;
@@ -293,11 +300,11 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
       bool d;
       float rew;
       if (KIND == TB_ENV_SWING) {
-        rew = swing_step(A.P, s_hull, e, a, ns, cnt);
+        rew = swing_step(A.P, s_hull, e, a, ns, cnt TB_STAMP_PASS);
         make_obs<TB_ENV_SWING>(e, o);
         d = e.done != TB_DONE_NO;  // swingracket_env.py:145 returns self.done
       } else {
-        rew = tennis_step(A.P, s_hull, e, a, o, d, cnt);
+        rew = tennis_step(A.P, s_hull, e, a, o, d, cnt TB_STAMP_PASS);
       }
       cnt[6] += (uint32_t)ns;
       ns_total += ns;
@@ -320,6 +327,13 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
     store_env<KIND>(A, i, e, any_reset);
   }
   flush_counters(A.counters, cnt);
+#ifdef TB_DIAG_STAMPS
+  if ((threadIdx.x & 63) == 0) {  // per-wave sums (lane 0 carries the wave's scalar clock reads)
+    for (int k = 0; k < 6; ++k) atomicAdd(&g_diag_cycles[k], (unsigned long long)st.acc[k]);
+    atomicAdd(&g_diag_cycles[8], stamp_now() - t_kernel0);
+    atomicAdd(&g_diag_cycles[9], 1ull);
+  }
+#endif
 }
 
 // reset kernel (masked)
@@ -415,12 +429,30 @@ void to_kparams(const TbParams* p, KParams* k) {
   float top = p->ground_half[2] > p->goal_half_len ? p->ground_half[2] : p->goal_half_len;
   if ((p->flags & TB_F_NET) && p->net_half[2] > top) top = p->net_half[2];
   k->static_top = top;
-  float ymin = p->hull_edges[0][0], ymax = ymin, zmin = p->hull_edges[0][1], zmax = zmin;
-  for (int i = 1; i < p->n_hull; ++i) {
-    float y = p->hull_edges[i][0], z = p->hull_edges[i][1];
-    ymin = y < ymin ? y : ymin; ymax = y > ymax ? y : ymax; zmin = z < zmin ? z : zmin; zmax = z > zmax ? z : zmax;
+  {  // cull planes: 8 fixed directions + the 4 longest edges, each pushed out by its own rounding
+    int np = 0;
+    for (int d = 0; d < 8; ++d) {
+      double ang = d * 0.78539816339744830962, ny = cos(ang), nz = sin(ang), hmax = -1e30;
+      for (int i = 0; i < p->n_hull; ++i) { double v = ny * p->hull_edges[i][0] + nz * p->hull_edges[i][1]; hmax = v > hmax ? v : hmax; }
+      k->cull_planes[np][0] = (float)ny; k->cull_planes[np][1] = (float)nz; k->cull_planes[np][2] = (float)(hmax + 1e-6); ++np;
+    }
+    bool used[TB_MAX_HULL] = {false};
+    for (int pick = 0; pick < TB_N_CULL - 8; ++pick) {
+      int best = -1; double bl = -1.0;
+      for (int i = 0; i < p->n_hull; ++i) {
+        double l2 = (double)p->hull_edges[i][2] * p->hull_edges[i][2] + (double)p->hull_edges[i][3] * p->hull_edges[i][3];
+        if (!used[i] && l2 > bl) { bl = l2; best = i; }
+      }
+      used[best] = true;
+      double il = 1.0 / sqrt(bl), ny = p->hull_edges[best][3] * il, nz = -p->hull_edges[best][2] * il;  // outward normal of a CCW edge
+      double hmax = -1e30;
+      for (int i = 0; i < p->n_hull; ++i) { double v = ny * p->hull_edges[i][0] + nz * p->hull_edges[i][1]; hmax = v > hmax ? v : hmax; }
+      k->cull_planes[np][0] = (float)ny; k->cull_planes[np][1] = (float)nz; k->cull_planes[np][2] = (float)(hmax + 1e-6); ++np;
+    }
   }
-  k->hull_box[0] = ymin; k->hull_box[1] = ymax; k->hull_box[2] = zmin; k->hull_box[3] = zmax;
+  // same float operations as the rows would do per contact (oracle setup_row): bit-identical
+  k->ball_kn = 1.0f / p->ball_inv_mass;
+  k->ball_kt = 1.0f / fmaf(p->ball_inv_inertia, p->ball_radius * p->ball_radius, p->ball_inv_mass);
 }
 
 }  // namespace
@@ -614,6 +646,15 @@ int tb_diag_stream_copy(const uint32_t* src_dev, uint32_t* dst_dev, int n, int r
   HIP_TRY(hipGetLastError());
   return TB_OK;
 }
+
+#ifdef TB_DIAG_STAMPS
+int tb_diag_read_stamps(unsigned long long* out16, int reset) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_diag_cycles), sizeof(unsigned long long) * 16));
+  if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_diag_cycles), z, sizeof z)); }
+  return TB_OK;
+}
+#endif
 
 int tb_counters_reset(TbHandle* h, void* stream) {
   if (!h) return fail(TB_E_INVAL, "tb_counters_reset: null handle");

@@ -13,9 +13,15 @@ from tennisbot_rl_amd.params import ENV_SWING  # noqa: E402
 from tennisbot_rl_amd.stepper import BatchedEnv  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+mode = sys.argv[2] if len(sys.argv) > 2 else "full"
+from tennisbot_rl_amd.params import F_DEFAULT, F_NET, default_params  # noqa: E402
+from tennisbot_rl_amd import stepper  # noqa: E402
+if mode.startswith("lib="):
+    stepper._LIB_PATH = mode[4:]
+params = default_params(flags=F_NET if mode == "contact_off" else F_DEFAULT)
 rng = np.random.Generator(np.random.PCG64(0))
 acts = torch.from_numpy(rng.uniform(-1, 1, (104, n, 6)).astype(np.float32)).cuda()
-env = BatchedEnv(ENV_SWING, n, seed=0, reuse_buffers=True)
+env = BatchedEnv(ENV_SWING, n, seed=0, reuse_buffers=True, params=params)
 env.reset()
 for ep in range(4):
     short = []
