@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound for each CPU baseline leg")
     ap.add_argument("--sweep", action="store_true", help="also time N = 4096 .. 4M envs on one GPU (extra JSON key)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-pipeline", action="store_true", help="run the SwingRacket fast-forward inside the step kernel instead of a side stream")
     return ap.parse_args()
 
 
@@ -96,6 +97,7 @@ def time_steps(env, buf, steps, warmup, torch, dist_on, tail_gather=True):
     ev0.record(torch.cuda.current_stream(dev))  # the stream the step kernel is launched on
     for t in range(steps):
         buf.step_into(env, t % T)
+    env.flush()  # pipelined fast-forwards: every step's outputs are complete from here on
     ev1.record(torch.cuda.current_stream(dev))
     if tail_gather:
         buf.all_gather()  # collect boundary: one collective (no-op for a single rank)
@@ -163,11 +165,13 @@ def main():
     kind = ENV_SWING if args.env == "swing" else ENV_TENNIS
     flags = F_NET if args.contact_off else F_DEFAULT
     N = args.envs_per_gpu
+    pipeline = kind == ENV_SWING and not args.no_pipeline
     env = BatchedEnv(kind, N, device=dev, seed=args.seed, env_id_base=rank * N, params=default_params(flags=flags),
-                     track_terminal_obs=False)
+                     track_terminal_obs=False, pipeline=pipeline)
     T_buf = min(args.steps, 1100)  # rollout length of the reference: n_steps = 1100 (train_swing.py:49-50)
     buf = RolloutBuffer(kind, T_buf, N, dev)
     fill_actions(buf.actions, args.seed + rank, torch)
+    buf.bind(env)
     env.reset()
     env.counters_reset()
     wall, ev_s = time_steps(env, buf, args.steps, args.warmup, torch, dist_on)
@@ -217,9 +221,10 @@ def main():
     if args.sweep and not dist_on:
         sweep = []
         for n in (4096, 32768, 262144, 1048576, 4194304):
-            e2 = BatchedEnv(kind, n, device=dev, seed=args.seed, params=default_params(flags=flags), track_terminal_obs=False)
+            e2 = BatchedEnv(kind, n, device=dev, seed=args.seed, params=default_params(flags=flags), track_terminal_obs=False, pipeline=pipeline)
             b2 = RolloutBuffer(kind, 26, n, dev)
             fill_actions(b2.actions, args.seed, torch)
+            b2.bind(e2)
             e2.reset()
             k = 52 if n >= 1048576 else 104
             w, evs = time_steps(e2, b2, k, 26, torch, False, tail_gather=False)

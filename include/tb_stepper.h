@@ -192,6 +192,22 @@ int tb_step(TbHandle *h, const float *actions_dev, float *obs_dev, float *reward
 int tb_rollout(TbHandle *h, int n_steps, const float *actions_dev, float *obs_dev,
                float *reward_dev, uint8_t *done_dev, int32_t *substeps_total_dev, void *stream);
 
+/*
+ * Pipelined fast-forward (SwingRacket-v0 with TB_F_AUTO_RESET; HIP streams, no reference
+ * counterpart). The <= 775-substep fast-forward of swingracket_env.py:105-141 takes no
+ * agent input, and the next episode does not depend on its outcome. With the pipeline
+ * enabled, the 26th tb_step after a full tb_reset parks each env's pre-loop state, resets
+ * the env and returns at once with obs (first observation of the new episode) and done = 1;
+ * the loop itself runs on a stream owned by the handle, overlapping the following steps, and
+ * then writes THAT step's reward, terminal observation and substep count into the buffers
+ * that were passed to that tb_step call. Those buffers must therefore stay valid and must not
+ * be reused until tb_flush; results are bit-identical to the unpipelined path.
+ * tb_flush makes `stream` wait for all outstanding fast-forwards (tb_get_state, tb_set_state,
+ * tb_counters, tb_reset, tb_set_params and tb_destroy do so themselves).
+ */
+int tb_set_pipeline(TbHandle *h, int enable);
+int tb_flush(TbHandle *h, void *stream);
+
 /* Snapshot / restore the persistent state (the reference never checkpoints env state;
  * SURVEY.md section 5). words: [tb_state_words][N] uint32 bit patterns, done: [N] bytes.
  * `on_device` != 0: the buffers are device memory (async on stream); 0: host memory

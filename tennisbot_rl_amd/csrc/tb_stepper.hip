@@ -42,6 +42,11 @@ struct KArgs {
   unsigned long long* counters;  // [TB_N_COUNTERS]
   unsigned long long seed, env_id_base;
   int n, T;
+  // pipelined fast-forward (tb_set_pipeline): a step that starts a SwingRacket fast-forward parks
+  // the env's pre-loop state in a slot and resets the env; tb_ff_kernel finishes it on a side stream
+  uint32_t* ff_words;     // [W][n] slot
+  uint8_t* ff_flag;       // [n]: 1 = parked, waiting for tb_ff_kernel
+  int defer;
 };
 
 struct EnvRegs {
@@ -61,9 +66,7 @@ TB_DEV float ld(const uint32_t* w, int row, int n, int i) { return __uint_as_flo
 TB_DEV void st(uint32_t* w, int row, int n, int i, float v) { w[(size_t)row * n + i] = __float_as_uint(v); }
 
 template <int KIND>
-TB_DEV void load_env(const KArgs& A, int i, EnvRegs& e) {
-  const uint32_t* w = A.words;
-  const int n = A.n;
+TB_DEV void load_env(const uint32_t* w, const uint8_t* done_state, int n, int i, EnvRegs& e) {
   e.r.p = mk(ld(w, TB_W_RP, n, i), ld(w, TB_W_RP + 1, n, i), ld(w, TB_W_RP + 2, n, i));
   e.r.q.x = ld(w, TB_W_RQ, n, i); e.r.q.y = ld(w, TB_W_RQ + 1, n, i); e.r.q.z = ld(w, TB_W_RQ + 2, n, i); e.r.q.w = ld(w, TB_W_RQ + 3, n, i);
   e.r.v = mk(ld(w, TB_W_RV, n, i), ld(w, TB_W_RV + 1, n, i), ld(w, TB_W_RV + 2, n, i));
@@ -75,14 +78,12 @@ TB_DEV void load_env(const KArgs& A, int i, EnvRegs& e) {
   for (int k = 0; k < 6; ++k) e.aux[k] = k < Dims<KIND>::NAUX ? ld(w, 22 + k, n, i) : 0.0f;
   e.step_count = (int)w[(size_t)(Dims<KIND>::W - 2) * n + i];
   e.episode = w[(size_t)(Dims<KIND>::W - 1) * n + i];
-  e.done = A.done_state[i];
+  e.done = done_state[i];
 }
 
 // `all`: also the rows that only change on reset (goal / spawn / d0 / shoot force / episode)
 template <int KIND>
-TB_DEV void store_env(const KArgs& A, int i, const EnvRegs& e, bool all) {
-  uint32_t* w = A.words;
-  const int n = A.n;
+TB_DEV void store_env(uint32_t* w, uint8_t* done_state, int n, int i, const EnvRegs& e, bool all) {
   st(w, TB_W_RP, n, i, e.r.p.x); st(w, TB_W_RP + 1, n, i, e.r.p.y); st(w, TB_W_RP + 2, n, i, e.r.p.z);
   st(w, TB_W_RQ, n, i, e.r.q.x); st(w, TB_W_RQ + 1, n, i, e.r.q.y); st(w, TB_W_RQ + 2, n, i, e.r.q.z); st(w, TB_W_RQ + 3, n, i, e.r.q.w);
   st(w, TB_W_RV, n, i, e.r.v.x); st(w, TB_W_RV + 1, n, i, e.r.v.y); st(w, TB_W_RV + 2, n, i, e.r.v.z);
@@ -96,7 +97,7 @@ TB_DEV void store_env(const KArgs& A, int i, const EnvRegs& e, bool all) {
     w[(size_t)(Dims<KIND>::W - 1) * n + i] = e.episode;
   }
   w[(size_t)(Dims<KIND>::W - 2) * n + i] = (uint32_t)e.step_count;
-  A.done_state[i] = (uint8_t)e.done;
+  done_state[i] = (uint8_t)e.done;
 }
 
 template <int KIND>
@@ -178,8 +179,26 @@ TB_DEV vec3 restoring_force(const EnvRegs& e) {  // swingracket_env.py:135-141
   return mk(-50.0f * (e.r.p.x - e.aux[2]), -2.0f * (e.r.p.y - e.aux[3]), -2.0f * ((e.r.p.z - e.aux[4]) - 4.0f));
 }
 
-// swingracket_env.py:75-145
-TB_DEV float swing_step(const KParams& P, const float4* hull, EnvRegs& e, const float* a, int& ns, uint32_t* cnt TB_STAMP_ARG) {
+// the fast-forward of swingracket_env.py:105-141: substeps until the ball touches the court or
+// the goal, or step_count > 800. No agent input enters it.
+TB_DEV float swing_fast_forward(const KParams& P, const float4* hull, EnvRegs& e, int& ns, uint32_t* cnt TB_STAMP_ARG) {
+  const vec3 zero = mk(0.0f, 0.0f, 0.0f);
+  float reward = 0.0f;
+  vec3 Fp = zero;  // the substep before the loop cleared the accumulated forces
+  while (!e.done) {  // :106 -- per-lane loop; the wave leaves when its last lane is done
+    int bits = substep<TB_ENV_SWING>(P, hull, e.r, e.b, Fp, zero, zero, e.aux[0], e.aux[1] TB_STAMP_PASS);  // :107
+    e.step_count += 1; ns++;
+    if (bits & CT_RACKET) cnt[0]++;
+    if (bits & (CT_GROUND | CT_NET)) { e.done = TB_DONE_PENDING_FORCE; reward += moved_dist_to_goal(e); cnt[1]++; }  // :111-114
+    if (bits & CT_GOAL) { reward += moved_dist_to_goal(e); reward += 50.0f; e.done = TB_DONE_PENDING_FORCE; cnt[2]++; }  // :119-123
+    if (e.step_count > 800) { if (!e.done) cnt[3]++; e.done = TB_DONE_PENDING_FORCE; }  // :127-128
+    Fp = restoring_force(e);  // :135-141
+  }
+  return reward;
+}
+
+// swingracket_env.py:75-145. `defer`: leave the fast-forward to tb_ff_kernel (sets `parked`).
+TB_DEV float swing_step(const KParams& P, const float4* hull, EnvRegs& e, const float* a, int& ns, uint32_t* cnt, bool defer, bool& parked TB_STAMP_ARG) {
   vec3 F = mk(a[0] * 400.0f, a[1] * 400.0f, FMA(a[2], 400.0f, 4.0f * 9.81f));  // :76-77
   vec3 T = mk(a[3] * 5.0f, a[4] * 5.0f, a[5] * 5.0f);                          // :78
   const vec3 zero = mk(0.0f, 0.0f, 0.0f);
@@ -194,16 +213,8 @@ TB_DEV float swing_step(const KParams& P, const float4* hull, EnvRegs& e, const 
   if (bits & CT_RACKET) cnt[0]++;
   if (e.step_count < 25 && (bits & CT_RACKET)) reward += 2.0f;  // :98-101
   if (e.step_count > 25) {                                      // :105
-    vec3 Fp = zero;  // the substep above cleared the accumulated forces
-    while (!e.done) {  // :106 -- per-lane loop; the wave leaves when its last lane is done
-      bits = substep<TB_ENV_SWING>(P, hull, e.r, e.b, Fp, zero, zero, e.aux[0], e.aux[1] TB_STAMP_PASS);  // :107
-      e.step_count += 1; ns++;
-      if (bits & CT_RACKET) cnt[0]++;
-      if (bits & (CT_GROUND | CT_NET)) { e.done = TB_DONE_PENDING_FORCE; reward += moved_dist_to_goal(e); cnt[1]++; }  // :111-114
-      if (bits & CT_GOAL) { reward += moved_dist_to_goal(e); reward += 50.0f; e.done = TB_DONE_PENDING_FORCE; cnt[2]++; }  // :119-123
-      if (e.step_count > 800) { if (!e.done) cnt[3]++; e.done = TB_DONE_PENDING_FORCE; }  // :127-128
-      Fp = restoring_force(e);  // :135-141
-    }
+    if (defer && !e.done) parked = true;  // reward so far is 0: the bonus window closed at step 25
+    else reward += swing_fast_forward(P, hull, e, ns, cnt TB_STAMP_PASS);
   }
   return reward;
 }
@@ -268,7 +279,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < A.n;
   EnvRegs e;
-  if (live) load_env<KIND>(A, i, e);  // issue the state loads first; the outline staging overlaps them
+  if (live) load_env<KIND>(A.words, A.done_state, A.n, i, e);  // issue the state loads first; the outline staging overlaps them
   stage_hull(s_hull, A);
 
   uint32_t cnt[TB_N_COUNTERS];
@@ -297,12 +308,20 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
       }
       float o[NO];
       int ns = 1;
-      bool d;
+      bool d, parked = false;
       float rew;
       if (KIND == TB_ENV_SWING) {
-        rew = swing_step(A.P, s_hull, e, a, ns, cnt TB_STAMP_PASS);
+        rew = swing_step(A.P, s_hull, e, a, ns, cnt, A.defer != 0, parked TB_STAMP_PASS);
         make_obs<TB_ENV_SWING>(e, o);
         d = e.done != TB_DONE_NO;  // swingracket_env.py:145 returns self.done
+        if (parked) {
+          // Every SwingRacket episode ends inside this step (the loop only exits through done), so
+          // done = 1 is known now; reward, terminal obs and substep count of this step are written
+          // later by tb_ff_kernel from the parked state. The env itself restarts immediately.
+          store_env<TB_ENV_SWING>(A.ff_words, A.ff_flag, A.n, i, e, true);
+          A.ff_flag[i] = 1;
+          d = true;
+        }
       } else {
         rew = tennis_step(A.P, s_hull, e, a, o, d, cnt TB_STAMP_PASS);
       }
@@ -313,7 +332,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
         cnt[7]++;
       if (d && (A.P.flags & TB_F_AUTO_RESET)) {
         cnt[5]++;
-        if (A.term_obs) write_obs<KIND>(A.term_obs, (size_t)i, o);
+        if (A.term_obs && !parked) write_obs<KIND>(A.term_obs, (size_t)i, o);
         e.episode += 1u;
         reset_env<KIND>(A, i, e);
         make_obs<KIND>(e, o);
@@ -324,7 +343,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
       A.done_out[row] = d ? 1 : 0;
     }
     if (A.substeps) A.substeps[i] = ns_total;
-    store_env<KIND>(A, i, e, any_reset);
+    store_env<KIND>(A.words, A.done_state, A.n, i, e, any_reset);
   }
   flush_counters(A.counters, cnt);
 #ifdef TB_DIAG_STAMPS
@@ -336,6 +355,40 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
 #endif
 }
 
+// finishes parked SwingRacket fast-forwards (side stream): same device code as the in-step loop
+__global__ void __launch_bounds__(256) tb_ff_kernel(KArgs A) {
+  __shared__ float4 s_hull[TB_MAX_HULL * 2];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < A.n && A.ff_flag[i] == 1;
+  EnvRegs e;
+  if (live) load_env<TB_ENV_SWING>(A.ff_words, A.ff_flag, A.n, i, e);
+  stage_hull(s_hull, A);
+  uint32_t cnt[TB_N_COUNTERS];
+#pragma unroll
+  for (int k = 0; k < TB_N_COUNTERS; ++k) cnt[k] = 0u;
+#ifdef TB_DIAG_STAMPS
+  Stamps st;
+  for (int k = 0; k < 8; ++k) st.acc[k] = 0u;
+  st.t = stamp_now();
+#endif
+  if (live) {
+    e.done = TB_DONE_NO;  // the slot's byte is the parking flag, the parked env was not done
+    int ns = 1;           // the step kernel ran the first substep of this agent step
+    float rew = swing_fast_forward(A.P, s_hull, e, ns, cnt TB_STAMP_PASS);
+    cnt[6] += (uint32_t)(ns - 1);
+    if (!(finite3(e.r.p) && finite3(e.r.v) && finite3(e.r.w) && finite3(e.b.p) && finite3(e.b.v) && finite3(e.b.w) &&
+          isfinite(e.r.q.x) && isfinite(e.r.q.y) && isfinite(e.r.q.z) && isfinite(e.r.q.w)))
+      cnt[7]++;
+    float o[TB_SWING_OBS_DIM];
+    make_obs<TB_ENV_SWING>(e, o);
+    if (A.term_obs) write_obs<TB_ENV_SWING>(A.term_obs, (size_t)i, o);
+    A.reward[i] = rew;
+    if (A.substeps) A.substeps[i] = ns;
+    A.ff_flag[i] = 0;
+  }
+  flush_counters(A.counters, cnt);
+}
+
 // reset kernel (masked)
 template <int KIND>
 __global__ void __launch_bounds__(256) tb_reset_kernel(KArgs A) {
@@ -345,7 +398,7 @@ __global__ void __launch_bounds__(256) tb_reset_kernel(KArgs A) {
   EnvRegs e;
   e.episode = A.words[(size_t)(Dims<KIND>::W - 1) * A.n + i] + 1u;
   reset_env<KIND>(A, i, e);
-  store_env<KIND>(A, i, e, true);
+  store_env<KIND>(A.words, A.done_state, A.n, i, e, true);
   if (A.obs) {
     float o[Dims<KIND>::O];
     make_obs<KIND>(e, o);
@@ -457,6 +510,8 @@ void to_kparams(const TbParams* p, KParams* k) {
 
 }  // namespace
 
+#define TB_FF_SLOTS 4
+
 struct TbHandle {
   int device, kind, n, block;
   uint64_t seed, env_id_base;
@@ -467,6 +522,16 @@ struct TbHandle {
   float4* d_hull;
   float4* h_hull;  // pinned staging copy of the outline table
   unsigned long long* d_counters;
+  // pipelined fast-forward
+  int pipeline;            // enabled by tb_set_pipeline
+  int phase, phase_valid;  // agent steps since the last full reset (SwingRacket episodes are exactly 26 steps)
+  hipStream_t side[TB_FF_SLOTS];  // one stream per slot: consecutive fast-forwards overlap each other too
+  const void *last_term, *last_sub;  // shared late-written buffers force ordering between fast-forwards
+  int last_slot;
+  uint32_t* d_ff_words[TB_FF_SLOTS];
+  uint8_t* d_ff_flag[TB_FF_SLOTS];
+  hipEvent_t ev_step[TB_FF_SLOTS], ev_ff[TB_FF_SLOTS];
+  int ff_busy[TB_FF_SLOTS], next_slot;
 };
 
 namespace {
@@ -495,13 +560,43 @@ int upload_hull(TbHandle* h, hipStream_t s) {
   return TB_OK;
 }
 
+// make `s` wait for every fast-forward still running on the side stream
+int wait_side(TbHandle* h, hipStream_t s) {
+  for (int k = 0; k < TB_FF_SLOTS; ++k)
+    if (h->ff_busy[k]) HIP_TRY(hipStreamWaitEvent(s, h->ev_ff[k], 0));
+  return TB_OK;
+}
+
 int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* reward, uint8_t* done, float* term, int32_t* substeps, hipStream_t s) {
   KArgs a = base_args(h);
   a.actions = actions; a.obs = obs; a.reward = reward; a.done_out = done; a.term_obs = term; a.substeps = substeps; a.T = T;
   dim3 grid((unsigned)((h->n + h->block - 1) / h->block)), block((unsigned)h->block);
+  // Park the fast-forward when this call is the 26th agent step since a full reset: all envs then
+  // enter it together. The phase is only a launch hint -- a lane that is not where the host thinks
+  // simply runs its loop inside whichever step kernel it is in.
+  const bool defer = T == 1 && h->pipeline && h->kind == TB_ENV_SWING && (h->kp.flags & TB_F_AUTO_RESET) && h->phase_valid && h->phase == 25;
+  int slot = -1;
+  if (defer) {
+    slot = h->next_slot;
+    h->next_slot = (slot + 1) % TB_FF_SLOTS;
+    if (h->ff_busy[slot]) HIP_TRY(hipStreamWaitEvent(s, h->ev_ff[slot], 0));  // slot still in use by an older fast-forward
+    a.defer = 1; a.ff_words = h->d_ff_words[slot]; a.ff_flag = h->d_ff_flag[slot];
+  }
   if (h->kind == TB_ENV_SWING) hipLaunchKernelGGL(tb_step_kernel<TB_ENV_SWING>, grid, block, 0, s, a);
   else hipLaunchKernelGGL(tb_step_kernel<TB_ENV_TENNIS>, grid, block, 0, s, a);
   HIP_TRY(hipGetLastError());
+  if (defer) {
+    HIP_TRY(hipEventRecord(h->ev_step[slot], s));
+    HIP_TRY(hipStreamWaitEvent(h->side[slot], h->ev_step[slot], 0));
+    // two fast-forwards that write the same terminal-obs / substeps buffer must finish in order
+    if (h->last_slot >= 0 && h->last_slot != slot && ((term && term == h->last_term) || (substeps && substeps == h->last_sub)))
+      HIP_TRY(hipStreamWaitEvent(h->side[slot], h->ev_ff[h->last_slot], 0));
+    hipLaunchKernelGGL(tb_ff_kernel, grid, block, 0, h->side[slot], a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev_ff[slot], h->side[slot]));
+    h->ff_busy[slot] = 1; h->last_slot = slot; h->last_term = term; h->last_sub = substeps;
+  }
+  if (h->phase_valid) h->phase = (h->phase + T) % 26;
   return TB_OK;
 }
 
@@ -559,8 +654,43 @@ int tb_destroy(TbHandle* h) {
   if (h->d_hull) (void)hipFree(h->d_hull);
   if (h->h_hull) (void)hipHostFree(h->h_hull);
   if (h->d_counters) (void)hipFree(h->d_counters);
+  for (int k = 0; k < TB_FF_SLOTS; ++k) {
+    if (h->d_ff_words[k]) (void)hipFree(h->d_ff_words[k]);
+    if (h->d_ff_flag[k]) (void)hipFree(h->d_ff_flag[k]);
+    if (h->ev_step[k]) (void)hipEventDestroy(h->ev_step[k]);
+    if (h->ev_ff[k]) (void)hipEventDestroy(h->ev_ff[k]);
+  }
+  for (int k = 0; k < TB_FF_SLOTS; ++k)
+    if (h->side[k]) (void)hipStreamDestroy(h->side[k]);
   free(h);
   return TB_OK;
+}
+
+int tb_set_pipeline(TbHandle* h, int enable) {
+  if (!h) return fail(TB_E_INVAL, "tb_set_pipeline: null handle");
+  DeviceGuard g(h->device);
+  if (enable && !h->side[0]) {
+    if (h->kind != TB_ENV_SWING) return fail(TB_E_UNSUPPORTED, "tb_set_pipeline: only SwingRacket-v0 has a fast-forward to overlap");
+    const size_t wb = sizeof(uint32_t) * (size_t)TB_SWING_WORDS * h->n;
+    h->last_slot = -1;
+    for (int k = 0; k < TB_FF_SLOTS; ++k) {
+      HIP_TRY(hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
+      HIP_TRY(hipMalloc((void**)&h->d_ff_words[k], wb));
+      HIP_TRY(hipMalloc((void**)&h->d_ff_flag[k], (size_t)h->n));
+      HIP_TRY(hipMemset(h->d_ff_flag[k], 0, (size_t)h->n));
+      HIP_TRY(hipEventCreateWithFlags(&h->ev_step[k], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&h->ev_ff[k], hipEventDisableTiming));
+    }
+    HIP_TRY(hipDeviceSynchronize());
+  }
+  h->pipeline = enable ? 1 : 0;
+  return TB_OK;
+}
+
+int tb_flush(TbHandle* h, void* stream) {
+  if (!h) return fail(TB_E_INVAL, "tb_flush: null handle");
+  DeviceGuard g(h->device);
+  return wait_side(h, (hipStream_t)stream);
 }
 
 int tb_set_params(TbHandle* h, const TbParams* params, void* stream) {
@@ -569,6 +699,7 @@ int tb_set_params(TbHandle* h, const TbParams* params, void* stream) {
   DeviceGuard g(h->device);
   hipStream_t s = (hipStream_t)stream;
   // the staging buffer may still feed an earlier async copy on another stream: settle it first
+  if (int rc = wait_side(h, s)) return rc;
   HIP_TRY(hipStreamSynchronize(s));
   h->params = *params;
   to_kparams(params, &h->kp);
@@ -580,6 +711,9 @@ int tb_set_params(TbHandle* h, const TbParams* params, void* stream) {
 int tb_reset(TbHandle* h, const uint8_t* mask_dev, float* obs_dev, void* stream) {
   if (!h) return fail(TB_E_INVAL, "tb_reset: null handle");
   DeviceGuard g(h->device);
+  if (int rc = wait_side(h, (hipStream_t)stream)) return rc;
+  if (mask_dev) h->phase_valid = 0;  // episodes are no longer in lockstep
+  else { h->phase_valid = 1; h->phase = 0; }
   KArgs a = base_args(h);
   a.mask = mask_dev; a.obs = obs_dev;
   dim3 grid((unsigned)((h->n + 255) / 256)), block(256);
@@ -609,6 +743,7 @@ int tb_get_state(TbHandle* h, uint32_t* words, uint8_t* done, int on_device, voi
   if (!h || !words) return fail(TB_E_INVAL, "tb_get_state: null argument");
   DeviceGuard g(h->device);
   hipStream_t s = (hipStream_t)stream;
+  if (int rc = wait_side(h, s)) return rc;
   const size_t wb = sizeof(uint32_t) * (size_t)words_of(h->kind) * h->n;
   hipMemcpyKind k = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
   HIP_TRY(hipMemcpyAsync(words, h->d_words, wb, k, s));
@@ -621,6 +756,8 @@ int tb_set_state(TbHandle* h, const uint32_t* words, const uint8_t* done, int on
   if (!h || !words) return fail(TB_E_INVAL, "tb_set_state: null argument");
   DeviceGuard g(h->device);
   hipStream_t s = (hipStream_t)stream;
+  if (int rc = wait_side(h, s)) return rc;
+  h->phase_valid = 0;  // injected states need not be in lockstep
   const size_t wb = sizeof(uint32_t) * (size_t)words_of(h->kind) * h->n;
   hipMemcpyKind k = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   HIP_TRY(hipMemcpyAsync(h->d_words, words, wb, k, s));
@@ -633,6 +770,7 @@ int tb_set_state(TbHandle* h, const uint32_t* words, const uint8_t* done, int on
 int tb_counters(TbHandle* h, uint64_t* out, void* stream) {
   if (!h || !out) return fail(TB_E_INVAL, "tb_counters: null argument");
   DeviceGuard g(h->device);
+  if (int rc = wait_side(h, (hipStream_t)stream)) return rc;
   HIP_TRY(hipMemcpyAsync(out, h->d_counters, sizeof(uint64_t) * TB_N_COUNTERS, hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   return TB_OK;

@@ -42,8 +42,27 @@ class RolloutBuffer:
         done = raw[off[3]: off[3] + T * N].view(T, N)
         return obs, act, rew, done
 
+    def bind(self, env):
+        """validate this buffer against `env` once and cache the per-step device addresses, so the
+        collect loop is one C call per step (no tensor slicing, no per-step checks)"""
+        t = self.torch
+        env._check_tensor(self.actions[0], (self.N, self.A), t.float32, "rollout actions[t]")
+        env._check_tensor(self.obs[0], (self.N, self.O), t.float32, "rollout obs[t]")
+        env._check_tensor(self.rewards[0], (self.N,), t.float32, "rollout rewards[t]")
+        env._check_tensor(self.dones[0], (self.N,), t.uint8, "rollout dones[t]")
+        if self.N * self.O * 4 % env._row_align or self.N * self.A * 4 % env._row_align:
+            raise ValueError("rollout rows are not %d-byte aligned for this batch size" % env._row_align)
+        N, O, A = self.N, self.O, self.A
+        self._ptrs = [(self.actions.data_ptr() + k * N * A * 4, self.obs.data_ptr() + k * N * O * 4,
+                       self.rewards.data_ptr() + k * N * 4, self.dones.data_ptr() + k * N) for k in range(self.T)]
+        self._bound = env
+        return self
+
     def step_into(self, env, t):
         """run env.step on actions[t], with outputs written in place at slot t"""
+        if getattr(self, "_bound", None) is env:
+            env.step_ptrs(*self._ptrs[t])
+            return None
         return env.step(self.actions[t], out=(self.obs[t], self.rewards[t], self.dones[t]))
 
     def all_gather(self, group=None):

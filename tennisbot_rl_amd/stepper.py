@@ -57,6 +57,10 @@ def load_library():
     L.tb_set_state.argtypes = [vp, vp, vp, i32, vp]
     L.tb_counters.argtypes = [vp, vp, vp]
     L.tb_counters_reset.argtypes = [vp, vp]
+    L.tb_set_pipeline.argtypes = [vp, i32]
+    L.tb_set_pipeline.restype = i32
+    L.tb_flush.argtypes = [vp, vp]
+    L.tb_flush.restype = i32
     L.tb_diag_stream_copy.argtypes = [vp, vp, i32, i32, i32, vp]
     L.tb_diag_stream_copy.restype = i32
     for f in ("tb_create", "tb_destroy", "tb_set_params", "tb_reset", "tb_step", "tb_rollout", "tb_get_state",
@@ -87,7 +91,7 @@ class BatchedEnv:
     """
 
     def __init__(self, env_kind, num_envs, device=None, seed=0, env_id_base=0, params=None, auto_reset=True,
-                 reuse_buffers=False, track_terminal_obs=True):
+                 reuse_buffers=False, track_terminal_obs=True, pipeline=False):
         import torch
         self.torch = torch
         if isinstance(env_kind, str):
@@ -118,6 +122,16 @@ class BatchedEnv:
         self._term = torch.zeros((n, o), dtype=torch.float32, device=self.device) if (auto_reset and track_terminal_obs) else None
         self._substeps = torch.zeros(n, dtype=torch.int32, device=self.device)
         self._bufs = None
+        # pipelined fast-forward (tb_set_pipeline): terminal rewards of SwingRacket episodes are
+        # written later, from a side stream, into the buffers of the step that ended the episode
+        self.pipeline = bool(pipeline)
+        self._inflight = []
+        if self.pipeline:
+            if not (auto_reset and env_kind == ENV_SWING):
+                raise ValueError("pipeline=True needs SwingRacket-v0 with auto_reset")
+            if reuse_buffers:
+                raise ValueError("pipeline=True writes late into each step's own buffers: reuse_buffers must be off")
+            _check(self.L, self.L.tb_set_pipeline(self._h, 1), "tb_set_pipeline")
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -186,9 +200,27 @@ class BatchedEnv:
             rew = self._check_tensor(out[1], (self.num_envs,), t.float32, "out[1]")
             done = self._check_tensor(out[2], (self.num_envs,), t.uint8, "out[2]")
         _check(self.L, self.L.tb_step(self._h, a.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(),
-                                      None if self._term is None else self._term.data_ptr(), self._substeps.data_ptr(),
-                                      self._stream()), "tb_step")
+                                      None if self._term is None else self._term.data_ptr(),
+                                      None if self.pipeline else self._substeps.data_ptr(), self._stream()), "tb_step")
+        if self.pipeline and out is None:
+            self._inflight.append(rew)  # keep the late-written buffer alive until flush()
+            if len(self._inflight) > 4096:
+                self.flush()
         return obs, rew, done
+
+    def step_ptrs(self, actions_ptr, obs_ptr, reward_ptr, done_ptr):
+        """Unchecked fast path for callers that validated their buffers once (RolloutBuffer.bind):
+        raw device addresses of [N, A] f32 actions and [N, O] f32 / [N] f32 / [N] u8 outputs."""
+        rc = self.L.tb_step(self._h, actions_ptr, obs_ptr, reward_ptr, done_ptr, None, None,
+                            self.torch.cuda.current_stream(self.device).cuda_stream)
+        if rc:
+            _check(self.L, rc, "tb_step")
+
+    def flush(self):
+        """Pipelined mode: make the current stream wait until every outstanding fast-forward has
+        written its step's reward / terminal observation / substep count."""
+        _check(self.L, self.L.tb_flush(self._h, self._stream()), "tb_flush")
+        self._inflight = []
 
     def rollout(self, actions):
         """T steps in one launch: actions [T, N, A] -> obs [T, N, O], reward [T, N], done [T, N]."""
@@ -206,10 +238,14 @@ class BatchedEnv:
         """[N, O]: for envs whose episode ended in the latest step, its final observation."""
         if self._term is None:
             raise StepperError("terminal observations are only tracked with auto_reset=True")
+        if self.pipeline:
+            self.flush()
         return self._term
 
     def last_substeps(self):
         """int32 [N]: physics substeps executed by the latest step()/rollout() call."""
+        if self.pipeline:
+            raise StepperError("per-step substep counts are not tracked in pipelined mode (use counters()['substeps'])")
         return self._substeps
 
     def observe(self):

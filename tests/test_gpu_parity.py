@@ -290,3 +290,45 @@ def test_float32_drift_vs_float64_truth(torch):
         if quiet:
             assert err < 2e-4, (k, err)
     assert np.array_equal(g["step_count"], c["step_count"])
+
+
+@pytest.mark.parametrize("n", [4096, 1000])
+def test_pipelined_fast_forward_is_bit_identical(torch, n):
+    """tb_set_pipeline: the fast-forward runs on a side stream and writes the terminal step's
+    reward late; after flush() every output equals the unpipelined path bit for bit"""
+    from tennisbot_rl_amd.rollout import RolloutBuffer
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    T = 26 * 4 + 7
+    rng = np.random.default_rng(41)
+    acts = torch.from_numpy(rng.uniform(-1, 1, (T, n, 6)).astype(np.float32)).cuda()
+    a = BatchedEnv(ENV_SWING, n, seed=6, pipeline=True)
+    b = BatchedEnv(ENV_SWING, n, seed=6)
+    ba, bb = RolloutBuffer(ENV_SWING, T, n, "cuda:0"), RolloutBuffer(ENV_SWING, T, n, "cuda:0")
+    ba.actions.copy_(acts); bb.actions.copy_(acts)
+    assert torch.equal(a.reset(), b.reset())
+    for t in range(T):
+        ba.step_into(a, t); bb.step_into(b, t)
+    a.flush()
+    torch.cuda.synchronize()
+    assert torch.equal(ba.dones, bb.dones) and int(ba.dones.sum()) == 4 * n
+    assert torch.equal(ba.obs, bb.obs)
+    assert torch.equal(ba.rewards, bb.rewards) and float(ba.rewards.abs().sum()) > 0
+    assert torch.equal(a.terminal_obs(), b.terminal_obs())
+    wa, da = a.get_state_words(); wb, db = b.get_state_words()
+    assert torch.equal(wa, wb) and torch.equal(da, db)
+    assert a.counters() == b.counters()
+    # a state injection breaks the lockstep assumption: the library falls back to in-kernel loops
+    a.set_state_words(wa, da)
+    for t in range(30):
+        oa, ra, dna = a.step(acts[t]); ob, rb, dnb = b.step(acts[t])
+        a.flush()
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(dna, dnb)
+    # ... and a full reset re-arms it
+    assert torch.equal(a.reset(), b.reset())
+    outs = []
+    for t in range(26):
+        outs.append((a.step(acts[t]), b.step(acts[t])))
+    a.flush()
+    for (oa, ra, dna), (ob, rb, dnb) in outs:
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(dna, dnb)
+    a.close(); b.close()
