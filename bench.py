@@ -63,9 +63,10 @@ def parse():
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--contact-off", action="store_true", help="BASELINE configs[1] bench mode: racket<->ball pair disabled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound for each CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work per baseline leg (1 core, all cores)")
     ap.add_argument("--sweep", action="store_true", help="also time N = 4096 .. 4M envs on one GPU (extra JSON key)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of replaying one captured hipGraph")
     ap.add_argument("--no-pipeline", action="store_true", help="run the SwingRacket fast-forward inside the step kernel instead of a side stream")
     return ap.parse_args()
 
@@ -83,21 +84,32 @@ def fill_actions(buf_actions, seed, torch):
         buf_actions[t0:t0 + n].copy_(a[:n])
 
 
-def time_steps(env, buf, steps, warmup, torch, dist_on, tail_gather=True):
-    """W untimed + K timed steps; returns (wall seconds, HIP-event seconds of the K launches)"""
+def time_steps(env, buf, steps, warmup, torch, dist_on, tail_gather=True, graph=False):
+    """W untimed + K timed steps; returns (wall seconds, HIP-event seconds of the K launches).
+    graph=True: the K timed steps are captured once into a hipGraph (outside the timed region)
+    and the timed region replays it -- same kernels, same buffers, no per-step host work."""
     dev = env.device
     T = buf.T
     for t in range(warmup):
         buf.step_into(env, t % T)
+    g = None
+    if graph:
+        def body():
+            for t in range(steps):
+                buf.step_into(env, t % T)
+        g = env.capture(body)
     if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize(dev)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(torch.cuda.current_stream(dev))  # the stream the step kernel is launched on
-    for t in range(steps):
-        buf.step_into(env, t % T)
-    env.flush()  # pipelined fast-forwards: every step's outputs are complete from here on
+    if g is not None:
+        g.replay()
+    else:
+        for t in range(steps):
+            buf.step_into(env, t % T)
+        env.flush()  # pipelined fast-forwards: every step's outputs are complete from here on
     ev1.record(torch.cuda.current_stream(dev))
     if tail_gather:
         buf.all_gather()  # collect boundary: one collective (no-op for a single rank)
@@ -134,7 +146,7 @@ def cpu_baseline(kind_name, n_envs, seconds, seed):
                 b.step(acts[(done_steps + t) % 104])
             done_steps += 26
             el = time.perf_counter() - t0
-            if el > seconds or done_steps >= 1040:
+            if el > seconds:
                 break
         out[label] = {"steps_per_s": done_steps * n_envs / el, "agent_steps": done_steps, "seconds": el,
                       "substeps_per_s": float(b.counters()[6]) / el, "threads": threads}
@@ -174,7 +186,8 @@ def main():
     buf.bind(env)
     env.reset()
     env.counters_reset()
-    wall, ev_s = time_steps(env, buf, args.steps, args.warmup, torch, dist_on)
+    use_graph = not args.no_graph
+    wall, ev_s = time_steps(env, buf, args.steps, args.warmup, torch, dist_on, graph=use_graph)
     c = env.counters()
 
     wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
@@ -205,7 +218,8 @@ def main():
             "config": {"workload": "%s, %d envs/GPU, %s, auto-reset, U(-1,1) actions, rollout buffer %d steps%s" % (
                 "SwingRacket-v0" if args.env == "swing" else "Tennisbot-v0", N,
                 "racket<->ball contact off (configs[1] bench mode)" if args.contact_off else "full contact semantics",
-                T_buf, ", 1 RCCL all-gather of rollouts at the collect boundary" if dist_on else ""),
+                T_buf, ", fast-forward pipelined on side streams" if pipeline else "", ", K steps replayed as one hipGraph" if use_graph else "",
+                ", 1 RCCL all-gather of rollouts at the collect boundary" if dist_on else ""),
                 "envs_per_gpu": N, "global_envs": world * N, "parallelism": "env-sharded x%d" % world},
             "substeps_per_s": timed_substeps / wall_max,
             "substeps_per_agent_step": timed_substeps / (world * N * args.steps),
@@ -227,7 +241,7 @@ def main():
             b2.bind(e2)
             e2.reset()
             k = 52 if n >= 1048576 else 104
-            w, evs = time_steps(e2, b2, k, 26, torch, False, tail_gather=False)
+            w, evs = time_steps(e2, b2, k, 26, torch, False, tail_gather=False, graph=use_graph)
             ab = ALGO_BYTES[args.env]
             sweep.append({"envs": n, "steps_per_s": n * k / w, "launch_us": evs / k * 1e6,
                           "achieved_GBs": (ab["read"] + ab["write"]) * n / (evs / k) / 1e9})

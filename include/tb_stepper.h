@@ -207,6 +207,12 @@ int tb_rollout(TbHandle *h, int n_steps, const float *actions_dev, float *obs_de
  */
 int tb_set_pipeline(TbHandle *h, int enable);
 int tb_flush(TbHandle *h, void *stream);
+/* Stream-capture support (hipGraph): events recorded inside a capture are meaningless outside
+ * it and vice versa. Call with host_wait = 1 right BEFORE beginning a capture that will contain
+ * tb_step calls (drains the side streams on the host and forgets their events), capture
+ * ... tb_step x K ... tb_flush on the capturing stream, end the capture, then call with
+ * host_wait = 0 (forget the capture-local events). */
+int tb_pipeline_sync(TbHandle *h, int host_wait);
 
 /* Snapshot / restore the persistent state (the reference never checkpoints env state;
  * SURVEY.md section 5). words: [tb_state_words][N] uint32 bit patterns, done: [N] bytes.

@@ -291,6 +291,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
   for (int k = 0; k < 8; ++k) st.acc[k] = 0u;
   st.t = stamp_now();
   const unsigned long long t_kernel0 = st.t;
+  const unsigned long long rt_kernel0 = __builtin_amdgcn_s_memrealtime();
 #endif
   if (live) {
     bool any_reset = false;
@@ -351,6 +352,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
     for (int k = 0; k < 6; ++k) atomicAdd(&g_diag_cycles[k], (unsigned long long)st.acc[k]);
     atomicAdd(&g_diag_cycles[8], stamp_now() - t_kernel0);
     atomicAdd(&g_diag_cycles[9], 1ull);
+    atomicAdd(&g_diag_cycles[14], __builtin_amdgcn_s_memrealtime() - rt_kernel0);  // 100 MHz ticks
   }
 #endif
 }
@@ -684,6 +686,17 @@ int tb_set_pipeline(TbHandle* h, int enable) {
     HIP_TRY(hipDeviceSynchronize());
   }
   h->pipeline = enable ? 1 : 0;
+  return TB_OK;
+}
+
+int tb_pipeline_sync(TbHandle* h, int host_wait) {
+  if (!h) return fail(TB_E_INVAL, "tb_pipeline_sync: null handle");
+  DeviceGuard g(h->device);
+  for (int k = 0; k < TB_FF_SLOTS; ++k) {
+    if (host_wait && h->side[k]) HIP_TRY(hipStreamSynchronize(h->side[k]));
+    h->ff_busy[k] = 0;
+  }
+  h->last_slot = -1;
   return TB_OK;
 }
 

@@ -61,6 +61,8 @@ def load_library():
     L.tb_set_pipeline.restype = i32
     L.tb_flush.argtypes = [vp, vp]
     L.tb_flush.restype = i32
+    L.tb_pipeline_sync.argtypes = [vp, i32]
+    L.tb_pipeline_sync.restype = i32
     L.tb_diag_stream_copy.argtypes = [vp, vp, i32, i32, i32, vp]
     L.tb_diag_stream_copy.restype = i32
     for f in ("tb_create", "tb_destroy", "tb_set_params", "tb_reset", "tb_step", "tb_rollout", "tb_get_state",
@@ -215,6 +217,21 @@ class BatchedEnv:
                             self.torch.cuda.current_stream(self.device).cuda_stream)
         if rc:
             _check(self.L, rc, "tb_step")
+
+    def capture(self, fn):
+        """Capture `fn()` -- a fixed sequence of step()/step_ptrs()/RolloutBuffer.step_into calls on
+        fixed buffers -- into a HIP graph and return it; `graph.replay()` then runs the whole
+        sequence with one launch (no per-step host work). In pipelined mode the side-stream
+        fast-forwards are captured as forked branches and joined by the final flush()."""
+        t = self.torch
+        t.cuda.current_stream(self.device).synchronize()
+        _check(self.L, self.L.tb_pipeline_sync(self._h, 1), "tb_pipeline_sync")
+        g = t.cuda.CUDAGraph()
+        with t.cuda.graph(g):
+            fn()
+            self.flush()
+        _check(self.L, self.L.tb_pipeline_sync(self._h, 0), "tb_pipeline_sync")
+        return g
 
     def flush(self):
         """Pipelined mode: make the current stream wait until every outstanding fast-forward has

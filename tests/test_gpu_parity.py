@@ -332,3 +332,32 @@ def test_pipelined_fast_forward_is_bit_identical(torch, n):
     for (oa, ra, dna), (ob, rb, dnb) in outs:
         assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(dna, dnb)
     a.close(); b.close()
+
+
+def test_hipgraph_replay_equals_eager(torch):
+    """BatchedEnv.capture: K steps (+ pipelined fast-forward branches) as one hipGraph launch"""
+    from tennisbot_rl_amd.rollout import RolloutBuffer
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    n, T = 2048, 78
+    rng = np.random.default_rng(43)
+    acts = torch.from_numpy(rng.uniform(-1, 1, (T, n, 6)).astype(np.float32)).cuda()
+    for pipeline in (True, False):
+        a = BatchedEnv(ENV_SWING, n, seed=8, pipeline=pipeline)
+        b = BatchedEnv(ENV_SWING, n, seed=8)
+        ba, bb = RolloutBuffer(ENV_SWING, T, n, "cuda:0").bind(a), RolloutBuffer(ENV_SWING, T, n, "cuda:0")
+        ba.actions.copy_(acts); bb.actions.copy_(acts)
+        a.reset(); b.reset()
+
+        def body():
+            for t in range(T):
+                ba.step_into(a, t)
+        g = a.capture(body)
+        for rep in range(2):  # 78 = 3 whole episodes: the graph can be replayed back to back
+            g.replay()
+            for t in range(T):
+                bb.step_into(b, t)
+            torch.cuda.synchronize()
+            assert torch.equal(ba.obs, bb.obs) and torch.equal(ba.rewards, bb.rewards) and torch.equal(ba.dones, bb.dones)
+        wa, da = a.get_state_words(); wb, db = b.get_state_words()
+        assert torch.equal(wa, wb) and torch.equal(da, db) and a.counters() == b.counters()
+        a.close(); b.close()
