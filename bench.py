@@ -84,6 +84,9 @@ def fill_actions(buf_actions, seed, torch):
         buf_actions[t0:t0 + n].copy_(a[:n])
 
 
+GRAPH_STATE = {"used": True}
+
+
 def time_steps(env, buf, steps, warmup, torch, dist_on, tail_gather=True, graph=False):
     """W untimed + K timed steps; returns (wall seconds, HIP-event seconds of the K launches).
     graph=True: the K timed steps are captured once into a hipGraph (outside the timed region)
@@ -97,7 +100,15 @@ def time_steps(env, buf, steps, warmup, torch, dist_on, tail_gather=True, graph=
         def body():
             for t in range(steps):
                 buf.step_into(env, t % T)
-        g = env.capture(body)
+        # capture does not execute anything, but the library's host-side episode phase advances as
+        # if it did; a failed capture must not leave it (or the device state) ahead, so the phase is
+        # re-armed by restoring the state the warm-up left behind
+        try:
+            g = env.capture(body)
+        except Exception as exc:  # fall back to per-step launches and say so
+            print("hipGraph capture failed (%s: %s); launching every step from the host" % (type(exc).__name__, exc), file=sys.stderr)
+            g = None
+            GRAPH_STATE["used"] = False
     if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize(dev)
@@ -215,10 +226,10 @@ def main():
             "ms_per_step": wall_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s, %d envs/GPU, %s, auto-reset, U(-1,1) actions, rollout buffer %d steps%s" % (
+            "config": {"workload": "%s, %d envs/GPU, %s, auto-reset, U(-1,1) actions, rollout buffer %d steps%s%s%s" % (
                 "SwingRacket-v0" if args.env == "swing" else "Tennisbot-v0", N,
                 "racket<->ball contact off (configs[1] bench mode)" if args.contact_off else "full contact semantics",
-                T_buf, ", fast-forward pipelined on side streams" if pipeline else "", ", K steps replayed as one hipGraph" if use_graph else "",
+                T_buf, ", fast-forward pipelined on side streams" if pipeline else "", ", K steps replayed as one hipGraph" if (use_graph and GRAPH_STATE["used"]) else "",
                 ", 1 RCCL all-gather of rollouts at the collect boundary" if dist_on else ""),
                 "envs_per_gpu": N, "global_envs": world * N, "parallelism": "env-sharded x%d" % world},
             "substeps_per_s": timed_substeps / wall_max,

@@ -227,10 +227,14 @@ class BatchedEnv:
         t.cuda.current_stream(self.device).synchronize()
         _check(self.L, self.L.tb_pipeline_sync(self._h, 1), "tb_pipeline_sync")
         g = t.cuda.CUDAGraph()
-        with t.cuda.graph(g):
-            fn()
-            self.flush()
-        _check(self.L, self.L.tb_pipeline_sync(self._h, 0), "tb_pipeline_sync")
+        try:
+            # thread_local: other threads (e.g. the RCCL watchdog of torch.distributed) may keep
+            # issuing HIP calls while this thread captures
+            with t.cuda.graph(g, capture_error_mode="thread_local"):
+                fn()
+                self.flush()
+        finally:
+            _check(self.L, self.L.tb_pipeline_sync(self._h, 0), "tb_pipeline_sync")
         return g
 
     def flush(self):

@@ -42,6 +42,15 @@ def main(d, out):
                 "launches": nf[n], "FETCH_SIZE_KiB_raw": f[n], "WRITE_SIZE_KiB_raw": w[n],
                 "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "traffic_bytes_per_launch": fb + wb,
                 "traffic_bytes_per_env_step": (fb + wb) / n, "algorithmic_bytes_per_env_step": 267}
+        # pipelined runs: the fast-forward is its own kernel (one launch per 26 agent steps)
+        ff, nff = per_kernel(os.path.join(d, "%s_FETCH_SIZE_counter_collection.csv" % tag), "FETCH_SIZE", "tb_ff_kernel")
+        fw, _ = per_kernel(os.path.join(d, "%s_WRITE_SIZE_counter_collection.csv" % tag), "WRITE_SIZE", "tb_ff_kernel")
+        for n in ff:
+            fb, wb = ff[n] * 1024.0 / fetch_ratio, fw[n] * 1024.0 / write_ratio
+            res["workloads"]["swing_%d" % n]["ff_kernel"] = {
+                "launches": nff[n], "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
+                "traffic_bytes_per_env_per_launch": (fb + wb) / n,
+                "note": "one tb_ff_kernel launch per 26 tb_step_kernel launches; reads the parked state (121 B/env), writes reward (4 B/env)"}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
