@@ -50,7 +50,7 @@ extern "C" {
 
 /* persistent state, structure-of-arrays: 32-bit words [TB_*_WORDS][N] + one byte [N] */
 #define TB_SWING_WORDS 30
-#define TB_TENNIS_WORDS 27
+#define TB_TENNIS_WORDS 28
 /* rows shared by both envs */
 #define TB_W_RP 0   /* racket COM position (3)  racket.py:131 returns the COM frame */
 #define TB_W_RQ 3   /* racket orientation quaternion x,y,z,w (4) */
@@ -67,8 +67,9 @@ extern "C" {
 #define TB_W_SW_EPISODE 29 /* episode index (uint32), keys the reset RNG */
 /* Tennisbot-v0 rows */
 #define TB_W_TN_SHOOT 22  /* ball_shoot_force (3)      tennisbot_env.py:237-241 */
-#define TB_W_TN_STEP 25   /* step_count (int32)        tennisbot_env.py:122 */
-#define TB_W_TN_EPISODE 26
+#define TB_W_TN_SCALE 25  /* racket globalScaling this episode was built with  tennisbot_env.py:230-234 */
+#define TB_W_TN_STEP 26   /* step_count (int32)        tennisbot_env.py:122 */
+#define TB_W_TN_EPISODE 27
 
 /* done byte: 0 running; 1 done, and (Swing) the restoring force issued at the end
  * of the last fast-forward substep (swingracket_env.py:135-141) is still pending in
@@ -110,11 +111,13 @@ typedef struct TbParams {
   /* racket: racket.urdf:17-21, racket.py:43-45 */
   float racket_mass, racket_inv_mass;
   float racket_inertia[3], racket_inv_inertia[3]; /* body-frame diagonal */
-  float racket_com[3];       /* inertial origin in the link frame, times racket_scale */
-  float racket_half_thick;   /* times racket_scale */
-  float hull_margin;         /* URDF convex-hull collision margin, 0.001 */
-  float hull_bound_radius;   /* max distance COM -> inflated hull, for the cull */
-  float racket_scale;        /* tennisbot_env.py:213-215,234 globalScaling */
+  float racket_com[3];       /* inertial origin in the link frame, at scale 1 */
+  float racket_half_thick;   /* at scale 1 */
+  float hull_margin;         /* URDF convex-hull collision margin, 0.001 (not scaled) */
+  float hull_bound_radius;   /* max distance COM -> hull vertex at scale 1, for the cull */
+  float racket_scale;        /* tennisbot_env.py:213-215: the globalScaling an env's racket is rebuilt
+                              * with at its NEXT reset (tennisbot_env.py:230-234); each Tennisbot env
+                              * keeps the scale of its current episode in its own state word */
   /* ball: ball.urdf:11-15,27-32, objects.py:48-50,67-72 */
   float ball_mass, ball_inv_mass, ball_inv_inertia, ball_radius;
   float magnus_k;            /* F = k (w x v); 0 reproduces the reference (BASELINE configs[4] extension) */
@@ -126,7 +129,7 @@ typedef struct TbParams {
   float ground_half[3];
   float net_half[3];
   float goal_radius, goal_half_len;
-  /* racket collision outline: CCW convex polygon in the COM frame (y, z), pre-scaled.
+  /* racket collision outline: CCW convex polygon in the COM frame (y, z), at scale 1.
    * record i = { a.y, a.z, e.y, e.z, 1/|e|^2, 1/|e|, 0, 0 } with e = v[i+1] - v[i] */
   int32_t n_hull;
   float hull_edges[TB_MAX_HULL][TB_HULL_REC];

@@ -143,6 +143,7 @@ typedef struct {
   real ball_inv_mass, ball_inv_inertia, ball_radius, magnus_k, ball_spin_max;
   real rest_racket, rest_court, rest_goal, fric_racket, fric_court, fric_goal;
   real ground_half[3], net_half[3], goal_radius, goal_half_len;
+  real racket_scale;
   int n_hull; real hull_edges[TB_MAX_HULL][6];
 } Prm;
 
@@ -175,7 +176,7 @@ static void prm_from(Prm *Q, const TbParams *P) {
     Q->racket_com[i] = W(P->racket_com[i]); Q->ground_half[i] = W(P->ground_half[i]); Q->net_half[i] = W(P->net_half[i]);
   }
   Q->racket_half_thick = P->racket_half_thick; /* mesh data: exact as stored */
-  Q->hull_margin = W(P->hull_margin); Q->hull_bound_radius = W(P->hull_bound_radius);
+  Q->hull_margin = W(P->hull_margin); Q->hull_bound_radius = W(P->hull_bound_radius); Q->racket_scale = W(P->racket_scale);
   Q->ball_inv_mass = W(P->ball_inv_mass); Q->ball_inv_inertia = W(P->ball_inv_inertia); Q->ball_radius = W(P->ball_radius);
   Q->magnus_k = W(P->magnus_k); Q->ball_spin_max = W(P->ball_spin_max);
   Q->rest_racket = W(P->rest_racket); Q->rest_court = W(P->rest_court); Q->rest_goal = W(P->rest_goal);
@@ -205,7 +206,7 @@ typedef struct { v3 p; v3 v; v3 w; } Ball;
 typedef struct {
   Racket r;
   Ball b;
-  real aux[6]; /* swing: goal.x goal.y spawn.x spawn.y spawn.z d0 ; tennis: shoot xyz */
+  real aux[6]; /* swing: goal.x goal.y spawn.x spawn.y spawn.z d0 ; tennis: shoot xyz, racket scale */
   int32_t step_count;
   uint32_t episode;
   uint8_t done;
@@ -234,13 +235,16 @@ typedef struct {
 /* ball vs racket: the racket's dynamic mesh collides as the convex hull of racket.stl,
  * i.e. a prism over a convex polygon in the racket's (y, z) plane,
  * inflated by the URDF hull margin. racket.urdf:12-16. */
-static Hit sphere_vs_racket(const Prm *P, const Racket *rk, v3 c) {
+static Hit sphere_vs_racket(const Prm *P, const Racket *rk, v3 c, real s) {
   Hit h; memset(&h, 0, sizeof h);
   const real r = P->ball_radius, thr = P->contact_threshold;
   v3 d = sub3(c, rk->p);
-  real reach = (P->hull_bound_radius + r) + thr;
+  real reach = ((P->hull_bound_radius * s + P->hull_margin) + r) + thr;
   if (dot3(d, d) > reach * reach) return h;
-  v3 l = qrot_inv(rk->q, d);
+  /* globalScaling s (tennisbot_env.py:234): dist(p, s*Hull) = s * dist(p/s, Hull), so the query
+   * point is taken to the unscaled outline; margin and ball radius are not scaled */
+  real inv_s = R(1) / s;
+  v3 l = mul3(inv_s, qrot_inv(rk->q, d));
   real ax = FABS(l.x) - P->racket_half_thick;
   real sx = l.x < R(0) ? R(-1) : R(1);
   int inside = 1, deep_edge = 0;
@@ -278,7 +282,7 @@ static Hit sphere_vs_racket(const Prm *P, const Racket *rk, v3 c) {
     real inv = R(1) / dist_hull;
     nl = V3(dx * inv, best_ry * inv, best_rz * inv);
   }
-  h.dist = (dist_hull - P->hull_margin) - r;
+  h.dist = (dist_hull * s - P->hull_margin) - r;
   h.hit = h.dist < thr;
   h.n = qrot(rk->q, nl);
   h.rr = axpy3(-(r + h.dist), h.n, d);
@@ -513,12 +517,12 @@ static void integrate_pose(const Prm *P, Racket *rk, Ball *b) {
   }
 }
 
-static int substep(const Prm *P, int kind, Racket *rk, Ball *b, v3 Fr, v3 Tr, v3 Fb, real gx, real gy) {
+static int substep(const Prm *P, int kind, Racket *rk, Ball *b, v3 Fr, v3 Tr, v3 Fb, real gx, real gy, real scale) {
   Row rows[4];
   int nrows = 0, bits = 0;
   Hit h;
   if (P->flags & TB_F_RACKET_BALL) {
-    h = sphere_vs_racket(P, rk, b->p);
+    h = sphere_vs_racket(P, rk, b->p, scale);
     if (h.hit) { bits |= CT_RACKET; }
   } else h.hit = 0;
   Hit hg = sphere_vs_box(P, P->ground_half, b->p);
@@ -586,11 +590,12 @@ static void reset_env(const struct TboBatch *B, Env *e, uint64_t env_id) {
     real x = uniform(R(7.5), R(5), u[0]), y = uniform(R(-5), R(10), u[1]), z = uniform(R(0.2), R(0.21) - R(0.2), u[2]);
     q4 q0 = {R(0), R(0), R(0), R(1)};
     e->r.q = q0;
-    e->r.p = add3(V3(x, y, z), com);
+    e->aux[3] = P->racket_scale; /* Racket(..., scale=self.racket_scale), tennisbot_env.py:230-234 */
+    e->r.p = add3(V3(x, y, z), mul3(e->aux[3], com));
     e->aux[0] = uniform(R(25), R(12.5), u[3]);
     e->aux[1] = uniform(R(-10), R(20), w[0]);
     e->aux[2] = R(20);
-    e->aux[3] = e->aux[4] = e->aux[5] = R(0);
+    e->aux[4] = e->aux[5] = R(0);
     e->b.p = V3(uniform(R(-12), R(6), w[1]), uniform(R(-1), R(2), w[2]), uniform(R(1), R(0.5), w[3]));
     ctr[3] = 2u;
   }
@@ -620,7 +625,7 @@ static real swing_step(const Prm *P, Env *e, const float *a, int *substeps, uint
     F = add3(F, V3(R(-50) * (e->r.p.x - e->aux[2]), R(-2) * (e->r.p.y - e->aux[3]), R(-2) * ((e->r.p.z - e->aux[4]) - R(4))));
     e->done = TB_DONE_YES;
   }
-  int bits = substep(P, TB_ENV_SWING, &e->r, &e->b, F, T, zero, e->aux[0], e->aux[1]); /* :82 */
+  int bits = substep(P, TB_ENV_SWING, &e->r, &e->b, F, T, zero, e->aux[0], e->aux[1], R(1)); /* :82 */
   e->step_count += 1;                                                                   /* :83 */
   int ns = 1;
   real reward = R(0);
@@ -629,7 +634,7 @@ static real swing_step(const Prm *P, Env *e, const float *a, int *substeps, uint
   if (e->step_count > 25) {                                     /* :105 */
     v3 Fp = zero; /* forces were cleared by the substep above */
     while (!e->done) { /* :106 */
-      bits = substep(P, TB_ENV_SWING, &e->r, &e->b, Fp, zero, zero, e->aux[0], e->aux[1]); /* :107 */
+      bits = substep(P, TB_ENV_SWING, &e->r, &e->b, Fp, zero, zero, e->aux[0], e->aux[1], R(1)); /* :107 */
       e->step_count += 1; ns++;
       if (bits & CT_RACKET) cnt[0]++;
       if (bits & (CT_GROUND | CT_NET)) { e->done = TB_DONE_PENDING_FORCE; reward += moved_dist_to_goal(e); cnt[1]++; } /* :111-114 */
@@ -653,7 +658,7 @@ static real tennis_step(const Prm *P, Env *e, const float *a, float *obs, int *r
   v3 F = V3(R(a[0]) * R(10), R(a[1]) * R(10), R(4) * R(9.81)); /* :112-115 */
   v3 Fb = zero;
   if (e->step_count < 5) Fb = V3(e->aux[0], e->aux[1], e->aux[2]); /* :118-119 */
-  int bits = substep(P, TB_ENV_TENNIS, &e->r, &e->b, F, zero, Fb, R(0), R(0)); /* :121 */
+  int bits = substep(P, TB_ENV_TENNIS, &e->r, &e->b, F, zero, Fb, R(0), R(0), e->aux[3]); /* :121 */
   e->step_count += 1;                                                        /* :122 */
   if (bits & CT_RACKET) cnt[0]++;
   fill_obs(TB_ENV_TENNIS, e, obs); /* :134-136 */
@@ -681,7 +686,7 @@ TboBatch *tbo_create(const TbParams *params, int env_kind, int n_envs, uint64_t 
   TboBatch *B = (TboBatch *)calloc(1, sizeof *B);
   B->P0 = *params; prm_from(&B->P, params); B->kind = env_kind; B->n = n_envs; B->seed = seed; B->env_id_base = env_id_base; B->threads = 1;
   B->e = (Env *)calloc((size_t)n_envs, sizeof(Env));
-  for (int i = 0; i < n_envs; ++i) { B->e[i].r.q.w = R(1); B->e[i].episode = 0xFFFFFFFFu; } /* first reset -> episode 0 */
+  for (int i = 0; i < n_envs; ++i) { B->e[i].r.q.w = R(1); if (env_kind == TB_ENV_TENNIS) B->e[i].aux[3] = R(1); B->e[i].episode = 0xFFFFFFFFu; } /* first reset -> episode 0 */
   return B;
 }
 void tbo_destroy(TboBatch *B) { if (B) { free(B->e); free(B); } }
@@ -755,7 +760,7 @@ static void env_to_vals(int kind, const Env *e, double *v) {
   for (int k = 0; k < 13; ++k) v[k] = (double)f[k];
   f = (const real *)&e->b;
   for (int k = 0; k < 9; ++k) v[13 + k] = (double)f[k];
-  int na = kind == TB_ENV_SWING ? 6 : 3;
+  int na = kind == TB_ENV_SWING ? 6 : 4;
   for (int k = 0; k < na; ++k) v[22 + k] = (double)e->aux[k];
   v[22 + na] = (double)e->step_count;
   v[23 + na] = (double)e->episode;
@@ -790,7 +795,7 @@ void tbo_set_state(TboBatch *B, const uint32_t *words, const uint8_t *done) {
     for (int k = 0; k < 13; ++k) d[k] = (real)f[k];
     d = (real *)&e->b;
     for (int k = 0; k < 9; ++k) d[k] = (real)f[13 + k];
-    int na = B->kind == TB_ENV_SWING ? 6 : 3;
+    int na = B->kind == TB_ENV_SWING ? 6 : 4;
     for (int k = 0; k < na; ++k) e->aux[k] = (real)f[22 + k];
     memcpy(&e->step_count, &words[(size_t)(nw - 2) * n + i], 4);
     e->episode = words[(size_t)(nw - 1) * n + i];
@@ -804,7 +809,7 @@ int tbo_query_racket(const TbParams *P0, const float rp[3], const float rq[4], c
   Racket rk; memset(&rk, 0, sizeof rk);
   rk.p = V3(R(rp[0]), R(rp[1]), R(rp[2]));
   rk.q.x = R(rq[0]); rk.q.y = R(rq[1]); rk.q.z = R(rq[2]); rk.q.w = R(rq[3]);
-  Hit h = sphere_vs_racket(P, &rk, V3(R(c[0]), R(c[1]), R(c[2])));
+  Hit h = sphere_vs_racket(P, &rk, V3(R(c[0]), R(c[1]), R(c[2])), P->racket_scale);
   out[0] = h.dist; out[1] = h.n.x; out[2] = h.n.y; out[3] = h.n.z; out[4] = h.rr.x; out[5] = h.rr.y; out[6] = h.rr.z; out[7] = 0;
   return h.hit;
 }

@@ -96,7 +96,7 @@ TB_DEV float uniform(float lo, float span, uint32_t u) { return lo + span * ((fl
 struct KParams {
   float dt, inv_dt, gravity, lin_damp, ang_damp, max_ang_step, rest_vel_threshold, erp, contact_threshold;
   int solver_iters; uint32_t flags; float solver_tol;
-  float racket_inv_mass, racket_inertia[3], racket_inv_inertia[3], racket_com[3], racket_half_thick, hull_margin, hull_bound_radius;
+  float racket_inv_mass, racket_inertia[3], racket_inv_inertia[3], racket_com[3], racket_half_thick, hull_margin, hull_bound_radius, racket_scale;
   float ball_inv_mass, ball_inv_inertia, ball_radius, magnus_k, ball_spin_max;
   float rest_racket, rest_court, rest_goal, fric_racket, fric_court, fric_goal;
   float ground_half[3], net_half[3], goal_radius, goal_half_len;
@@ -148,15 +148,20 @@ TB_DEV unsigned long long stamp_now() {
 // `hull` points at the LDS copy of the edge records {a.y a.z e.y e.z | 1/|e|^2 1/|e| - -}.
 // The bounding-sphere cull is done by the caller (substep) so that a whole wave can skip
 // the sweep with one ballot; `d` = ball centre - racket COM.
-TB_DEV bool racket_in_reach(const KParams& P, vec3 d) {
-  float reach = (P.hull_bound_radius + P.ball_radius) + P.contact_threshold;
+// `s` is the env's racket scale (globalScaling, tennisbot_env.py:234): dist(p, s*Hull) =
+// s * dist(p/s, Hull), so the query point goes to the unscaled outline; the margin and the ball
+// radius are not scaled. SCALED = false (SwingRacket, s == 1) drops the multiplications by 1.
+TB_DEV bool racket_in_reach(const KParams& P, vec3 d, float s) {
+  float reach = ((P.hull_bound_radius * s + P.hull_margin) + P.ball_radius) + P.contact_threshold;
   return !(dot(d, d) > reach * reach);
 }
-TB_DEV Hit sphere_vs_racket_sweep(const KParams& P, const float4* hull, const Racket& rk, vec3 d) {
+template <bool SCALED>
+TB_DEV Hit sphere_vs_racket_sweep(const KParams& P, const float4* hull, const Racket& rk, vec3 d, float s) {
   Hit h;
   h.hit = false; h.dist = 0.0f; h.n = mk(0, 0, 0); h.rr = mk(0, 0, 0);
   const float r = P.ball_radius, thr = P.contact_threshold;
   vec3 l = rotate_inv(rk.q, d);
+  if (SCALED) l = (1.0f / s) * l;
   float ax = fabsf(l.x) - P.racket_half_thick;
   // Local-frame culls before the 38-edge sweep. In a SwingRacket episode the ball starts
   // 0.47 m in FRONT of the face, inside the bounding sphere, and falls alongside the racket:
@@ -167,11 +172,11 @@ TB_DEV Hit sphere_vs_racket_sweep(const KParams& P, const float4* hull, const Ra
   //      separation; 0.1 mm of slack covers all rounding, lanes inside the slack just run the
   //      exact sweep. (A plain bounding box is too loose next to the handle, where the outline
   //      is a narrow wedge: a tumbling racket's ball spends many substeps there.)
-  if ((ax - P.hull_margin) - r >= thr) return h;
+  if (((SCALED ? ax * s : ax) - P.hull_margin) - r >= thr) return h;
   float sep = -3.0e38f;
 #pragma unroll
   for (int k = 0; k < TB_N_CULL; ++k) sep = fmaxf(sep, FMA(P.cull_planes[k][1], l.z, P.cull_planes[k][0] * l.y) - P.cull_planes[k][2]);
-  if ((sep - P.hull_margin) - r >= thr + 1.0e-4f) return h;
+  if (((SCALED ? sep * s : sep) - P.hull_margin) - r >= thr + 1.0e-4f) return h;
 #ifdef TB_DIAG_STAMPS
   {
     unsigned long long m = __ballot(1);
@@ -217,7 +222,7 @@ TB_DEV Hit sphere_vs_racket_sweep(const KParams& P, const float4* hull, const Ra
     float inv = 1.0f / dist_hull;
     nl = mk(dx * inv, best_ry * inv, best_rz * inv);
   }
-  h.dist = (dist_hull - P.hull_margin) - r;
+  h.dist = ((SCALED ? dist_hull * s : dist_hull) - P.hull_margin) - r;
   h.hit = h.dist < thr;
   h.n = rotate(rk.q, nl);
   h.rr = fma3(-(r + h.dist), h.n, d);
@@ -508,14 +513,14 @@ TB_DEV void integrate_pose(const KParams& P, Racket& rk, Ball& b) {
 // sweep / the static tests / the impulse solver only if __any lane needs them, and those
 // branches are wave-uniform (s_cbranch on the ballot), never if-converted into the hot path.
 template <int KIND>
-TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, vec3 Fr, vec3 Tr, vec3 Fb, float goal_x, float goal_y TB_STAMP_ARG) {
+TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, vec3 Fr, vec3 Tr, vec3 Fb, float goal_x, float goal_y, float scale TB_STAMP_ARG) {
   int bits = 0;
   TB_STAMP(st, 0);  // everything between two substeps (loop control, env logic)
   Hit hr, hg, hn, hc;
   hr.hit = false; hg.hit = false; hn.hit = false; hc.hit = false;
 
   vec3 d = b.p - rk.p;
-  bool near_racket = (P.flags & TB_F_RACKET_BALL) && racket_in_reach(P, d);
+  bool near_racket = (P.flags & TB_F_RACKET_BALL) && racket_in_reach(P, d, scale);
 #ifdef TB_DIAG_NO_NARROW
   near_racket = false;
 #endif
@@ -523,7 +528,7 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, ve
 #ifdef TB_DIAG_STAMPS
     if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)__ballot(1)) - 1u) atomicAdd(&g_diag_cycles[12], 1ull);  // wave-substeps with a lane in reach
 #endif
-    if (near_racket) hr = sphere_vs_racket_sweep(P, hull, rk, d);
+    if (near_racket) hr = sphere_vs_racket_sweep<KIND == TB_ENV_TENNIS>(P, hull, rk, d, scale);
   }
 #ifdef TB_DIAG_STAMPS
   if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)__ballot(1)) - 1u) atomicAdd(&g_diag_cycles[13], 1ull);  // wave-substeps

@@ -52,7 +52,7 @@ struct KArgs {
 struct EnvRegs {
   Racket r;
   Ball b;
-  float aux[6];  // swing: goal.x goal.y spawn.x spawn.y spawn.z d0 ; tennis: shoot force xyz
+  float aux[6];  // swing: goal.x goal.y spawn.x spawn.y spawn.z d0 ; tennis: shoot force xyz, racket scale
   int step_count;
   uint32_t episode;
   uint32_t done;
@@ -60,7 +60,7 @@ struct EnvRegs {
 
 template <int KIND> struct Dims;
 template <> struct Dims<TB_ENV_SWING> { static constexpr int W = TB_SWING_WORDS, A = TB_SWING_ACT_DIM, O = TB_SWING_OBS_DIM, NAUX = 6; };
-template <> struct Dims<TB_ENV_TENNIS> { static constexpr int W = TB_TENNIS_WORDS, A = TB_TENNIS_ACT_DIM, O = TB_TENNIS_OBS_DIM, NAUX = 3; };
+template <> struct Dims<TB_ENV_TENNIS> { static constexpr int W = TB_TENNIS_WORDS, A = TB_TENNIS_ACT_DIM, O = TB_TENNIS_OBS_DIM, NAUX = 4; };
 
 TB_DEV float ld(const uint32_t* w, int row, int n, int i) { return __uint_as_float(w[(size_t)row * n + i]); }
 TB_DEV void st(uint32_t* w, int row, int n, int i, float v) { w[(size_t)row * n + i] = __float_as_uint(v); }
@@ -152,11 +152,12 @@ TB_DEV void reset_env(const KArgs& A, int i, EnvRegs& e) {
     float x = uniform(7.5f, 5.0f, u[0]), y = uniform(-5.0f, 10.0f, u[1]), z = uniform(0.2f, 0.21f - 0.2f, u[2]);
     quat q0; q0.x = 0.0f; q0.y = 0.0f; q0.z = 0.0f; q0.w = 1.0f;
     e.r.q = q0;
-    e.r.p = mk(x, y, z) + com;
+    e.aux[3] = P.racket_scale;  // Racket(..., scale=self.racket_scale), tennisbot_env.py:230-234
+    e.r.p = mk(x, y, z) + e.aux[3] * com;
     e.aux[0] = uniform(25.0f, 12.5f, u[3]);
     e.aux[1] = uniform(-10.0f, 20.0f, w[0]);
     e.aux[2] = 20.0f;
-    e.aux[3] = 0.0f; e.aux[4] = 0.0f; e.aux[5] = 0.0f;
+    e.aux[4] = 0.0f; e.aux[5] = 0.0f;
     e.b.p = mk(uniform(-12.0f, 6.0f, w[1]), uniform(-1.0f, 2.0f, w[2]), uniform(1.0f, 0.5f, w[3]));
     spin_block = 2u;
   }
@@ -186,7 +187,7 @@ TB_DEV float swing_fast_forward(const KParams& P, const float4* hull, EnvRegs& e
   float reward = 0.0f;
   vec3 Fp = zero;  // the substep before the loop cleared the accumulated forces
   while (!e.done) {  // :106 -- per-lane loop; the wave leaves when its last lane is done
-    int bits = substep<TB_ENV_SWING>(P, hull, e.r, e.b, Fp, zero, zero, e.aux[0], e.aux[1] TB_STAMP_PASS);  // :107
+    int bits = substep<TB_ENV_SWING>(P, hull, e.r, e.b, Fp, zero, zero, e.aux[0], e.aux[1], 1.0f TB_STAMP_PASS);  // :107
     e.step_count += 1; ns++;
     if (bits & CT_RACKET) cnt[0]++;
     if (bits & (CT_GROUND | CT_NET)) { e.done = TB_DONE_PENDING_FORCE; reward += moved_dist_to_goal(e); cnt[1]++; }  // :111-114
@@ -206,7 +207,7 @@ TB_DEV float swing_step(const KParams& P, const float4* hull, EnvRegs& e, const 
     F = F + restoring_force(e);
     e.done = TB_DONE_YES;
   }
-  int bits = substep<TB_ENV_SWING>(P, hull, e.r, e.b, F, T, zero, e.aux[0], e.aux[1] TB_STAMP_PASS);  // :82
+  int bits = substep<TB_ENV_SWING>(P, hull, e.r, e.b, F, T, zero, e.aux[0], e.aux[1], 1.0f TB_STAMP_PASS);  // :82
   e.step_count += 1;                                                                      // :83
   ns = 1;
   float reward = 0.0f;
@@ -230,7 +231,7 @@ TB_DEV float tennis_step(const KParams& P, const float4* hull, EnvRegs& e, const
   vec3 F = mk(a[0] * 10.0f, a[1] * 10.0f, 4.0f * 9.81f);  // :112-115
   vec3 Fb = zero;
   if (e.step_count < 5) Fb = mk(e.aux[0], e.aux[1], e.aux[2]);  // :118-119
-  int bits = substep<TB_ENV_TENNIS>(P, hull, e.r, e.b, F, zero, Fb, 0.0f, 0.0f TB_STAMP_PASS);  // :121
+  int bits = substep<TB_ENV_TENNIS>(P, hull, e.r, e.b, F, zero, Fb, 0.0f, 0.0f, e.aux[3] TB_STAMP_PASS);  // :121
   e.step_count += 1;                                                                // :122
   if (bits & CT_RACKET) cnt[0]++;
   make_obs<TB_ENV_TENNIS>(e, obs);  // :134-136
@@ -414,6 +415,7 @@ __global__ void tb_init_kernel(uint32_t* words, uint8_t* done, int n, int nwords
   if (i >= n) return;
   for (int k = 0; k < nwords; ++k) words[(size_t)k * n + i] = 0u;
   words[(size_t)(TB_W_RQ + 3) * n + i] = __float_as_uint(1.0f);
+  if (nwords == TB_TENNIS_WORDS) words[(size_t)TB_W_TN_SCALE * n + i] = __float_as_uint(1.0f);
   words[(size_t)(nwords - 1) * n + i] = 0xFFFFFFFFu;
   done[i] = TB_DONE_NO;
 }
@@ -474,7 +476,7 @@ void to_kparams(const TbParams* p, KParams* k) {
     k->racket_inertia[i] = p->racket_inertia[i]; k->racket_inv_inertia[i] = p->racket_inv_inertia[i];
     k->racket_com[i] = p->racket_com[i]; k->ground_half[i] = p->ground_half[i]; k->net_half[i] = p->net_half[i];
   }
-  k->racket_half_thick = p->racket_half_thick; k->hull_margin = p->hull_margin; k->hull_bound_radius = p->hull_bound_radius;
+  k->racket_half_thick = p->racket_half_thick; k->hull_margin = p->hull_margin; k->hull_bound_radius = p->hull_bound_radius; k->racket_scale = p->racket_scale;
   k->ball_inv_mass = p->ball_inv_mass; k->ball_inv_inertia = p->ball_inv_inertia; k->ball_radius = p->ball_radius;
   k->magnus_k = p->magnus_k; k->ball_spin_max = p->ball_spin_max;
   k->rest_racket = p->rest_racket; k->rest_court = p->rest_court; k->rest_goal = p->rest_goal;

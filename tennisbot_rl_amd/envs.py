@@ -275,6 +275,6 @@ class TennisbotVecEnv(_VecEnvBase):
 
     def set_racket_scale(self, scale):
         """curriculum hook of train.py:147-149,164-176 (`env.set_racket_scale(s)`): applies
-        to every env at its next reset"""
+        to each env at its own next reset, as in tennisbot_env.py:230-234"""
         self.racket_scale = scale
-        self.batch.set_params(default_params(racket_scale=scale, flags=self.batch.params.flags))
+        self.batch.set_racket_scale(scale)

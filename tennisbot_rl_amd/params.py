@@ -31,14 +31,14 @@ COUNTER_NAMES = ("racket_ball_contact_substeps", "ball_court_terminations", "goa
 
 OBS_DIM = {ENV_SWING: 6, ENV_TENNIS: 12}
 ACT_DIM = {ENV_SWING: 6, ENV_TENNIS: 2}
-STATE_WORDS = {ENV_SWING: 30, ENV_TENNIS: 27}
+STATE_WORDS = {ENV_SWING: 30, ENV_TENNIS: 28}
 
 # SoA row names (include/tb_stepper.h TB_W_*); the last two rows are integers
 _COMMON_ROWS = (["racket_pos"] * 3 + ["racket_quat"] * 4 + ["racket_vel"] * 3 + ["racket_angvel"] * 3
                 + ["ball_pos"] * 3 + ["ball_vel"] * 3 + ["ball_angvel"] * 3)
 STATE_ROWS = {
     ENV_SWING: _COMMON_ROWS + ["goal"] * 2 + ["spawn_pos"] * 3 + ["init_dist", "step_count", "episode"],
-    ENV_TENNIS: _COMMON_ROWS + ["shoot_force"] * 3 + ["step_count", "episode"],
+    ENV_TENNIS: _COMMON_ROWS + ["shoot_force"] * 3 + ["racket_scale", "step_count", "episode"],
 }
 
 _ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "scene.json")
@@ -69,7 +69,7 @@ class TbParams(ctypes.Structure):
         return out
 
     def hull_vertices(self):
-        """CCW (y, z) hull vertices in the COM frame, as the kernels see them."""
+        """CCW (y, z) hull vertices in the COM frame at scale 1, as the kernels see them."""
         e = np.ctypeslib.as_array(self.hull_edges)[: self.n_hull]
         return e[:, :2].astype(np.float64)
 
@@ -144,18 +144,20 @@ def default_params(racket_scale=1.0, flags=F_DEFAULT, scene=None, **overrides):
     for i in range(3):
         p.racket_inertia[i] = float(prim["racket_inertia"][i])
         p.racket_inv_inertia[i] = 1.0 / float(prim["racket_inertia"][i])
-        p.racket_com[i] = float(rk["inertial_origin"][i]) * s
+        p.racket_com[i] = float(rk["inertial_origin"][i])
         p.ground_half[i] = float(prim["ground_half"][i])
         p.net_half[i] = float(prim["net_half"][i])
-    p.racket_half_thick = float(rk["half_thickness"]) * s
+    # geometry is stored at scale 1; `racket_scale` is what the NEXT reset of an env builds its
+    # racket with (tennisbot_env.py:213-215,230-234) and the kernels scale per env on the fly
+    p.racket_half_thick = float(rk["half_thickness"])
     p.racket_scale = s
     com = rk["inertial_origin"]
-    rec = hull_edge_table(rk["hull_yz_ccw"], (com[1], com[2]), s)
+    rec = hull_edge_table(rk["hull_yz_ccw"], (com[1], com[2]), 1.0)
     if len(rec) > TB_MAX_HULL:
         raise ValueError("hull has %d vertices, the kernels take at most %d" % (len(rec), TB_MAX_HULL))
     p.n_hull = len(rec)
     np.ctypeslib.as_array(p.hull_edges)[: len(rec)] = rec
-    # bound radius about the COM, x extent and margin included (slightly rounded up)
+    # bound radius about the COM at scale 1, x extent included (slightly rounded up)
     vmax = float(np.sqrt((rec[:, :2].astype(np.float64) ** 2).sum(1).max() + float(p.racket_half_thick) ** 2))
-    p.hull_bound_radius = (vmax + float(prim["hull_margin"])) * 1.0001
+    p.hull_bound_radius = vmax * 1.0001
     return p

@@ -288,8 +288,11 @@ class BatchedEnv:
 
     def set_racket_scale(self, scale):
         """tennisbot_env.py:213-215: takes effect at the next reset of each env (the reference
-        rebuilds the racket with globalScaling=scale in reset(), :230-234)."""
-        self.set_params(default_params(racket_scale=scale, flags=self.params.flags))
+        rebuilds the racket with globalScaling=scale in reset(), :230-234); every env keeps the
+        scale of its current episode in its own state word."""
+        p = self.params.copy()
+        p.racket_scale = float(scale)
+        self.set_params(p)
 
     # ------------------------------------------------------------------ state save / restore
     def get_state_words(self):

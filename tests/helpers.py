@@ -12,7 +12,7 @@ def make_words(kind, n, **fields):
     Unspecified rows default to 0 (quaternion: identity; init_dist: 1)."""
     names = STATE_ROWS[kind]
     vals = np.zeros((STATE_WORDS[kind], n), np.float64)
-    defaults = {"racket_quat": IDENT_Q, "init_dist": (1.0,)}
+    defaults = {"racket_quat": IDENT_Q, "init_dist": (1.0,), "racket_scale": (1.0,)}
     done = np.asarray(fields.pop("done", np.zeros(n)), np.uint8) * np.ones(n, np.uint8)
     groups = {}
     for i, nm in enumerate(names):

@@ -361,3 +361,30 @@ def test_hipgraph_replay_equals_eager(torch):
         wa, da = a.get_state_words(); wb, db = b.get_state_words()
         assert torch.equal(wa, wb) and torch.equal(da, db) and a.counters() == b.counters()
         a.close(); b.close()
+
+
+def test_curriculum_scale_applies_at_each_envs_own_reset(torch):
+    """train.py:164-176 calls env.set_racket_scale(s) between rollouts; tennisbot_env.py:230-234
+    uses it at the next reset. In a batch every env must switch at ITS next reset."""
+    n = 512
+    env, ref = make_pair(torch, ENV_TENNIS, n)
+    rng = np.random.default_rng(51)
+    same(env.reset().cpu().numpy(), ref.reset(), "reset")
+    scales = {0: 3.0, 300: 2.3, 700: 1.3}
+    for t in range(1100):
+        if t in scales:
+            env.set_racket_scale(scales[t])
+            p = ref.params.copy(); p.racket_scale = scales[t]; ref.set_params(p)
+        a = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+        obs, rew, done = env.step(torch.from_numpy(a).cuda())
+        o2, r2, d2, s2 = ref.step(a)
+        same(done.cpu().numpy(), d2, "scale curriculum done %d" % t)
+        same(obs.cpu().numpy(), o2, "scale curriculum obs %d" % t)
+        same(rew.cpu().numpy(), r2, "scale curriculum reward %d" % t)
+        if t % 100 == 50:
+            compare_state(env, ref, "scale curriculum %d" % t)
+            sc = env.get_state()["racket_scale"][:, 0]
+            assert set(np.unique(sc)) <= {1.0, np.float32(3.0), np.float32(2.3), np.float32(1.3)}
+    st = env.get_state()
+    assert len(np.unique(st["racket_scale"])) >= 2   # envs are at different curriculum stages at the same time
+    env.close()

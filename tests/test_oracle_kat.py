@@ -59,17 +59,27 @@ def test_asset_constants():
     assert per == pytest.approx(1.6369, abs=1e-4)
 
 
-def test_hull_table_is_ccw_convex_and_scaled():
-    for s in (1.0, 2.3):
-        p = default_params(racket_scale=s)
-        v = p.hull_vertices()
-        e = np.roll(v, -1, 0) - v
-        assert np.all(e[:, 0] * np.roll(e, -1, 0)[:, 1] - e[:, 1] * np.roll(e, -1, 0)[:, 0] > 0)  # convex, CCW
-        # COM frame: link z in [0, .697] -> [-0.5, 0.197], scaled
-        assert v[:, 1].min() == pytest.approx(-0.5 * s, abs=1e-6)
-        assert v[:, 1].max() == pytest.approx((0.6971475 - 0.5) * s, abs=1e-6)
-        assert p.racket_half_thick == pytest.approx(0.0145 * s)
-        assert p.racket_com[2] == pytest.approx(0.5 * s)
+def test_hull_table_is_ccw_convex_and_scale_is_per_env():
+    p = default_params()
+    v = p.hull_vertices()
+    e = np.roll(v, -1, 0) - v
+    assert np.all(e[:, 0] * np.roll(e, -1, 0)[:, 1] - e[:, 1] * np.roll(e, -1, 0)[:, 0] > 0)  # convex, CCW
+    # COM frame: link z in [0, .697] -> [-0.5, 0.197]
+    assert v[:, 1].min() == pytest.approx(-0.5, abs=1e-6) and v[:, 1].max() == pytest.approx(0.6971475 - 0.5, abs=1e-6)
+    # geometry is stored at scale 1; racket_scale only says what the next reset builds (tennisbot_env.py:230-234)
+    p3 = default_params(racket_scale=2.3)
+    assert np.array_equal(p3.hull_vertices(), v) and p3.racket_half_thick == p.racket_half_thick and p3.racket_scale == np.float32(2.3)
+    # a scaled racket is the same shape 2.3x larger: face distance and rim distance scale, margin and radius do not
+    hx, m, r = p.racket_half_thick, 0.001, 0.0335
+    hit, d, n, rr = query_racket(p3, (0, 0, 0), (0, 0, 0, 1), (0.2, 0.0, 0.1))
+    assert d == pytest.approx(0.2 - 2.3 * hx - m - r, abs=1e-6) and np.allclose(n, (1, 0, 0))
+    top = (0.6971475 - 0.5) * 2.3
+    hit, d, n, rr = query_racket(p3, (0, 0, 0), (0, 0, 0, 1), (0.0, 0.0, top + 0.05))
+    assert d == pytest.approx(0.05 - m - r, abs=2e-6) and np.allclose(n, (0, 0, 1), atol=1e-6)
+    # a ball that clears the unit racket's rim by 3 cm is inside the scaled one's outline: face contact
+    hit1, d1, _, _ = query_racket(p, (0, 0, 0), (0, 0, 0, 1), (hx + m + r - 1e-4, 0.18, 0.1))
+    hit3, d3, n3, _ = query_racket(p3, (0, 0, 0), (0, 0, 0, 1), (2.3 * hx + m + r - 1e-4, 0.18, 0.1))
+    assert not hit1 and hit3 and d3 == pytest.approx(-1e-4, abs=2e-6) and np.allclose(n3, (1, 0, 0))
 
 
 def test_sphere_vs_racket_face_edge_and_deep():
