@@ -1,0 +1,230 @@
+"""On-device PPO for the batched envs: the caller of the hot path.
+
+Counterpart of what `train_swing.py:80-122` / `train.py:104-151` obtain from
+stable-baselines3 (absent here; the learner itself is out of scope):
+same policy architecture and hyper-parameters, but collection never leaves the GPU --
+observations, actions, rewards and dones live in the rank's `RolloutBuffer`, the step kernel
+writes into it in place, the SwingRacket fast-forward overlaps on side streams, and with
+several ranks the shards are exchanged by ONE all-gather per rollout.
+
+The network is torch.nn (6 -> 32 -> 64 -> 32 -> A, tanh; library GEMMs): it is 10^4 flops
+per env-step, plumbing around the stepper, not a kernel this repository optimises.
+"""
+import math
+import time
+
+import numpy as np
+
+from .params import ACT_DIM, ENV_SWING, OBS_DIM
+from .rollout import RolloutBuffer
+from .stepper import ENV_IDS, BatchedEnv
+
+# hyper-parameters of the reference scripts (and SB3 1.8.0 defaults where they are silent)
+SWING_DEFAULTS = dict(net_arch=(32, 64, 32), ent_coef=0.002, learning_rate=3e-4)   # train_swing.py:80-91
+TENNIS_DEFAULTS = dict(net_arch=(64, 64), ent_coef=0.01, learning_rate=3e-4)        # train.py:4-33,104-110
+COMMON = dict(gamma=0.99, gae_lambda=0.95, clip_range=0.2, vf_coef=0.5, max_grad_norm=0.5, n_epochs=10)
+
+
+def build_actor_critic(obs_dim, act_dim, net_arch=(32, 64, 32)):
+    """SB3 `MlpPolicy` with separate pi / vf towers (net_arch=dict(pi=..., vf=...),
+    train_swing.py:80-82): tanh MLPs, linear action mean, state-independent log_std."""
+    import torch
+    from torch import nn
+
+    class ActorCritic(nn.Module):
+        def __init__(self):
+            super().__init__()
+
+            def tower():
+                layers, d = [], obs_dim
+                for h in net_arch:
+                    layers += [nn.Linear(d, h), nn.Tanh()]
+                    d = h
+                return nn.Sequential(*layers)
+            self.policy_net, self.value_net_body = tower(), tower()
+            self.action_net = nn.Linear(net_arch[-1], act_dim)
+            self.value_net = nn.Linear(net_arch[-1], 1)
+            self.log_std = nn.Parameter(torch.zeros(act_dim))
+            for m in list(self.policy_net) + list(self.value_net_body):  # SB3 ortho_init gains
+                if isinstance(m, nn.Linear):
+                    nn.init.orthogonal_(m.weight, gain=math.sqrt(2)); nn.init.zeros_(m.bias)
+            nn.init.orthogonal_(self.action_net.weight, gain=0.01); nn.init.zeros_(self.action_net.bias)
+            nn.init.orthogonal_(self.value_net.weight, gain=1.0); nn.init.zeros_(self.value_net.bias)
+
+        def forward(self, obs):
+            return self.action_net(self.policy_net(obs)), self.value_net(self.value_net_body(obs)).squeeze(-1)
+
+        def act(self, obs, deterministic=False):
+            mean, value = self(obs)
+            std = self.log_std.exp()
+            a = mean if deterministic else mean + std * torch.randn_like(mean)
+            logp = (-0.5 * ((a - mean) / std) ** 2 - self.log_std - 0.5 * math.log(2 * math.pi)).sum(-1)
+            return a, value, logp
+
+        def evaluate(self, obs, actions):
+            mean, value = self(obs)
+            std = self.log_std.exp()
+            logp = (-0.5 * ((actions - mean) / std) ** 2 - self.log_std - 0.5 * math.log(2 * math.pi)).sum(-1)
+            entropy = (0.5 + 0.5 * math.log(2 * math.pi) + self.log_std).sum()
+            return value, logp, entropy
+
+        def load_sb3_arrays(self, arrays):
+            """weights in SB3's `policy.pth` naming (as exported by tools/export_reference_policy.py)"""
+            sd = {}
+            for k, v in arrays.items():
+                k = k.replace("__", ".")
+                k = k.replace("mlp_extractor.policy_net.", "policy_net.").replace("mlp_extractor.value_net.", "value_net_body.")
+                sd[k] = torch.as_tensor(np.asarray(v))
+            self.load_state_dict(sd)
+            return self
+
+    return ActorCritic()
+
+
+class PPOTrainer:
+    """clipped-surrogate PPO over a BatchedEnv; one process per GPU when distributed"""
+
+    def __init__(self, env_id="SwingRacket-v0", num_envs=4096, n_steps=104, device=None, seed=0, batch_size=None,
+                 pipeline=True, **hp):
+        import torch
+        self.torch = torch
+        kind = ENV_IDS[env_id]
+        d = dict(SWING_DEFAULTS if kind == ENV_SWING else TENNIS_DEFAULTS)
+        d.update(COMMON)
+        d.update(hp)
+        self.hp = d
+        dist = torch.distributed
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.env = BatchedEnv(kind, num_envs, device=device, seed=seed, env_id_base=self.rank * num_envs,
+                              track_terminal_obs=False, pipeline=pipeline and kind == ENV_SWING)
+        self.device = self.env.device
+        self.n_steps, self.num_envs = int(n_steps), int(num_envs)
+        self.buf = RolloutBuffer(kind, self.n_steps, num_envs, self.device).bind(self.env)
+        torch.manual_seed(seed)  # identical initial weights on every rank
+        self.policy = build_actor_critic(OBS_DIM[kind], ACT_DIM[kind], tuple(d["net_arch"])).to(self.device)
+        torch.manual_seed(seed + 1000 * (self.rank + 1))  # ... but rank-local exploration noise
+        self.opt = torch.optim.Adam(self.policy.parameters(), lr=d["learning_rate"], eps=1e-5)
+        self.batch_size = batch_size or min(self.n_steps * num_envs, 65536)
+        self.values = torch.zeros((self.n_steps, num_envs), device=self.device)
+        self.logps = torch.zeros((self.n_steps, num_envs), device=self.device)
+        self.obs_seq = torch.zeros((self.n_steps, num_envs, self.env.obs_dim), device=self.device)
+        self._raw_actions = torch.zeros((self.n_steps, num_envs, self.env.act_dim), device=self.device)
+        self.obs = self.env.reset()
+        self.num_timesteps = 0
+
+    # ------------------------------------------------------------------ collect
+    def collect(self):
+        """n_steps of every env into the rollout buffer, entirely on the device"""
+        t = self.torch
+        buf, env = self.buf, self.env
+        with t.no_grad():
+            for k in range(self.n_steps):
+                a, v, lp = self.policy.act(self.obs)
+                buf.actions[k].copy_(a.clamp(-1.0, 1.0))  # SB3 clips Box actions before env.step
+                self.values[k], self.logps[k] = v, lp
+                # log-prob is of the unclipped sample, as in SB3; the buffer keeps what the env saw
+                self._raw_actions[k] = a
+                buf.step_into(env, k)
+                self.obs_seq[k] = self.obs
+                self.obs = buf.obs[k]
+            env.flush()  # terminal rewards of pipelined fast-forwards are in place from here on
+            _, last_value = self.policy(self.obs)
+        self.num_timesteps += self.n_steps * self.num_envs * self.world
+        return last_value
+
+    def advantages(self, last_value):
+        t, hp = self.torch, self.hp
+        rew, done = self.buf.rewards, self.buf.dones.float()
+        adv = t.zeros_like(rew)
+        gae = t.zeros(self.num_envs, device=self.device)
+        for k in reversed(range(self.n_steps)):
+            nonterminal = 1.0 - done[k]
+            next_value = last_value if k == self.n_steps - 1 else self.values[k + 1]
+            # auto-reset: after a done the next stored value belongs to a new episode -> no bootstrap
+            delta = rew[k] + hp["gamma"] * next_value * nonterminal - self.values[k]
+            gae = delta + hp["gamma"] * hp["gae_lambda"] * nonterminal * gae
+            adv[k] = gae
+        return adv, adv + self.values
+
+    # ------------------------------------------------------------------ update
+    def update(self, adv, returns):
+        t, hp = self.torch, self.hp
+        dist = t.distributed
+        n = self.n_steps * self.num_envs
+        obs = self.obs_seq.reshape(n, -1); act = self._raw_actions.reshape(n, -1)
+        old_lp = self.logps.reshape(n); adv = adv.reshape(n); returns = returns.reshape(n)
+        stats = {}
+        for epoch in range(hp["n_epochs"]):
+            perm = t.randperm(n, device=self.device)
+            for s in range(0, n, self.batch_size):
+                idx = perm[s:s + self.batch_size]
+                a = adv[idx]
+                a = (a - a.mean()) / (a.std() + 1e-8)
+                value, logp, entropy = self.policy.evaluate(obs[idx], act[idx])
+                ratio = (logp - old_lp[idx]).exp()
+                pg = -t.min(a * ratio, a * ratio.clamp(1 - hp["clip_range"], 1 + hp["clip_range"])).mean()
+                vl = ((returns[idx] - value) ** 2).mean()
+                loss = pg + hp["vf_coef"] * vl - hp["ent_coef"] * entropy
+                self.opt.zero_grad(set_to_none=True)
+                loss.backward()
+                if self.world > 1:  # data-parallel: average gradients over ranks (RCCL all-reduce)
+                    for p in self.policy.parameters():
+                        dist.all_reduce(p.grad)
+                        p.grad /= self.world
+                t.nn.utils.clip_grad_norm_(self.policy.parameters(), hp["max_grad_norm"])
+                self.opt.step()
+            stats = {"policy_loss": float(pg.detach()), "value_loss": float(vl.detach()), "entropy": float(entropy.detach())}
+        return stats
+
+    def learn(self, total_timesteps, log=print, gather_rollouts=True):
+        history = []
+        while self.num_timesteps < total_timesteps:
+            t0 = time.perf_counter()
+            last_value = self.collect()
+            if gather_rollouts and self.world > 1:
+                self.buf.all_gather()  # the collect-boundary exchange of SURVEY.md 8e (one collective)
+            self.torch.cuda.synchronize(self.device)
+            t1 = time.perf_counter()
+            adv, returns = self.advantages(last_value)
+            stats = self.update(adv, returns)
+            self.torch.cuda.synchronize(self.device)
+            t2 = time.perf_counter()
+            ep = float(self.buf.dones.sum())
+            stats.update(timesteps=self.num_timesteps, episodes=ep,
+                         mean_episode_reward=float(self.buf.rewards.sum()) / max(ep, 1.0),
+                         collect_steps_per_s=self.n_steps * self.num_envs * self.world / (t1 - t0), update_s=t2 - t1)
+            history.append(stats)
+            if log and self.rank == 0:
+                log("timesteps %10d  episodes %7d  mean episode reward %8.3f  collect %.1f M steps/s  update %.2f s"
+                    % (stats["timesteps"], ep, stats["mean_episode_reward"], stats["collect_steps_per_s"] / 1e6, stats["update_s"]))
+        return history
+
+    def evaluate(self, n_episodes_steps=26, deterministic=False):
+        """EvalCallback counterpart (train_swing.py:111-114, deterministic=False there): mean
+        episode reward over one more rollout of the same envs"""
+        t = self.torch
+        total = t.zeros((), device=self.device)
+        eps = t.zeros((), device=self.device)
+        with t.no_grad():
+            for k in range(n_episodes_steps):
+                a, _, _ = self.policy.act(self.obs, deterministic=deterministic)
+                self.obs, r, d = self.env.step(a.clamp(-1.0, 1.0))
+                self.env.flush()
+                total += r.sum(); eps += d.float().sum()
+        return float(total) / max(float(eps), 1.0)
+
+    def save(self, path):
+        """policy + optimizer + the env batch itself (the reference checkpoints only the learner,
+        train_swing.py:115-117; SURVEY.md section 5 asks for env state as well)"""
+        w, d = self.env.get_state_words()
+        self.torch.save({"policy": self.policy.state_dict(), "optimizer": self.opt.state_dict(), "num_timesteps": self.num_timesteps,
+                         "env_words": w.cpu(), "env_done": d.cpu(), "hp": self.hp}, path)
+
+    def load(self, path):
+        ck = self.torch.load(path, map_location=self.device, weights_only=True)
+        self.policy.load_state_dict(ck["policy"]); self.opt.load_state_dict(ck["optimizer"])
+        self.num_timesteps = int(ck["num_timesteps"])
+        self.env.set_state_words(ck["env_words"].to(self.device), ck["env_done"].to(self.device))
+        self.obs = self.env.observe()
+        return self
