@@ -85,7 +85,7 @@ class PPOTrainer:
     """clipped-surrogate PPO over a BatchedEnv; one process per GPU when distributed"""
 
     def __init__(self, env_id="SwingRacket-v0", num_envs=4096, n_steps=104, device=None, seed=0, batch_size=None,
-                 pipeline=True, **hp):
+                 pipeline=True, graph=True, **hp):
         import torch
         self.torch = torch
         kind = ENV_IDS[env_id]
@@ -110,28 +110,52 @@ class PPOTrainer:
         self.logps = torch.zeros((self.n_steps, num_envs), device=self.device)
         self.obs_seq = torch.zeros((self.n_steps, num_envs, self.env.obs_dim), device=self.device)
         self._raw_actions = torch.zeros((self.n_steps, num_envs, self.env.act_dim), device=self.device)
-        self.obs = self.env.reset()
+        self.last_value = torch.zeros(num_envs, device=self.device)
+        self.obs_in = self.env.reset().clone()  # static input of the (captured) rollout
+        self.use_graph, self._graph = bool(graph), None
         self.num_timesteps = 0
 
     # ------------------------------------------------------------------ collect
-    def collect(self):
-        """n_steps of every env into the rollout buffer, entirely on the device"""
+    def _collect_body(self):
         t = self.torch
         buf, env = self.buf, self.env
+        cur = self.obs_in
+        for k in range(self.n_steps):
+            a, v, lp = self.policy.act(cur)
+            buf.actions[k].copy_(a.clamp(-1.0, 1.0))  # SB3 clips Box actions before env.step
+            self.values[k], self.logps[k] = v, lp
+            # log-prob is of the unclipped sample, as in SB3; the buffer keeps what the env saw
+            self._raw_actions[k] = a
+            buf.step_into(env, k)
+            self.obs_seq[k] = cur
+            cur = buf.obs[k]
+        env.flush()  # terminal rewards of pipelined fast-forwards are in place from here on
+        self.last_value.copy_(self.policy(cur)[1])
+        self.obs_in.copy_(cur)
+
+    def collect(self):
+        """n_steps of every env into the rollout buffer, entirely on the device. With graph=True
+        the whole rollout -- policy forward, sampling, env step, side-stream fast-forwards -- is
+        captured once as a hipGraph and replayed (fixed buffers, in-place parameter updates)."""
+        t = self.torch
         with t.no_grad():
-            for k in range(self.n_steps):
-                a, v, lp = self.policy.act(self.obs)
-                buf.actions[k].copy_(a.clamp(-1.0, 1.0))  # SB3 clips Box actions before env.step
-                self.values[k], self.logps[k] = v, lp
-                # log-prob is of the unclipped sample, as in SB3; the buffer keeps what the env saw
-                self._raw_actions[k] = a
-                buf.step_into(env, k)
-                self.obs_seq[k] = self.obs
-                self.obs = buf.obs[k]
-            env.flush()  # terminal rewards of pipelined fast-forwards are in place from here on
-            _, last_value = self.policy(self.obs)
+            if self.use_graph and self._graph is None:
+                try:
+                    self._collect_body()  # warm-up on the real stream (allocator, lazy inits)
+                    t.cuda.synchronize(self.device)
+                    self.num_timesteps += self.n_steps * self.num_envs * self.world
+                    self._graph = self.env.capture(self._collect_body)
+                    return self.last_value
+                except Exception as exc:  # noqa: BLE001 - any capture problem means: run eagerly
+                    print("hipGraph capture of the rollout failed (%s); collecting eagerly" % exc)
+                    self.use_graph = False
+                    return self.last_value
+            if self._graph is not None:
+                self._graph.replay()
+            else:
+                self._collect_body()
         self.num_timesteps += self.n_steps * self.num_envs * self.world
-        return last_value
+        return self.last_value
 
     def advantages(self, last_value):
         t, hp = self.torch, self.hp
@@ -208,9 +232,10 @@ class PPOTrainer:
         eps = t.zeros((), device=self.device)
         with t.no_grad():
             for k in range(n_episodes_steps):
-                a, _, _ = self.policy.act(self.obs, deterministic=deterministic)
-                self.obs, r, d = self.env.step(a.clamp(-1.0, 1.0))
+                a, _, _ = self.policy.act(self.obs_in, deterministic=deterministic)
+                obs, r, d = self.env.step(a.clamp(-1.0, 1.0))
                 self.env.flush()
+                self.obs_in.copy_(obs)
                 total += r.sum(); eps += d.float().sum()
         return float(total) / max(float(eps), 1.0)
 
@@ -226,5 +251,5 @@ class PPOTrainer:
         self.policy.load_state_dict(ck["policy"]); self.opt.load_state_dict(ck["optimizer"])
         self.num_timesteps = int(ck["num_timesteps"])
         self.env.set_state_words(ck["env_words"].to(self.device), ck["env_done"].to(self.device))
-        self.obs = self.env.observe()
+        self.obs_in.copy_(self.env.observe())
         return self
