@@ -148,6 +148,11 @@ def cpu_baseline(kind_name, n_envs, seconds, seed):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, int(os.environ.get("TB_CPU_THREADS", "16"))))
     out = {}
+    try:  # the PyBullet path is the preferred baseline where it exists
+        import pybullet  # noqa: F401
+        out["pybullet"] = "importable, but the reference's asset files do not travel to this host: not run (tools/pybullet_crosscheck.py is the harness)"
+    except ImportError:
+        out["pybullet"] = "not importable on this host: CPU baseline is the float32 restatement (kind \"port\")"
     for label, threads in (("1core", 1), ("allcores", cores)):
         b = OracleBatch(default_params(flags=F_DEFAULT | F_AUTO_RESET), kind, n_envs, seed=seed, precision="f32", threads=threads)
         b.reset()
@@ -268,7 +273,7 @@ def main():
             "value": best["steps_per_s"], "unit": "env steps/s", "cores": best["threads"], "kind": "port",
             "sample": "float32 CPU oracle (oracle/tb_oracle.c, OpenMP over envs), %d envs x %d agent steps (whole 26-step episodes incl. fast-forward), %.1f s"
                       % (N, best["agent_steps"], best["seconds"]),
-            "value_1core": cb["1core"]["steps_per_s"], "substeps_per_s": best["substeps_per_s"],
+            "value_1core": cb["1core"]["steps_per_s"], "substeps_per_s": best["substeps_per_s"], "pybullet": cb["pybullet"],
             "substeps_per_s_1core": cb["1core"]["substeps_per_s"],
         }
     if dist_on:

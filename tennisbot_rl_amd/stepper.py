@@ -334,6 +334,18 @@ class BatchedEnv:
         out["done"] = d.cpu().numpy()
         return out
 
+    def save_state(self, path):
+        """on-disk checkpoint of the env batch (npz): raw SoA words + done bytes + identity"""
+        w, d = self.get_state_words()
+        np.savez_compressed(path, words=w.cpu().numpy(), done=d.cpu().numpy(), env_kind=self.kind, num_envs=self.num_envs,
+                            seed=self.seed, env_id_base=self.env_id_base, rows=np.array(STATE_ROWS[self.kind]))
+
+    def load_state(self, path):
+        z = np.load(path, allow_pickle=False)
+        if int(z["env_kind"]) != self.kind or int(z["num_envs"]) != self.num_envs:
+            raise ValueError("checkpoint is for env kind %d x %d envs" % (int(z["env_kind"]), int(z["num_envs"])))
+        self.set_state_words(z["words"], z["done"])
+
     def counters(self):
         c = (ctypes.c_uint64 * N_COUNTERS)()
         _check(self.L, self.L.tb_counters(self._h, c, self._stream()), "tb_counters")
