@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work per baseline leg (1 core, all cores)")
     ap.add_argument("--sweep", action="store_true", help="also time N = 4096 .. 4M envs on one GPU (extra JSON key)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--gather-chunks", type=int, default=1, help="N > 1: ship the rollout in this many step-chunks overlapped with the rollout's own compute (1 = ONE all-gather at the collect boundary)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of replaying one captured hipGraph")
     ap.add_argument("--no-pipeline", action="store_true", help="run the SwingRacket fast-forward inside the step kernel instead of a side stream")
     return ap.parse_args()
@@ -84,50 +85,61 @@ def fill_actions(buf_actions, seed, torch):
         buf_actions[t0:t0 + n].copy_(a[:n])
 
 
-GRAPH_STATE = {"used": True}
+GRAPH_STATE = {"used": True, "chunks": 1}
 
 
-def time_steps(env, buf, steps, warmup, torch, dist_on, tail_gather=True, graph=False):
+def time_steps(env, buf, steps, warmup, torch, dist_on, tail_gather=True, graph=False, gather_chunks=1):
     """W untimed + K timed steps; returns (wall seconds, HIP-event seconds of the K launches).
-    graph=True: the K timed steps are captured once into a hipGraph (outside the timed region)
-    and the timed region replays it -- same kernels, same buffers, no per-step host work."""
+    graph=True: the K timed steps are captured once into hipGraphs (outside the timed region) and
+    the timed region replays them -- same kernels, same buffers, no per-step host work.
+    gather_chunks=C > 1 (multi-rank): the rollout is exchanged in C step-chunks, each all-gather
+    issued asynchronously as soon as its steps are enqueued, instead of one collective at the end."""
     dev = env.device
     T = buf.T
     for t in range(warmup):
         buf.step_into(env, t % T)
-    g = None
+    chunks = gather_chunks if (dist_on and tail_gather and gather_chunks > 1 and steps == T and steps % gather_chunks == 0) else 1
+    seg = steps // chunks
+    graphs = None
     if graph:
-        def body():
-            for t in range(steps):
-                buf.step_into(env, t % T)
-        # capture does not execute anything, but the library's host-side episode phase advances as
-        # if it did; a failed capture must not leave it (or the device state) ahead, so the phase is
-        # re-armed by restoring the state the warm-up left behind
         try:
-            g = env.capture(body)
+            graphs = []
+            for c in range(chunks):
+                def body(c=c):
+                    for t in range(c * seg, (c + 1) * seg):
+                        buf.step_into(env, t % T)
+                graphs.append(env.capture(body))
         except Exception as exc:  # fall back to per-step launches and say so
             print("hipGraph capture failed (%s: %s); launching every step from the host" % (type(exc).__name__, exc), file=sys.stderr)
-            g = None
+            graphs = None
             GRAPH_STATE["used"] = False
+    if chunks > 1:
+        buf.begin_gather(chunks)
     if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize(dev)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(torch.cuda.current_stream(dev))  # the stream the step kernel is launched on
-    if g is not None:
-        g.replay()
-    else:
-        for t in range(steps):
-            buf.step_into(env, t % T)
-        env.flush()  # pipelined fast-forwards: every step's outputs are complete from here on
+    for c in range(chunks):
+        if graphs is not None:
+            graphs[c].replay()
+        else:
+            for t in range(c * seg, (c + 1) * seg):
+                buf.step_into(env, t % T)
+            env.flush()  # pipelined fast-forwards: every step's outputs are complete from here on
+        if chunks > 1:
+            buf.gather_chunk(c)
     ev1.record(torch.cuda.current_stream(dev))
-    if tail_gather:
+    if chunks > 1:
+        buf.finish_gather()
+    elif tail_gather:
         buf.all_gather()  # collect boundary: one collective (no-op for a single rank)
     if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
+    GRAPH_STATE["chunks"] = chunks
     return wall, ev0.elapsed_time(ev1) * 1e-3
 
 
@@ -184,11 +196,19 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("--gpus %d needs the torch.distributed launcher (one process per GPU)" % args.gpus)
+    # TB_BENCH_REHEARSAL=1: several ranks share cuda:0 over gloo -- a one-GPU rehearsal of the
+    # multi-rank control flow (the numbers mean nothing; RCCL refuses two ranks on one device)
+    rehearsal = os.environ.get("TB_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group(backend="nccl", device_id=dev)
+        if rehearsal:
+            torch.distributed.init_process_group(backend="gloo")
+        else:
+            torch.distributed.init_process_group(backend="nccl", device_id=dev)
 
     kind = ENV_SWING if args.env == "swing" else ENV_TENNIS
     flags = F_NET if args.contact_off else F_DEFAULT
@@ -203,7 +223,11 @@ def main():
     env.reset()
     env.counters_reset()
     use_graph = not args.no_graph
-    wall, ev_s = time_steps(env, buf, args.steps, args.warmup, torch, dist_on, graph=use_graph)
+    wall, ev_s = time_steps(env, buf, args.steps, args.warmup, torch, dist_on, graph=use_graph, gather_chunks=args.gather_chunks)
+    gather_note = ""
+    if dist_on:
+        gather_note = (", 1 RCCL all-gather of rollouts at the collect boundary" if GRAPH_STATE["chunks"] == 1 else
+                       ", rollouts all-gathered (RCCL) in %d step-chunks overlapped with the rollout" % GRAPH_STATE["chunks"])
     c = env.counters()
 
     wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
@@ -235,7 +259,7 @@ def main():
                 "SwingRacket-v0" if args.env == "swing" else "Tennisbot-v0", N,
                 "racket<->ball contact off (configs[1] bench mode)" if args.contact_off else "full contact semantics",
                 T_buf, ", fast-forward pipelined on side streams" if pipeline else "", ", K steps replayed as one hipGraph" if (use_graph and GRAPH_STATE["used"]) else "",
-                ", 1 RCCL all-gather of rollouts at the collect boundary" if dist_on else ""),
+                gather_note),
                 "envs_per_gpu": N, "global_envs": world * N, "parallelism": "env-sharded x%d" % world},
             "substeps_per_s": timed_substeps / wall_max,
             "substeps_per_agent_step": timed_substeps / (world * N * args.steps),

@@ -7,8 +7,11 @@ boundary -- SB3's `collect_rollouts` end, the counterpart of the hook the refere
 in train.py:164 -- the ranks exchange their shards with ONE all-gather (RCCL over xGMI:
 `torch.distributed` backend "nccl" on ROCm; "gloo" in the CPU tests).
 
-Packed layout per rank (bytes): obs f32 [T][N][O] | act f32 [T][N][A] | rew f32 [T][N] | done u8 [T][N],
-padded to 16 B. n_steps defaults to the reference's 1100 (train_swing.py:49-50).
+Packed layout per rank: T per-step records, each `obs f32 [N][O] | act f32 [N][A] | rew f32 [N] |
+done u8 [N]` (every part padded to 16 B), so any range of steps is one contiguous byte range:
+the whole buffer goes out in ONE all-gather, and `all_gather_chunked` can instead ship it in a
+few step-chunks on RCCL's stream while later steps are still being computed. n_steps defaults
+to the reference's 1100 (train_swing.py:49-50).
 """
 import numpy as np
 
@@ -25,21 +28,25 @@ class RolloutBuffer:
         self.torch = torch
         self.T, self.N = int(n_steps), int(num_envs)
         self.O, self.A = OBS_DIM[env_kind], ACT_DIM[env_kind]
-        T, N, O, A = self.T, self.N, self.O, self.A
-        sizes = [T * N * O * 4, T * N * A * 4, T * N * 4, T * N]
-        self.offsets = np.cumsum([0] + [_align(s) for s in sizes])
-        self.nbytes = int(self.offsets[-1])
+        N, O, A = self.N, self.O, self.A
+        parts = [N * O * 4, N * A * 4, N * 4, N]
+        self.part_offsets = np.cumsum([0] + [_align(x) for x in parts])  # within one step record
+        self.record = int(self.part_offsets[-1])
+        self.nbytes = self.record * self.T
         self.device = torch.device(device)
         self.raw = torch.zeros(self.nbytes, dtype=torch.uint8, device=self.device)
-        self.obs, self.actions, self.rewards, self.dones = self.views(self.raw)
+        self.obs, self.actions, self.rewards, self.dones = self.views(self.raw, self.T)
 
-    def views(self, raw):
-        """typed views into one packed shard"""
-        t, (T, N, O, A), off = self.torch, (self.T, self.N, self.O, self.A), self.offsets
-        obs = raw[off[0]: off[0] + T * N * O * 4].view(t.float32).view(T, N, O)
-        act = raw[off[1]: off[1] + T * N * A * 4].view(t.float32).view(T, N, A)
-        rew = raw[off[2]: off[2] + T * N * 4].view(t.float32).view(T, N)
-        done = raw[off[3]: off[3] + T * N].view(T, N)
+    def views(self, raw, n_steps):
+        """typed [n_steps, N, ...] views into a packed run of step records (strided over steps,
+        contiguous within a step)"""
+        t, (N, O, A), off, rec = self.torch, (self.N, self.O, self.A), self.part_offsets, self.record
+        f = raw.view(t.float32)
+        fo, bo = f.storage_offset(), raw.storage_offset()  # as_strided offsets are absolute in the storage
+        obs = f.as_strided((n_steps, N, O), (rec // 4, O, 1), fo + int(off[0]) // 4)
+        act = f.as_strided((n_steps, N, A), (rec // 4, A, 1), fo + int(off[1]) // 4)
+        rew = f.as_strided((n_steps, N), (rec // 4, 1), fo + int(off[2]) // 4)
+        done = raw.as_strided((n_steps, N), (rec, 1), bo + int(off[3]))
         return obs, act, rew, done
 
     def bind(self, env):
@@ -50,11 +57,9 @@ class RolloutBuffer:
         env._check_tensor(self.obs[0], (self.N, self.O), t.float32, "rollout obs[t]")
         env._check_tensor(self.rewards[0], (self.N,), t.float32, "rollout rewards[t]")
         env._check_tensor(self.dones[0], (self.N,), t.uint8, "rollout dones[t]")
-        if self.N * self.O * 4 % env._row_align or self.N * self.A * 4 % env._row_align:
-            raise ValueError("rollout rows are not %d-byte aligned for this batch size" % env._row_align)
-        N, O, A = self.N, self.O, self.A
-        self._ptrs = [(self.actions.data_ptr() + k * N * A * 4, self.obs.data_ptr() + k * N * O * 4,
-                       self.rewards.data_ptr() + k * N * 4, self.dones.data_ptr() + k * N) for k in range(self.T)]
+        base, off, rec = self.raw.data_ptr(), [int(x) for x in self.part_offsets], self.record
+        self._ptrs = [(base + k * rec + off[1], base + k * rec + off[0], base + k * rec + off[2], base + k * rec + off[3])
+                      for k in range(self.T)]
         self._bound = env
         return self
 
@@ -65,17 +70,58 @@ class RolloutBuffer:
             return None
         return env.step(self.actions[t], out=(self.obs[t], self.rewards[t], self.dones[t]))
 
-    def all_gather(self, group=None):
-        """one collective: returns a list of (obs, act, rew, done) views, one per rank, in
-        rank order (= global env id order). Single process: returns the local shard."""
+    def _world(self, group):
         dist = self.torch.distributed
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1
+        return dist.get_world_size(group)
+
+    def all_gather(self, group=None):
+        """ONE collective for the whole rollout: returns a list of (obs, act, rew, done) views,
+        one per rank, in rank order (= global env id order). Single process: the local shard."""
+        world = self._world(group)
+        if world == 1:
             return [(self.obs, self.actions, self.rewards, self.dones)]
-        world = dist.get_world_size(group)
+        t = self.torch
         if getattr(self, "_gathered", None) is None or self._gathered.numel() != world * self.nbytes:
-            self._gathered = self.torch.empty(world * self.nbytes, dtype=self.torch.uint8, device=self.device)
-        dist.all_gather_into_tensor(self._gathered, self.raw, group=group)
-        return [self.views(self._gathered[r * self.nbytes: (r + 1) * self.nbytes]) for r in range(world)]
+            self._gathered = t.empty(world * self.nbytes, dtype=t.uint8, device=self.device)
+        t.distributed.all_gather_into_tensor(self._gathered, self.raw, group=group)
+        return [self.views(self._gathered[r * self.nbytes: (r + 1) * self.nbytes], self.T) for r in range(world)]
+
+    # -- overlapped variant: the same bytes in a few step-chunks, each issued as soon as its steps
+    #    are enqueued (async on the collective's own stream), joined by finish_gather()
+    def begin_gather(self, n_chunks, group=None):
+        if self.T % n_chunks:
+            raise ValueError("n_steps %d is not divisible into %d chunks" % (self.T, n_chunks))
+        world, t = self._world(group), self.torch
+        self._chunks, self._chunk_steps, self._works, self._group = int(n_chunks), self.T // int(n_chunks), [], group
+        cb = self._chunk_steps * self.record
+        if world > 1 and (getattr(self, "_gath_chunks", None) is None or len(self._gath_chunks) != n_chunks
+                          or self._gath_chunks[0].numel() != world * cb):
+            self._gath_chunks = [t.empty(world * cb, dtype=t.uint8, device=self.device) for _ in range(n_chunks)]
+
+    def gather_chunk(self, c):
+        """call after the steps [c*S, (c+1)*S) have been enqueued on the current stream"""
+        world = self._world(self._group)
+        if world == 1:
+            return
+        cb = self._chunk_steps * self.record
+        src = self.raw[c * cb:(c + 1) * cb]
+        self._works.append(self.torch.distributed.all_gather_into_tensor(self._gath_chunks[c], src, group=self._group, async_op=True))
+
+    def finish_gather(self):
+        """wait for every chunk; returns per-rank (obs, act, rew, done) over all T steps"""
+        world, t = self._world(self._group), self.torch
+        if world == 1:
+            return [(self.obs, self.actions, self.rewards, self.dones)]
+        for w in self._works:
+            w.wait()
+        cb = self._chunk_steps * self.record
+        out = []
+        for r in range(world):
+            parts = [self.views(g[r * cb:(r + 1) * cb], self._chunk_steps) for g in self._gath_chunks]
+            out.append(tuple(t.cat([p[k] for p in parts], dim=0) for k in range(4)))
+        return out
 
     def concatenated(self, shards):
         """[T, world*N, ...] tensors in global env id order (what a learner consumes)"""

@@ -48,6 +48,12 @@ def _worker(rank, port, kind, out_dir):
     shards = buf.all_gather()
     assert len(shards) == WORLD
     obs, act, rew, done = buf.concatenated(shards)
+    # the chunked / overlapped variant moves the same bytes
+    buf.begin_gather(3)
+    for c in range(3):
+        buf.gather_chunk(c)
+    chunked = buf.concatenated(buf.finish_gather())
+    assert all(torch.equal(a, b) for a, b in zip(chunked, (obs, act, rew, done)))
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), obs=obs.numpy(), act=act.numpy(), rew=rew.numpy(), done=done.numpy())
     dist.barrier()
     dist.destroy_process_group()
@@ -81,10 +87,15 @@ def test_rollout_buffer_layout_and_reference_message_size():
     from tennisbot_rl_amd.rollout import RolloutBuffer
     b = RolloutBuffer(ENV_SWING, 7, 5, "cpu")
     assert b.obs.shape == (7, 5, 6) and b.actions.shape == (7, 5, 6) and b.rewards.shape == (7, 5) and b.dones.shape == (7, 5)
-    assert all(int(o) % 16 == 0 for o in b.offsets)
+    assert all(int(o) % 16 == 0 for o in b.part_offsets) and b.nbytes == 7 * b.record
+    assert b.obs[3].is_contiguous() and b.actions[3].is_contiguous() and b.dones[3].is_contiguous()
     b.obs.fill_(1.5); b.actions.fill_(-2.0); b.rewards.fill_(3.0); b.dones.fill_(1)
-    o, a, r, d = b.views(b.raw.clone())
+    o, a, r, d = b.views(b.raw.clone(), 7)
     assert float(o.min()) == 1.5 and float(a.max()) == -2.0 and float(r.mean()) == 3.0 and int(d.sum()) == 35
+    # steps 2..4 are one contiguous byte range holding exactly those steps
+    o2 = b.views(b.raw[2 * b.record: 5 * b.record], 3)[0]
+    b.obs[2:5].fill_(9.0)
+    assert float(o2.min()) == 9.0 and float(b.obs[5].max()) == 1.5
     sizes = lambda T, N, O, A: T * N * (O + A + 1) * 4 + T * N  # noqa: E731
     assert abs(sizes(1100, 4096, 6, 6) - 238.8e6) / 238.8e6 < 0.01
     t = RolloutBuffer(ENV_TENNIS, 3, 4, "cpu")
