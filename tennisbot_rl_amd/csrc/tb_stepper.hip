@@ -27,6 +27,8 @@ namespace {
 
 // ------------------------------------------------------------------------------------------
 // kernel arguments
+#define TB_COUNTER_SHARDS 64
+
 struct KArgs {
   KParams P;
   uint32_t* words;        // [W][n]
@@ -39,7 +41,7 @@ struct KArgs {
   float* term_obs;        // [n][O] or null (T == 1 only)
   int32_t* substeps;      // [n] or null
   const uint8_t* mask;    // reset kernel: [n] or null
-  unsigned long long* counters;  // [TB_N_COUNTERS]
+  unsigned long long* counters;  // [TB_COUNTER_SHARDS][TB_N_COUNTERS]
   unsigned long long seed, env_id_base;
   int n, T;
   // pipelined fast-forward (tb_set_pipeline): a step that starts a SwingRacket fast-forward parks
@@ -180,44 +182,48 @@ TB_DEV vec3 restoring_force(const EnvRegs& e) {  // swingracket_env.py:135-141
   return mk(-50.0f * (e.r.p.x - e.aux[2]), -2.0f * (e.r.p.y - e.aux[3]), -2.0f * ((e.r.p.z - e.aux[4]) - 4.0f));
 }
 
-// the fast-forward of swingracket_env.py:105-141: substeps until the ball touches the court or
-// the goal, or step_count > 800. No agent input enters it.
-TB_DEV float swing_fast_forward(const KParams& P, const float4* hull, EnvRegs& e, int& ns, uint32_t* cnt TB_STAMP_ARG) {
+// swingracket_env.py:75-145 as ONE loop around ONE substep call site (the substep is the bulk of
+// the kernel's code and registers; two inlined copies cost occupancy):
+//   iteration 0      the agent's substep (:76-83), contact bonus while step_count < 25 (:98-101)
+//   iterations 1..   the fast-forward of :105-141 -- substeps until the ball touches the court or
+//                    the goal or step_count > 800; no agent input enters it. The first of them runs
+//                    with no force at all (the previous substep cleared the accumulators), the
+//                    later ones with the restoring force of :135-141.
+// `in_ff` = start inside the fast-forward (tb_ff_kernel resuming a parked env).
+// `defer`  = leave the fast-forward to tb_ff_kernel: sets `parked` instead of looping.
+TB_DEV float swing_loop(const KParams& P, const float4* hull, EnvRegs& e, vec3 F, vec3 T, bool in_ff, bool defer, bool& parked,
+                        int& ns, uint32_t* cnt TB_STAMP_ARG) {
   const vec3 zero = mk(0.0f, 0.0f, 0.0f);
   float reward = 0.0f;
-  vec3 Fp = zero;  // the substep before the loop cleared the accumulated forces
-  while (!e.done) {  // :106 -- per-lane loop; the wave leaves when its last lane is done
-    int bits = substep<TB_ENV_SWING>(P, hull, e.r, e.b, Fp, zero, zero, e.aux[0], e.aux[1], 1.0f TB_STAMP_PASS);  // :107
-    e.step_count += 1; ns++;
+  for (;;) {
+    int bits = substep<TB_ENV_SWING>(P, hull, e.r, e.b, F, T, zero, e.aux[0], e.aux[1], 1.0f TB_STAMP_PASS);  // :82 / :107
+    e.step_count += 1; ns++;                                                                                   // :83 / :108
     if (bits & CT_RACKET) cnt[0]++;
-    if (bits & (CT_GROUND | CT_NET)) { e.done = TB_DONE_PENDING_FORCE; reward += moved_dist_to_goal(e); cnt[1]++; }  // :111-114
-    if (bits & CT_GOAL) { reward += moved_dist_to_goal(e); reward += 50.0f; e.done = TB_DONE_PENDING_FORCE; cnt[2]++; }  // :119-123
-    if (e.step_count > 800) { if (!e.done) cnt[3]++; e.done = TB_DONE_PENDING_FORCE; }  // :127-128
-    Fp = restoring_force(e);  // :135-141
+    if (!in_ff) {
+      if (e.step_count < 25 && (bits & CT_RACKET)) reward += 2.0f;  // :98-101
+      if (!(e.step_count > 25) || e.done) break;                    // :105-106
+      if (defer) { parked = true; break; }                          // reward so far is 0: the bonus window closed at step 25
+      in_ff = true; F = zero; T = zero;                             // accumulators were cleared by the substep above
+    } else {
+      if (bits & (CT_GROUND | CT_NET)) { e.done = TB_DONE_PENDING_FORCE; reward += moved_dist_to_goal(e); cnt[1]++; }  // :111-114
+      if (bits & CT_GOAL) { reward += moved_dist_to_goal(e); reward += 50.0f; e.done = TB_DONE_PENDING_FORCE; cnt[2]++; }  // :119-123
+      if (e.step_count > 800) { if (!e.done) cnt[3]++; e.done = TB_DONE_PENDING_FORCE; }  // :127-128
+      if (e.done) break;
+      F = restoring_force(e);  // :135-141 (also issued when done just became true; it then waits in the accumulator: TB_DONE_PENDING_FORCE)
+    }
   }
   return reward;
 }
 
-// swingracket_env.py:75-145. `defer`: leave the fast-forward to tb_ff_kernel (sets `parked`).
 TB_DEV float swing_step(const KParams& P, const float4* hull, EnvRegs& e, const float* a, int& ns, uint32_t* cnt, bool defer, bool& parked TB_STAMP_ARG) {
   vec3 F = mk(a[0] * 400.0f, a[1] * 400.0f, FMA(a[2], 400.0f, 4.0f * 9.81f));  // :76-77
   vec3 T = mk(a[3] * 5.0f, a[4] * 5.0f, a[5] * 5.0f);                          // :78
-  const vec3 zero = mk(0.0f, 0.0f, 0.0f);
   if (e.done == TB_DONE_PENDING_FORCE) {  // the force of :135-141 is still in the accumulator
     F = F + restoring_force(e);
     e.done = TB_DONE_YES;
   }
-  int bits = substep<TB_ENV_SWING>(P, hull, e.r, e.b, F, T, zero, e.aux[0], e.aux[1], 1.0f TB_STAMP_PASS);  // :82
-  e.step_count += 1;                                                                      // :83
-  ns = 1;
-  float reward = 0.0f;
-  if (bits & CT_RACKET) cnt[0]++;
-  if (e.step_count < 25 && (bits & CT_RACKET)) reward += 2.0f;  // :98-101
-  if (e.step_count > 25) {                                      // :105
-    if (defer && !e.done) parked = true;  // reward so far is 0: the bonus window closed at step 25
-    else reward += swing_fast_forward(P, hull, e, ns, cnt TB_STAMP_PASS);
-  }
-  return reward;
+  ns = 0;
+  return swing_loop(P, hull, e, F, T, false, defer, parked, ns, cnt TB_STAMP_PASS);
 }
 
 // tennisbot_env.py:90-102
@@ -254,8 +260,12 @@ TB_DEV float tennis_step(const KParams& P, const float4* hull, EnvRegs& e, const
 
 TB_DEV bool finite3(vec3 v) { return isfinite(v.x) && isfinite(v.y) && isfinite(v.z); }
 
-// wave-level sum of per-lane event counts; one atomic per wave and counter that is non-zero
+// wave-level sum of per-lane event counts; one atomic per wave and counter that is non-zero, into
+// one of TB_COUNTER_SHARDS copies (same-address atomics serialise at ~12 ns each: with one copy a
+// 1 M-env launch, 16 K waves, spent 200 us queueing on the substep counter alone). The mandatory
+// first substep of a step is not counted per wave: one lane of the launch adds n_envs * T.
 TB_DEV void flush_counters(unsigned long long* counters, const uint32_t* cnt) {
+  counters += (size_t)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (TB_COUNTER_SHARDS - 1)) * TB_N_COUNTERS;
 #pragma unroll
   for (int k = 0; k < TB_N_COUNTERS; ++k) {
     uint32_t v = cnt[k];
@@ -327,7 +337,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
       } else {
         rew = tennis_step(A.P, s_hull, e, a, o, d, cnt TB_STAMP_PASS);
       }
-      cnt[6] += (uint32_t)ns;
+      cnt[6] += (uint32_t)(ns - 1);  // substeps beyond the first of each agent step
       ns_total += ns;
       if (!(finite3(e.r.p) && finite3(e.r.v) && finite3(e.r.w) && finite3(e.b.p) && finite3(e.b.v) && finite3(e.b.w) &&
             isfinite(e.r.q.x) && isfinite(e.r.q.y) && isfinite(e.r.q.z) && isfinite(e.r.q.w)))
@@ -348,6 +358,8 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
     store_env<KIND>(A.words, A.done_state, A.n, i, e, any_reset);
   }
   flush_counters(A.counters, cnt);
+  if (blockIdx.x == 0 && threadIdx.x == 0)  // the first substep of every env in every agent step of this launch
+    atomicAdd(&A.counters[6], (unsigned long long)A.n * (unsigned long long)A.T);
 #ifdef TB_DIAG_STAMPS
   if ((threadIdx.x & 63) == 0) {  // per-wave sums (lane 0 carries the wave's scalar clock reads)
     for (int k = 0; k < 6; ++k) atomicAdd(&g_diag_cycles[k], (unsigned long long)st.acc[k]);
@@ -377,7 +389,9 @@ __global__ void __launch_bounds__(256) tb_ff_kernel(KArgs A) {
   if (live) {
     e.done = TB_DONE_NO;  // the slot's byte is the parking flag, the parked env was not done
     int ns = 1;           // the step kernel ran the first substep of this agent step
-    float rew = swing_fast_forward(A.P, s_hull, e, ns, cnt TB_STAMP_PASS);
+    bool parked = false;
+    const vec3 zero = mk(0.0f, 0.0f, 0.0f);
+    float rew = swing_loop(A.P, s_hull, e, zero, zero, true, false, parked, ns, cnt TB_STAMP_PASS);
     cnt[6] += (uint32_t)(ns - 1);
     if (!(finite3(e.r.p) && finite3(e.r.v) && finite3(e.r.w) && finite3(e.b.p) && finite3(e.b.v) && finite3(e.b.w) &&
           isfinite(e.r.q.x) && isfinite(e.r.q.y) && isfinite(e.r.q.z) && isfinite(e.r.q.w)))
@@ -525,7 +539,7 @@ struct TbHandle {
   uint8_t* d_done;
   float4* d_hull;
   float4* h_hull;  // pinned staging copy of the outline table
-  unsigned long long* d_counters;
+  unsigned long long* d_counters;     // [TB_COUNTER_SHARDS][TB_N_COUNTERS]
   // pipelined fast-forward
   int pipeline;            // enabled by tb_set_pipeline
   int phase, phase_valid;  // agent steps since the last full reset (SwingRacket episodes are exactly 26 steps)
@@ -638,8 +652,8 @@ int tb_create(const TbParams* params, int env_kind, int n_envs, int device, uint
   CREATE_TRY(hipMalloc((void**)&h->d_done, (size_t)n_envs));
   CREATE_TRY(hipMalloc((void**)&h->d_hull, sizeof(float) * TB_HULL_REC * TB_MAX_HULL));
   CREATE_TRY(hipHostMalloc((void**)&h->h_hull, sizeof(float) * TB_HULL_REC * TB_MAX_HULL, hipHostMallocDefault));
-  CREATE_TRY(hipMalloc((void**)&h->d_counters, sizeof(unsigned long long) * TB_N_COUNTERS));
-  CREATE_TRY(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * TB_N_COUNTERS, 0));
+  CREATE_TRY(hipMalloc((void**)&h->d_counters, sizeof(unsigned long long) * TB_N_COUNTERS * TB_COUNTER_SHARDS));
+  CREATE_TRY(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * TB_N_COUNTERS * TB_COUNTER_SHARDS, 0));
   hipLaunchKernelGGL(tb_init_kernel, dim3((unsigned)((n_envs + 255) / 256)), dim3(256), 0, 0, h->d_words, h->d_done, n_envs, nw);
   CREATE_TRY(hipGetLastError());
   if (int rc = upload_hull(h, 0)) { tb_destroy(h); return rc; }
@@ -786,8 +800,14 @@ int tb_counters(TbHandle* h, uint64_t* out, void* stream) {
   if (!h || !out) return fail(TB_E_INVAL, "tb_counters: null argument");
   DeviceGuard g(h->device);
   if (int rc = wait_side(h, (hipStream_t)stream)) return rc;
-  HIP_TRY(hipMemcpyAsync(out, h->d_counters, sizeof(uint64_t) * TB_N_COUNTERS, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  static_assert(sizeof(uint64_t) == sizeof(unsigned long long), "counter width");
+  uint64_t shards[TB_COUNTER_SHARDS][TB_N_COUNTERS];
+  HIP_TRY(hipMemcpyAsync(shards, h->d_counters, sizeof shards, hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  for (int k = 0; k < TB_N_COUNTERS; ++k) {
+    out[k] = 0;
+    for (int sh = 0; sh < TB_COUNTER_SHARDS; ++sh) out[k] += shards[sh][k];
+  }
   return TB_OK;
 }
 
@@ -812,7 +832,7 @@ int tb_diag_read_stamps(unsigned long long* out16, int reset) {
 int tb_counters_reset(TbHandle* h, void* stream) {
   if (!h) return fail(TB_E_INVAL, "tb_counters_reset: null handle");
   DeviceGuard g(h->device);
-  HIP_TRY(hipMemsetAsync(h->d_counters, 0, sizeof(uint64_t) * TB_N_COUNTERS, (hipStream_t)stream));
+  HIP_TRY(hipMemsetAsync(h->d_counters, 0, sizeof(uint64_t) * TB_N_COUNTERS * TB_COUNTER_SHARDS, (hipStream_t)stream));
   return TB_OK;
 }
 
