@@ -122,6 +122,18 @@ TB_DEV void write_obs(float* dst, size_t row, const float* o) {
   }
 }
 
+template <int KIND>
+TB_DEV void load_actions(const float* actions, size_t row, float* a) {
+  if (KIND == TB_ENV_SWING) {  // 24-byte rows: three 8-byte loads
+    const float2* ap = reinterpret_cast<const float2*>(actions + row * 6);
+    float2 a0 = ap[0], a1 = ap[1], a2 = ap[2];
+    a[0] = a0.x; a[1] = a0.y; a[2] = a1.x; a[3] = a1.y; a[4] = a2.x; a[5] = a2.y;
+  } else {
+    float2 a0 = *reinterpret_cast<const float2*>(actions + row * 2);
+    a[0] = a0.x; a[1] = a0.y;
+  }
+}
+
 // reset(): swingracket_env.py:151-186 / tennisbot_env.py:217-261. The world rebuild
 // (resetSimulation + 3-4 loadURDF + STL hull + texture) collapses to re-drawing the state.
 template <int KIND>
@@ -283,15 +295,31 @@ TB_DEV void stage_hull(float4* s_hull, const KArgs& A) {
 
 // ------------------------------------------------------------------------------------------
 // step / rollout kernel: T agent steps of every env, state in registers throughout
-template <int KIND>
+// LEAN (SwingRacket only): every lane that would start a fast-forward is parked for tb_ff_kernel, so
+// the loop is not compiled into this kernel at all -- the pipelined path's step kernel. Its code is
+// a third of the full kernel's, which is worth ~1.5 us of a ~7 us launch at 4096 envs.
+template <int KIND, bool LEAN>
 __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
   constexpr int NA = Dims<KIND>::A, NO = Dims<KIND>::O;
   __shared__ float4 s_hull[TB_MAX_HULL * 2];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < A.n;
   EnvRegs e;
-  if (live) load_env<KIND>(A.words, A.done_state, A.n, i, e);  // issue the state loads first; the outline staging overlaps them
+#ifdef TB_DIAG_STAMPS
+  const unsigned long long t_entry = stamp_now();
+#endif
+  // issue every load this launch depends on back to back -- state rows, the first step's actions,
+  // the outline table -- so that their latencies overlap instead of queueing behind the barrier
+  float a[NA];
+  if (live) {
+    load_env<KIND>(A.words, A.done_state, A.n, i, e);
+    load_actions<KIND>(A.actions, (size_t)i, a);
+  }
   stage_hull(s_hull, A);
+#ifdef TB_DIAG_STAMPS
+  if (live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long t_loaded = stamp_now();
+#endif
 
   uint32_t cnt[TB_N_COUNTERS];
 #pragma unroll
@@ -309,29 +337,25 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
     int ns_total = 0;
     for (int t = 0; t < A.T; ++t) {
       const size_t row = (size_t)t * A.n + i;
-      float a[NA];
-      if (KIND == TB_ENV_SWING) {
-        const float2* ap = reinterpret_cast<const float2*>(A.actions + row * 6);
-        float2 a0 = ap[0], a1 = ap[1], a2 = ap[2];
-        a[0] = a0.x; a[1] = a0.y; a[2] = a1.x; a[3] = a1.y; a[4] = a2.x; a[5] = a2.y;
-      } else {
-        float2 a0 = *reinterpret_cast<const float2*>(A.actions + row * 2);
-        a[0] = a0.x; a[1] = a0.y;
-      }
+      if (t > 0) load_actions<KIND>(A.actions, row, a);
       float o[NO];
       int ns = 1;
       bool d, parked = false;
       float rew;
       if (KIND == TB_ENV_SWING) {
-        rew = swing_step(A.P, s_hull, e, a, ns, cnt, A.defer != 0, parked TB_STAMP_PASS);
+        rew = swing_step(A.P, s_hull, e, a, ns, cnt, LEAN || A.defer != 0, parked TB_STAMP_PASS);
         make_obs<TB_ENV_SWING>(e, o);
         d = e.done != TB_DONE_NO;  // swingracket_env.py:145 returns self.done
         if (parked) {
           // Every SwingRacket episode ends inside this step (the loop only exits through done), so
           // done = 1 is known now; reward, terminal obs and substep count of this step are written
           // later by tb_ff_kernel from the parked state. The env itself restarts immediately.
-          store_env<TB_ENV_SWING>(A.ff_words, A.ff_flag, A.n, i, e, true);
-          A.ff_flag[i] = 1;
+          if (A.ff_words) {
+            store_env<TB_ENV_SWING>(A.ff_words, A.ff_flag, A.n, i, e, true);
+            A.ff_flag[i] = 1;
+          } else {
+            cnt[7]++;  // lockstep invariant broken (see launch_step): reported, never silent
+          }
           d = true;
         }
       } else {
@@ -354,9 +378,15 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
       A.reward[row] = rew;
       A.done_out[row] = d ? 1 : 0;
     }
+#ifdef TB_DIAG_STAMPS
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_diag_cycles[15], stamp_now() - t_loaded);  // compute + output stores issued
+#endif
     if (A.substeps) A.substeps[i] = ns_total;
     store_env<KIND>(A.words, A.done_state, A.n, i, e, any_reset);
   }
+#ifdef TB_DIAG_STAMPS
+  if ((threadIdx.x & 63) == 0) atomicAdd(&g_diag_cycles[7], t_loaded - t_entry);  // state + outline loads landed
+#endif
   flush_counters(A.counters, cnt);
   if (blockIdx.x == 0 && threadIdx.x == 0)  // the first substep of every env in every agent step of this launch
     atomicAdd(&A.counters[6], (unsigned long long)A.n * (unsigned long long)A.T);
@@ -589,21 +619,32 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
   KArgs a = base_args(h);
   a.actions = actions; a.obs = obs; a.reward = reward; a.done_out = done; a.term_obs = term; a.substeps = substeps; a.T = T;
   dim3 grid((unsigned)((h->n + h->block - 1) / h->block)), block((unsigned)h->block);
-  // Park the fast-forward when this call is the 26th agent step since a full reset: all envs then
-  // enter it together. The phase is only a launch hint -- a lane that is not where the host thinks
-  // simply runs its loop inside whichever step kernel it is in.
-  const bool defer = T == 1 && h->pipeline && h->kind == TB_ENV_SWING && (h->kp.flags & TB_F_AUTO_RESET) && h->phase_valid && h->phase == 25;
+  // Pipelined SwingRacket: the step kernel never loops (LEAN); a lane that starts a fast-forward is
+  // parked and tb_ff_kernel finishes it on a side stream. When the host knows the episode phase (all
+  // envs were reset together; episodes are exactly 26 steps) only the 26th call can park anything, so
+  // only that call is followed by tb_ff_kernel; when it does not (masked reset, injected state), every
+  // call gets a slot and a (then mostly idle) tb_ff_kernel.
+  const bool piped = T == 1 && h->pipeline && h->kind == TB_ENV_SWING && (h->kp.flags & TB_F_AUTO_RESET);
+  const bool may_park = piped && (!h->phase_valid || h->phase == 25);
   int slot = -1;
-  if (defer) {
+  if (may_park) {
     slot = h->next_slot;
     h->next_slot = (slot + 1) % TB_FF_SLOTS;
     if (h->ff_busy[slot]) HIP_TRY(hipStreamWaitEvent(s, h->ev_ff[slot], 0));  // slot still in use by an older fast-forward
     a.defer = 1; a.ff_words = h->d_ff_words[slot]; a.ff_flag = h->d_ff_flag[slot];
   }
-  if (h->kind == TB_ENV_SWING) hipLaunchKernelGGL(tb_step_kernel<TB_ENV_SWING>, grid, block, 0, s, a);
-  else hipLaunchKernelGGL(tb_step_kernel<TB_ENV_TENNIS>, grid, block, 0, s, a);
+  if (h->kind == TB_ENV_TENNIS) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false>), grid, block, 0, s, a);
+  else if (may_park) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_SWING, true>), grid, block, 0, s, a);
+  else if (piped) {
+    // phase known and not the 26th step: every env has step_count = phase < 25 (all were reset
+    // together and every library call that could break lockstep clears phase_valid), so no lane
+    // can start a fast-forward in this launch and the lean kernel needs no slot. Should the
+    // invariant ever be broken, the lane is counted in counters[7] instead of being dropped silently.
+    a.ff_words = nullptr; a.ff_flag = nullptr;
+    hipLaunchKernelGGL((tb_step_kernel<TB_ENV_SWING, true>), grid, block, 0, s, a);
+  } else hipLaunchKernelGGL((tb_step_kernel<TB_ENV_SWING, false>), grid, block, 0, s, a);
   HIP_TRY(hipGetLastError());
-  if (defer) {
+  if (may_park) {
     HIP_TRY(hipEventRecord(h->ev_step[slot], s));
     HIP_TRY(hipStreamWaitEvent(h->side[slot], h->ev_step[slot], 0));
     // two fast-forwards that write the same terminal-obs / substeps buffer must finish in order
@@ -730,6 +771,7 @@ int tb_set_params(TbHandle* h, const TbParams* params, void* stream) {
   // the staging buffer may still feed an earlier async copy on another stream: settle it first
   if (int rc = wait_side(h, s)) return rc;
   HIP_TRY(hipStreamSynchronize(s));
+  if ((params->flags ^ h->params.flags) & TB_F_AUTO_RESET) h->phase_valid = 0;  // episodes may stop / start restarting
   h->params = *params;
   to_kparams(params, &h->kp);
   if (int rc = upload_hull(h, s)) return rc;

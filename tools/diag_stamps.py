@@ -42,6 +42,8 @@ for ep in range(2):
         print("episode %d, %s: %.0f waves/launch, kernel span %.0f cycles/wave/launch; stamped %.0f cycles/wave/launch" % (ep, label, waves, v[8] / v[9], tot / v[9]))
         for k in range(6):
             print("    %-20s %6.1f %%  (%.0f cycles/wave/launch)" % (names[k], 100.0 * v[k] / tot, v[k] / v[9]))
+        print("    entry -> state/outline loads landed: %.0f cycles/wave/launch; loads landed -> step computed, outputs issued: %.0f"
+              % (v[7] / v[9], v[15] / v[9]))
         if v[14]:
             print("    shader clock while this kernel ran: %.2f GHz (s_memtime / s_memrealtime)" % (v[8] / v[14] * 0.1))
         print("    wave-substeps %d, with a lane inside the racket's bounding sphere %d, with a lane running the outline sweep %d (lane-sweeps %d)"
