@@ -292,9 +292,11 @@ TB_DEV Hit sphere_vs_goal(const KParams& P, float gx, float gy, vec3 c) {
 // ---------------------------------------------------------------- sequential-impulse contact rows
 // Sequential impulses as in Bullet's multibody solver: normal
 // row with restitution / ERP / speculative margin, two friction rows along btPlaneSpace1(n)
-// boxed by mu * j_n. Rows live in registers and are indexed statically: slot 0 = racket pair,
-// slots 1..3 = ground, net, goal (visited in that order, inactive ones skipped = the order of a
-// compacted list). What does not change during a solve is computed once per row: the racket's
+// boxed by mu * j_n. Slot 0 = racket pair, slots 1..3 = ground, net, goal (visited in that order,
+// inactive ones skipped = the order of a compacted list). The racket row lives in registers; the
+// three static rows are indexed at run time on purpose, which places them in scratch: contacts are
+// rare (a handful of substeps per episode), and ~100 VGPRs of static-row state would otherwise cap
+// the occupancy of every substep, free flight included. What does not change during a solve is computed once per row: the racket's
 // angular responses I_w^-1 (rr x dir) and, for static pairs, the ball-only effective masses
 // (host-derived constants). Same arithmetic as recomputing them every time, fewer instructions.
 struct RowS {  // ball vs static shape
@@ -427,11 +429,11 @@ TB_DEV void solve_contacts(const KParams& P, Rows& R, Racket& rk, Ball& b) {
   for (int it = 0; it < P.solver_iters; ++it) {
     bool moved = false;
     if (R.on[0]) moved |= normal_racket(P, R.rk, rk, b);
-#pragma unroll
+#pragma unroll 1
     for (int i = 0; i < 3; ++i)
       if (R.on[i + 1]) moved |= normal_static(P, R.st[i], b);
     if (R.on[0]) moved |= friction_racket(P, R.rk, rk, b);
-#pragma unroll
+#pragma unroll 1
     for (int i = 0; i < 3; ++i)
       if (R.on[i + 1]) moved |= friction_static(P, R.st[i], b);
     if (!moved) break;
@@ -516,6 +518,10 @@ template <int KIND>
 TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, vec3 Fr, vec3 Tr, vec3 Fb, float goal_x, float goal_y, float scale TB_STAMP_ARG) {
   int bits = 0;
   TB_STAMP(st, 0);  // everything between two substeps (loop control, env logic)
+  // the velocity update touches velocities only and the narrowphase reads poses only: their order
+  // is free, and running it first keeps the Hit records from staying live across it
+  integrate_velocities(P, rk, b, Fr, Tr, Fb);
+  TB_STAMP(st, 3);  // velocity update
   Hit hr, hg, hn, hc;
   hr.hit = false; hg.hit = false; hn.hit = false; hc.hit = false;
 
@@ -552,9 +558,6 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, ve
   if (hg.hit) bits |= CT_GROUND;
   if (hn.hit) bits |= CT_NET;
   if (hc.hit) bits |= CT_GOAL;
-
-  integrate_velocities(P, rk, b, Fr, Tr, Fb);
-  TB_STAMP(st, 3);  // velocity update
 
   if (__any(bits != 0)) {
     if (bits) {  // only lanes whose ball touches something enter the solver

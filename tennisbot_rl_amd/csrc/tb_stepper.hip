@@ -298,7 +298,10 @@ TB_DEV void stage_hull(float4* s_hull, const KArgs& A) {
 // LEAN (SwingRacket only): every lane that would start a fast-forward is parked for tb_ff_kernel, so
 // the loop is not compiled into this kernel at all -- the pipelined path's step kernel. Its code is
 // a third of the full kernel's, which is worth ~1.5 us of a ~7 us launch at 4096 envs.
-template <int KIND, bool LEAN>
+// MULTI: A.T agent steps in one launch (tb_rollout); otherwise exactly one (tb_step). A compile-time
+// trip count of 1 is worth ~50-100 VGPRs (no loop-carried copies of the per-step bookkeeping), i.e.
+// one to two more waves per SIMD for the kernel every RL step launches.
+template <int KIND, bool LEAN, bool MULTI>
 __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
   constexpr int NA = Dims<KIND>::A, NO = Dims<KIND>::O;
   __shared__ float4 s_hull[TB_MAX_HULL * 2];
@@ -335,7 +338,8 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
   if (live) {
     bool any_reset = false;
     int ns_total = 0;
-    for (int t = 0; t < A.T; ++t) {
+    const int n_steps = MULTI ? A.T : 1;
+    for (int t = 0; t < n_steps; ++t) {
       const size_t row = (size_t)t * A.n + i;
       if (t > 0) load_actions<KIND>(A.actions, row, a);
       float o[NO];
@@ -389,7 +393,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
 #endif
   flush_counters(A.counters, cnt);
   if (blockIdx.x == 0 && threadIdx.x == 0)  // the first substep of every env in every agent step of this launch
-    atomicAdd(&A.counters[6], (unsigned long long)A.n * (unsigned long long)A.T);
+    atomicAdd(&A.counters[6], (unsigned long long)A.n * (unsigned long long)(MULTI ? A.T : 1));
 #ifdef TB_DIAG_STAMPS
   if ((threadIdx.x & 63) == 0) {  // per-wave sums (lane 0 carries the wave's scalar clock reads)
     for (int k = 0; k < 6; ++k) atomicAdd(&g_diag_cycles[k], (unsigned long long)st.acc[k]);
@@ -633,16 +637,19 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
     if (h->ff_busy[slot]) HIP_TRY(hipStreamWaitEvent(s, h->ev_ff[slot], 0));  // slot still in use by an older fast-forward
     a.defer = 1; a.ff_words = h->d_ff_words[slot]; a.ff_flag = h->d_ff_flag[slot];
   }
-  if (h->kind == TB_ENV_TENNIS) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false>), grid, block, 0, s, a);
-  else if (may_park) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_SWING, true>), grid, block, 0, s, a);
+  if (T > 1) {
+    if (h->kind == TB_ENV_TENNIS) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((tb_step_kernel<TB_ENV_SWING, false, true>), grid, block, 0, s, a);
+  } else if (h->kind == TB_ENV_TENNIS) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, false>), grid, block, 0, s, a);
+  else if (may_park) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_SWING, true, false>), grid, block, 0, s, a);
   else if (piped) {
     // phase known and not the 26th step: every env has step_count = phase < 25 (all were reset
     // together and every library call that could break lockstep clears phase_valid), so no lane
     // can start a fast-forward in this launch and the lean kernel needs no slot. Should the
     // invariant ever be broken, the lane is counted in counters[7] instead of being dropped silently.
     a.ff_words = nullptr; a.ff_flag = nullptr;
-    hipLaunchKernelGGL((tb_step_kernel<TB_ENV_SWING, true>), grid, block, 0, s, a);
-  } else hipLaunchKernelGGL((tb_step_kernel<TB_ENV_SWING, false>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((tb_step_kernel<TB_ENV_SWING, true, false>), grid, block, 0, s, a);
+  } else hipLaunchKernelGGL((tb_step_kernel<TB_ENV_SWING, false, false>), grid, block, 0, s, a);
   HIP_TRY(hipGetLastError());
   if (may_park) {
     HIP_TRY(hipEventRecord(h->ev_step[slot], s));
