@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--env", choices=["swing", "tennis"], default="swing")
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--contact-off", action="store_true", help="BASELINE configs[1] bench mode: racket<->ball pair disabled")
+    ap.add_argument("--racket-ground", action="store_true", help="also simulate racket<->court contact (TB_F_RACKET_GROUND, row f3; opt-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work per baseline leg (1 core, all cores)")
     ap.add_argument("--sweep", action="store_true", help="also time N = 4096 .. 4M envs on one GPU (extra JSON key)")
@@ -212,6 +213,9 @@ def main():
 
     kind = ENV_SWING if args.env == "swing" else ENV_TENNIS
     flags = F_NET if args.contact_off else F_DEFAULT
+    if args.racket_ground:
+        from tennisbot_rl_amd.params import F_RACKET_GROUND
+        flags |= F_RACKET_GROUND
     N = args.envs_per_gpu
     pipeline = kind == ENV_SWING and not args.no_pipeline
     env = BatchedEnv(kind, N, device=dev, seed=args.seed, env_id_base=rank * N, params=default_params(flags=flags),
@@ -257,7 +261,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s, %d envs/GPU, %s, auto-reset, U(-1,1) actions, rollout buffer %d steps%s%s%s" % (
                 "SwingRacket-v0" if args.env == "swing" else "Tennisbot-v0", N,
-                "racket<->ball contact off (configs[1] bench mode)" if args.contact_off else "full contact semantics",
+                ("racket<->ball contact off (configs[1] bench mode)" if args.contact_off else "full contact semantics") + (" + racket<->court contact" if args.racket_ground else ""),
                 T_buf, ", fast-forward pipelined on side streams" if pipeline else "", ", K steps replayed as one hipGraph" if (use_graph and GRAPH_STATE["used"]) else "",
                 gather_note),
                 "envs_per_gpu": N, "global_envs": world * N, "parallelism": "env-sharded x%d" % world},

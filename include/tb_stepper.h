@@ -82,6 +82,11 @@ extern "C" {
 #define TB_F_AUTO_RESET 0x1u          /* VecEnv semantics: a done env is reset inside the step */
 #define TB_F_NET 0x2u                 /* court.urdf:43-47 second collision box */
 #define TB_F_RACKET_BALL 0x4u         /* racket<->ball narrowphase + impulse; clear = BASELINE configs[1] "no ball contact" bench mode */
+#define TB_F_RACKET_GROUND 0x8u       /* racket<->court-ground contact: up to 4 manifold points picked
+                                       * statelessly from the hull vertices. Opt-in: it changes nothing the envs reward
+                                       * (the racket only lands after the swing), while a 4-point resting manifold costs
+                                       * ~30x a free-flight substep and balls that land on the grounded racket run into
+                                       * the 800-substep timeout: the SwingRacket fast-forward gets ~100x dearer */
 #define TB_F_DEFAULT (TB_F_NET | TB_F_RACKET_BALL)
 
 #define TB_MAX_HULL 64
@@ -125,6 +130,9 @@ typedef struct TbParams {
   /* pair coefficients: product rule, objects.py:16-18,29-31,48-50; goal keeps defaults */
   float rest_racket, rest_court, rest_goal;
   float fric_racket, fric_court, fric_goal;
+  /* racket <-> court (TB_F_RACKET_GROUND): product rule again (0.81, 0.04); manifold threshold
+   * 0.02 * the racket's bounding radius at scale 1 (Bullet: 0.02 * angular motion disc) */
+  float rest_racket_court, fric_racket_court, racket_ground_threshold;
   /* statics: court.urdf:19-24,43-47; simplegoal.urdf:17-22 (origins inside <geometry> are ignored) */
   float ground_half[3];
   float net_half[3];

@@ -52,6 +52,8 @@ def _lib(precision):
         L.tbo_philox4x32.argtypes = [vp, vp, vp]
         L.tbo_query_racket.argtypes = [ctypes.POINTER(TbParams), vp, vp, vp, vp]
         L.tbo_query_racket.restype = i32
+        L.tbo_query_racket_ground.argtypes = [ctypes.POINTER(TbParams), vp, vp, vp]
+        L.tbo_query_racket_ground.restype = i32
         L.tbo_query_box.argtypes = [ctypes.POINTER(TbParams), vp, vp, vp]
         L.tbo_query_box.restype = i32
         L.tbo_query_goal.argtypes = [ctypes.POINTER(TbParams), ctypes.c_float, ctypes.c_float, vp, vp]
@@ -164,6 +166,14 @@ def query_racket(params, racket_pos, racket_quat, ball_pos, precision="f64"):
     a, b, c = (np.asarray(x, np.float32) for x in (racket_pos, racket_quat, ball_pos))
     hit = _lib(precision).tbo_query_racket(ctypes.byref(params), _p(a), _p(b), _p(c), _p(out))
     return bool(hit), out[0], out[1:4].copy(), out[4:7].copy()
+
+
+def query_racket_ground(params, racket_pos, racket_quat, precision="f64"):
+    """manifold of the opt-in racket<->court contact: list of (distance, arm from the racket COM)"""
+    out = np.zeros(32, np.float64)
+    a, b = (np.asarray(x, np.float32) for x in (racket_pos, racket_quat))
+    n = _lib(precision).tbo_query_racket_ground(ctypes.byref(params), _p(a), _p(b), _p(out))
+    return [(out[8 * j], out[8 * j + 1: 8 * j + 4].copy()) for j in range(n)]
 
 
 def query_box(params, half, ball_pos, precision="f64"):

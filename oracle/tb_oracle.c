@@ -142,6 +142,7 @@ typedef struct {
   real racket_inv_mass, racket_inertia[3], racket_inv_inertia[3], racket_com[3], racket_half_thick, hull_margin, hull_bound_radius;
   real ball_inv_mass, ball_inv_inertia, ball_radius, magnus_k, ball_spin_max;
   real rest_racket, rest_court, rest_goal, fric_racket, fric_court, fric_goal;
+  real rest_racket_court, fric_racket_court, racket_ground_threshold;
   real ground_half[3], net_half[3], goal_radius, goal_half_len;
   real racket_scale;
   int n_hull; real hull_edges[TB_MAX_HULL][6];
@@ -181,6 +182,8 @@ static void prm_from(Prm *Q, const TbParams *P) {
   Q->magnus_k = W(P->magnus_k); Q->ball_spin_max = W(P->ball_spin_max);
   Q->rest_racket = W(P->rest_racket); Q->rest_court = W(P->rest_court); Q->rest_goal = W(P->rest_goal);
   Q->fric_racket = W(P->fric_racket); Q->fric_court = W(P->fric_court); Q->fric_goal = W(P->fric_goal);
+  Q->rest_racket_court = W(P->rest_racket_court); Q->fric_racket_court = W(P->fric_racket_court);
+  Q->racket_ground_threshold = P->racket_ground_threshold; /* derived from mesh data: exact as stored */
   Q->goal_radius = W(P->goal_radius); Q->goal_half_len = W(P->goal_half_len);
   Q->n_hull = P->n_hull;
   for (int i = 0; i < P->n_hull; ++i)
@@ -356,11 +359,16 @@ static Hit sphere_vs_goal(const Prm *P, real gx, real gy, v3 c) {
  * normal row with restitution (product rule, velocity threshold), Baumgarte ERP on
  * penetration, speculative margin on positive distance; two friction rows along
  * btPlaneSpace1(n), each boxed by mu * normal impulse. No warm start. Bullet always runs its
- * iteration cap; here a sweep whose every update is <= solver_tol * |impulse| ends the solve
- * (converged to ~1e-6 relative; in float32 the updates otherwise oscillate by ulps forever). */
+ * iteration cap; here a sweep whose every update is <= solver_tol * (the largest normal impulse
+ * of the solve) ends it: converged to ~1e-6 of the contact force. In float32 the updates
+ * otherwise oscillate by ulps forever, and rows of a redundant manifold (a racket resting on four
+ * points) keep trading tiny impulses that are large only relative to themselves. */
+#define ROW_BALL_STATIC 0 /* ball pushed off a static shape */
+#define ROW_BALL_RACKET 1 /* ball pushed off the racket, racket pushed back */
+#define ROW_RACKET_COURT 2 /* racket pushed off the court ground (TB_F_RACKET_GROUND) */
 typedef struct {
-  int racket; /* 1: other body is the racket, 0: static */
-  v3 n, rr, t1, t2;
+  int kind;
+  v3 n, rr, t1, t2; /* n: toward the pushed body; rr: contact point relative to the racket COM */
   real mu, target, kn, kt1, kt2, jn, jt1, jt2;
 } Row;
 
@@ -370,8 +378,9 @@ static inline v3 racket_invI(const Prm *P, q4 q, v3 x) {
   return qrot(q, b);
 }
 static inline v3 rel_vel(const Row *c, const Racket *rk, const Ball *b, v3 rb) {
+  if (c->kind == ROW_RACKET_COURT) return add3(rk->v, cross3(rk->w, c->rr));
   v3 pv = add3(b->v, cross3(b->w, rb));
-  if (c->racket) pv = sub3(pv, add3(rk->v, cross3(rk->w, c->rr)));
+  if (c->kind == ROW_BALL_RACKET) pv = sub3(pv, add3(rk->v, cross3(rk->w, c->rr)));
   return pv;
 }
 static inline void plane_space(v3 n, v3 *p, v3 *q) {
@@ -388,25 +397,33 @@ static inline void plane_space(v3 n, v3 *p, v3 *q) {
   }
 }
 static inline void apply_impulse(const Prm *P, const Row *c, Racket *rk, Ball *b, v3 rb, v3 dir, real j, int angular_ball) {
+  if (c->kind == ROW_RACKET_COURT) {
+    rk->v = axpy3(j * P->racket_inv_mass, dir, rk->v);
+    rk->w = axpy3(j, racket_invI(P, rk->q, cross3(c->rr, dir)), rk->w);
+    return;
+  }
   b->v = axpy3(j * P->ball_inv_mass, dir, b->v);
   if (angular_ball) b->w = axpy3(j * P->ball_inv_inertia, cross3(rb, dir), b->w);
-  if (c->racket) {
+  if (c->kind == ROW_BALL_RACKET) {
     rk->v = axpy3(-(j * P->racket_inv_mass), dir, rk->v);
     rk->w = axpy3(-j, racket_invI(P, rk->q, cross3(c->rr, dir)), rk->w);
   }
 }
-static void setup_row(const Prm *P, Row *c, const Hit *h, int racket, real e, real mu, const Racket *rk, const Ball *b) {
+static void setup_row(const Prm *P, Row *c, const Hit *h, int kind, real e, real mu, const Racket *rk, const Ball *b) {
   const real r = P->ball_radius;
   memset(c, 0, sizeof *c);
-  c->racket = racket; c->n = h->n; c->rr = h->rr; c->mu = mu;
+  c->kind = kind; c->n = h->n; c->rr = h->rr; c->mu = mu;
   plane_space(c->n, &c->t1, &c->t2);
   v3 rb = mul3(-r, c->n);
-  real kn = P->ball_inv_mass, kt1 = FMA(P->ball_inv_inertia, r * r, P->ball_inv_mass), kt2 = kt1;
-  if (racket) {
+  real kn, kt1, kt2;
+  if (kind == ROW_RACKET_COURT) { kn = P->racket_inv_mass; kt1 = kn; kt2 = kn; }
+  else { kn = P->ball_inv_mass; kt1 = FMA(P->ball_inv_inertia, r * r, P->ball_inv_mass); kt2 = kt1; }
+  if (kind == ROW_BALL_RACKET) { kn = kn + P->racket_inv_mass; kt1 = kt1 + P->racket_inv_mass; kt2 = kt2 + P->racket_inv_mass; }
+  if (kind != ROW_BALL_STATIC) {
     v3 a;
-    a = cross3(c->rr, c->n);  kn = (kn + P->racket_inv_mass) + dot3(a, racket_invI(P, rk->q, a));
-    a = cross3(c->rr, c->t1); kt1 = (kt1 + P->racket_inv_mass) + dot3(a, racket_invI(P, rk->q, a));
-    a = cross3(c->rr, c->t2); kt2 = (kt2 + P->racket_inv_mass) + dot3(a, racket_invI(P, rk->q, a));
+    a = cross3(c->rr, c->n);  kn = kn + dot3(a, racket_invI(P, rk->q, a));
+    a = cross3(c->rr, c->t1); kt1 = kt1 + dot3(a, racket_invI(P, rk->q, a));
+    a = cross3(c->rr, c->t2); kt2 = kt2 + dot3(a, racket_invI(P, rk->q, a));
   }
   c->kn = R(1) / kn; c->kt1 = R(1) / kt1; c->kt2 = R(1) / kt2;
   real vn = dot3(c->n, rel_vel(c, rk, b, rb));
@@ -415,8 +432,88 @@ static void setup_row(const Prm *P, Row *c, const Hit *h, int racket, real e, re
   real pos = h->dist > R(0) ? -(h->dist * P->inv_dt) : -(h->dist * P->erp) * P->inv_dt;
   c->target = rest + pos; /* the normal row drives vn toward this value */
 }
+
+/* racket vs the court's ground box (court.urdf:19-24), SURVEY.md A.3 / 8f.3. Bullet would build a
+ * persistent manifold of up to 4 points over several frames; this restatement is stateless: the
+ * candidates are the hull's 2 x n_hull vertices closer to the ground's top face than the manifold
+ * threshold (and above the court), of which up to 4 are kept the way Bullet reduces a manifold --
+ * the deepest, the one farthest from it, the one spanning the largest triangle with those two, and
+ * the one spanning the largest triangle on the other side. Ties go to the lowest vertex index
+ * k = 2 i + side. All distances are taken in the racket frame (rotation invariant). A vertex that is
+ * already below the box's bottom face is under the court, not in contact with its top. */
+#define MAX_RG 4
+static inline v3 hull_vertex(const Prm *P, int k, real s) {
+  real hx = P->racket_half_thick * s;
+  return V3((k & 1) ? hx : -hx, P->hull_edges[k >> 1][0] * s, P->hull_edges[k >> 1][1] * s);
+}
+/* height of hull vertex v above the ground's top face (margin included); zr = world z in the racket frame */
+static inline real vertex_height(const Prm *P, const Racket *rk, v3 zr, v3 v) {
+  real dz = FMA(zr.x, v.x, FMA(zr.z, v.z, zr.y * v.y));
+  return ((rk->p.z + dz) - P->hull_margin) - P->ground_half[2];
+}
+static int racket_vs_ground(const Prm *P, const Racket *rk, real s, Hit out[MAX_RG]) {
+  const real top = P->ground_half[2], thr = P->racket_ground_threshold * s;
+  if ((rk->p.z - (P->hull_bound_radius * s + P->hull_margin)) - top >= thr) return 0;
+  v3 xr = qrot_inv(rk->q, V3(R(1), R(0), R(0))), yr = qrot_inv(rk->q, V3(R(0), R(1), R(0))), zr = qrot_inv(rk->q, V3(R(0), R(0), R(1)));
+  uint64_t cand[2] = {0, 0};
+  int p0 = -1; real h0 = R(0);
+  for (int k = 0; k < 2 * P->n_hull; ++k) {
+    v3 v = hull_vertex(P, k, s);
+    real h = vertex_height(P, rk, zr, v);
+    if (!(h < thr) || h < -(R(2) * top)) continue; /* above the manifold threshold, or already below the 2*hz thick box */
+    real wx = rk->p.x + FMA(xr.x, v.x, FMA(xr.z, v.z, xr.y * v.y)), wy = rk->p.y + FMA(yr.x, v.x, FMA(yr.z, v.z, yr.y * v.y));
+    if (FABS(wx) > P->ground_half[0] || FABS(wy) > P->ground_half[1]) continue;
+    cand[k & 1] |= (uint64_t)1 << (k >> 1);
+    if (p0 < 0 || h < h0) { p0 = k; h0 = h; }
+  }
+  if (p0 < 0) return 0;
+  int pick[MAX_RG] = {p0, -1, -1, -1};
+  v3 v0 = hull_vertex(P, p0, s);
+  real best = R(0);
+  for (int k = 0; k < 2 * P->n_hull; ++k) { /* farthest from the deepest */
+    if (!((cand[k & 1] >> (k >> 1)) & 1)) continue;
+    v3 d = sub3(hull_vertex(P, k, s), v0);
+    real d2 = dot3(d, d);
+    if (d2 > best) { best = d2; pick[1] = k; }
+  }
+  v3 c2 = V3(R(0), R(0), R(0));
+  if (pick[1] >= 0) {
+    v3 e = sub3(hull_vertex(P, pick[1], s), v0);
+    best = R(0);
+    for (int k = 0; k < 2 * P->n_hull; ++k) { /* largest triangle */
+      if (!((cand[k & 1] >> (k >> 1)) & 1)) continue;
+      v3 c = cross3(sub3(hull_vertex(P, k, s), v0), e);
+      real a2 = dot3(c, c);
+      if (a2 > best) { best = a2; pick[2] = k; c2 = c; }
+    }
+    if (pick[2] >= 0) {
+      best = R(0);
+      for (int k = 0; k < 2 * P->n_hull; ++k) { /* largest triangle on the other side of p0-p1 */
+        if (!((cand[k & 1] >> (k >> 1)) & 1)) continue;
+        v3 c = cross3(sub3(hull_vertex(P, k, s), v0), e);
+        if (!(dot3(c, c2) < R(0))) continue;
+        real a2 = dot3(c, c);
+        if (a2 > best) { best = a2; pick[3] = k; }
+      }
+    }
+  }
+  int n = 0;
+  for (int j = 0; j < MAX_RG; ++j) {
+    if (pick[j] < 0) continue;
+    v3 v = hull_vertex(P, pick[j], s);
+    Hit *h = &out[n++];
+    h->hit = 1;
+    h->dist = vertex_height(P, rk, zr, v);
+    h->n = V3(R(0), R(0), R(1));
+    h->rr = qrot(rk->q, v);
+    h->rr.z = h->rr.z - P->hull_margin; /* the point on the inflated hull */
+  }
+  return n;
+}
+
 static void solve_contacts(const Prm *P, Row *rows, int nrows, Racket *rk, Ball *b) {
   const real r = P->ball_radius;
+  real jref = R(0); /* largest normal impulse seen in this solve: the scale updates are judged against */
   for (int it = 0; it < P->solver_iters; ++it) {
     int moved = 0;
     for (int i = 0; i < nrows; ++i) {
@@ -427,7 +524,8 @@ static void solve_contacts(const Prm *P, Row *rows, int nrows, Racket *rk, Ball 
       if (jn < R(0)) jn = R(0);
       real d = jn - c->jn;
       c->jn = jn;
-      if (d != R(0)) { apply_impulse(P, c, rk, b, rb, c->n, d, 0); if (FABS(d) > P->solver_tol * FABS(jn)) moved = 1; }
+      if (jn > jref) jref = jn;
+      if (d != R(0)) { apply_impulse(P, c, rk, b, rb, c->n, d, 0); if (FABS(d) > P->solver_tol * jref) moved = 1; }
     }
     for (int i = 0; i < nrows; ++i) {
       Row *c = &rows[i];
@@ -443,7 +541,7 @@ static void solve_contacts(const Prm *P, Row *rows, int nrows, Racket *rk, Ball 
         jt = jt < -lim ? -lim : (jt > lim ? lim : jt);
         real d = jt - *acc;
         *acc = jt;
-        if (d != R(0)) { apply_impulse(P, c, rk, b, rb, t, d, 1); if (FABS(d) > P->solver_tol * FABS(jt)) moved = 1; }
+        if (d != R(0)) { apply_impulse(P, c, rk, b, rb, t, d, 1); if (FABS(d) > P->solver_tol * (FABS(jt) > jref ? FABS(jt) : jref)) moved = 1; }
       }
     }
     if (!moved) break;
@@ -458,6 +556,7 @@ static void solve_contacts(const Prm *P, Row *rows, int nrows, Racket *rk, Ball 
 #define CT_GROUND 2
 #define CT_NET 4
 #define CT_GOAL 8
+#define CT_RACKET_COURT 16
 
 static void integrate_velocities(const Prm *P, Racket *rk, Ball *b, v3 Fr, v3 Tr, v3 Fb) {
   const real dt = P->dt, g = P->gravity;
@@ -518,7 +617,7 @@ static void integrate_pose(const Prm *P, Racket *rk, Ball *b) {
 }
 
 static int substep(const Prm *P, int kind, Racket *rk, Ball *b, v3 Fr, v3 Tr, v3 Fb, real gx, real gy, real scale) {
-  Row rows[4];
+  Row rows[4 + MAX_RG];
   int nrows = 0, bits = 0;
   Hit h;
   if (P->flags & TB_F_RACKET_BALL) {
@@ -533,14 +632,19 @@ static int substep(const Prm *P, int kind, Racket *rk, Ball *b, v3 Fr, v3 Tr, v3
   if (hg.hit) bits |= CT_GROUND;
   if (hn.hit) bits |= CT_NET;
   if (hc.hit) bits |= CT_GOAL;
+  Hit hrg[MAX_RG];
+  int nrg = 0;
+  if (P->flags & TB_F_RACKET_GROUND) nrg = racket_vs_ground(P, rk, scale, hrg);
+  if (nrg) bits |= CT_RACKET_COURT;
 
   integrate_velocities(P, rk, b, Fr, Tr, Fb);
 
   if (bits) {
-    if (bits & CT_RACKET) setup_row(P, &rows[nrows++], &h, 1, P->rest_racket, P->fric_racket, rk, b);
-    if (bits & CT_GROUND) setup_row(P, &rows[nrows++], &hg, 0, P->rest_court, P->fric_court, rk, b);
-    if (bits & CT_NET) setup_row(P, &rows[nrows++], &hn, 0, P->rest_court, P->fric_court, rk, b);
-    if (bits & CT_GOAL) setup_row(P, &rows[nrows++], &hc, 0, P->rest_goal, P->fric_goal, rk, b);
+    if (bits & CT_RACKET) setup_row(P, &rows[nrows++], &h, ROW_BALL_RACKET, P->rest_racket, P->fric_racket, rk, b);
+    if (bits & CT_GROUND) setup_row(P, &rows[nrows++], &hg, ROW_BALL_STATIC, P->rest_court, P->fric_court, rk, b);
+    if (bits & CT_NET) setup_row(P, &rows[nrows++], &hn, ROW_BALL_STATIC, P->rest_court, P->fric_court, rk, b);
+    if (bits & CT_GOAL) setup_row(P, &rows[nrows++], &hc, ROW_BALL_STATIC, P->rest_goal, P->fric_goal, rk, b);
+    for (int j = 0; j < nrg; ++j) setup_row(P, &rows[nrows++], &hrg[j], ROW_RACKET_COURT, P->rest_racket_court, P->fric_racket_court, rk, b);
     solve_contacts(P, rows, nrows, rk, b);
   }
   integrate_pose(P, rk, b);
@@ -812,6 +916,16 @@ int tbo_query_racket(const TbParams *P0, const float rp[3], const float rq[4], c
   Hit h = sphere_vs_racket(P, &rk, V3(R(c[0]), R(c[1]), R(c[2])), P->racket_scale);
   out[0] = h.dist; out[1] = h.n.x; out[2] = h.n.y; out[3] = h.n.z; out[4] = h.rr.x; out[5] = h.rr.y; out[6] = h.rr.z; out[7] = 0;
   return h.hit;
+}
+int tbo_query_racket_ground(const TbParams *P0, const float rp[3], const float rq[4], double out[MAX_RG * 8]) {
+  Prm Pq, *P = &Pq; prm_from(P, P0);
+  Racket rk; memset(&rk, 0, sizeof rk);
+  rk.p = V3(R(rp[0]), R(rp[1]), R(rp[2]));
+  rk.q.x = R(rq[0]); rk.q.y = R(rq[1]); rk.q.z = R(rq[2]); rk.q.w = R(rq[3]);
+  Hit h[MAX_RG];
+  int n = racket_vs_ground(P, &rk, P->racket_scale, h);
+  for (int j = 0; j < n; ++j) { out[8 * j] = h[j].dist; out[8 * j + 1] = h[j].rr.x; out[8 * j + 2] = h[j].rr.y; out[8 * j + 3] = h[j].rr.z; }
+  return n;
 }
 int tbo_query_box(const TbParams *P0, const float half[3], const float c[3], double out[4]) {
   Prm Pq, *P = &Pq; prm_from(P, P0);

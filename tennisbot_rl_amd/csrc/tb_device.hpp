@@ -99,6 +99,7 @@ struct KParams {
   float racket_inv_mass, racket_inertia[3], racket_inv_inertia[3], racket_com[3], racket_half_thick, hull_margin, hull_bound_radius, racket_scale;
   float ball_inv_mass, ball_inv_inertia, ball_radius, magnus_k, ball_spin_max;
   float rest_racket, rest_court, rest_goal, fric_racket, fric_court, fric_goal;
+  float rest_racket_court, fric_racket_court, racket_ground_threshold;
   float ground_half[3], net_half[3], goal_radius, goal_half_len;
   float static_top;  // highest point of any enabled static shape (host-derived)
   // conservative convex superset of the outline (host-derived): half-planes n.p <= h in the COM
@@ -118,7 +119,7 @@ struct Hit {
   vec3 rr;     // racket pair: contact point on the racket relative to its COM
 };
 
-constexpr int CT_RACKET = 1, CT_GROUND = 2, CT_NET = 4, CT_GOAL = 8;
+constexpr int CT_RACKET = 1, CT_GROUND = 2, CT_NET = 4, CT_GOAL = 8, CT_RACKET_COURT = 16;
 
 // In-kernel stamps for the diagnostic build only (-DTB_DIAG_STAMPS, tools/diag_stamps.py):
 // cycles per substep segment, summed per wave into g_diag_cycles. Never compiled into the product.
@@ -358,63 +359,68 @@ TB_DEV void setup_racket(const KParams& P, RowR& c, const Hit& h, const Racket& 
   c.target = contact_target(P, dot(c.n, rel_vel_racket(c, rk, b, rb)), h.dist, P.rest_racket);
 }
 
-TB_DEV bool clamp_friction(float vt, float kt, float lim, float tol, float& acc, float& d) {
+// jref: the largest normal impulse seen so far in this solve -- updates are judged against it, so
+// that rows of a redundant manifold trading impulses that are tiny in absolute terms do not keep
+// the solve running to the iteration cap
+TB_DEV bool clamp_friction(float vt, float kt, float lim, float tol, float jref, float& acc, float& d) {
   float jt = FMA(-vt, kt, acc);
   jt = jt < -lim ? -lim : (jt > lim ? lim : jt);
   d = jt - acc;
   acc = jt;
-  return fabsf(d) > tol * fabsf(jt);
+  return fabsf(d) > tol * (fabsf(jt) > jref ? fabsf(jt) : jref);
 }
 
-TB_DEV bool normal_static(const KParams& P, RowS& c, Ball& b) {
+TB_DEV bool normal_static(const KParams& P, RowS& c, Ball& b, float& jref) {
   vec3 rb = (-P.ball_radius) * c.n;
   float vn = dot(c.n, ball_point_vel(b, rb));
   float jn = FMA(c.target - vn, P.ball_kn, c.jn);
   if (jn < 0.0f) jn = 0.0f;
   float d = jn - c.jn;
   c.jn = jn;
+  if (jn > jref) jref = jn;
   if (d == 0.0f) return false;
   b.v = fma3(d * P.ball_inv_mass, c.n, b.v);
-  return fabsf(d) > P.solver_tol * fabsf(jn);
+  return fabsf(d) > P.solver_tol * jref;
 }
-TB_DEV bool friction_static(const KParams& P, RowS& c, Ball& b) {
+TB_DEV bool friction_static(const KParams& P, RowS& c, Ball& b, float jref) {
   float lim = c.mu * c.jn;
   if (!(lim > 0.0f)) return false;
   bool moved = false;
   vec3 rb = (-P.ball_radius) * c.n;
   float d;
-  bool m = clamp_friction(dot(c.t1, ball_point_vel(b, rb)), P.ball_kt, lim, P.solver_tol, c.jt1, d);
+  bool m = clamp_friction(dot(c.t1, ball_point_vel(b, rb)), P.ball_kt, lim, P.solver_tol, jref, c.jt1, d);
   if (d != 0.0f) { moved |= m; b.v = fma3(d * P.ball_inv_mass, c.t1, b.v); b.w = fma3(d * P.ball_inv_inertia, cross(rb, c.t1), b.w); }
-  m = clamp_friction(dot(c.t2, ball_point_vel(b, rb)), P.ball_kt, lim, P.solver_tol, c.jt2, d);
+  m = clamp_friction(dot(c.t2, ball_point_vel(b, rb)), P.ball_kt, lim, P.solver_tol, jref, c.jt2, d);
   if (d != 0.0f) { moved |= m; b.v = fma3(d * P.ball_inv_mass, c.t2, b.v); b.w = fma3(d * P.ball_inv_inertia, cross(rb, c.t2), b.w); }
   return moved;
 }
-TB_DEV bool normal_racket(const KParams& P, RowR& c, Racket& rk, Ball& b) {
+TB_DEV bool normal_racket(const KParams& P, RowR& c, Racket& rk, Ball& b, float& jref) {
   vec3 rb = (-P.ball_radius) * c.n;
   float vn = dot(c.n, rel_vel_racket(c, rk, b, rb));
   float jn = FMA(c.target - vn, c.kn, c.jn);
   if (jn < 0.0f) jn = 0.0f;
   float d = jn - c.jn;
   c.jn = jn;
+  if (jn > jref) jref = jn;
   if (d == 0.0f) return false;
   b.v = fma3(d * P.ball_inv_mass, c.n, b.v);
   rk.v = fma3(-(d * P.racket_inv_mass), c.n, rk.v);
   rk.w = fma3(-d, c.an, rk.w);
-  return fabsf(d) > P.solver_tol * fabsf(jn);
+  return fabsf(d) > P.solver_tol * jref;
 }
-TB_DEV bool friction_racket(const KParams& P, RowR& c, Racket& rk, Ball& b) {
+TB_DEV bool friction_racket(const KParams& P, RowR& c, Racket& rk, Ball& b, float jref) {
   float lim = c.mu * c.jn;
   if (!(lim > 0.0f)) return false;
   bool moved = false;
   vec3 rb = (-P.ball_radius) * c.n;
   float d;
-  bool m = clamp_friction(dot(c.t1, rel_vel_racket(c, rk, b, rb)), c.kt1, lim, P.solver_tol, c.jt1, d);
+  bool m = clamp_friction(dot(c.t1, rel_vel_racket(c, rk, b, rb)), c.kt1, lim, P.solver_tol, jref, c.jt1, d);
   if (d != 0.0f) {
     moved |= m;
     b.v = fma3(d * P.ball_inv_mass, c.t1, b.v); b.w = fma3(d * P.ball_inv_inertia, cross(rb, c.t1), b.w);
     rk.v = fma3(-(d * P.racket_inv_mass), c.t1, rk.v); rk.w = fma3(-d, c.at1, rk.w);
   }
-  m = clamp_friction(dot(c.t2, rel_vel_racket(c, rk, b, rb)), c.kt2, lim, P.solver_tol, c.jt2, d);
+  m = clamp_friction(dot(c.t2, rel_vel_racket(c, rk, b, rb)), c.kt2, lim, P.solver_tol, jref, c.jt2, d);
   if (d != 0.0f) {
     moved |= m;
     b.v = fma3(d * P.ball_inv_mass, c.t2, b.v); b.w = fma3(d * P.ball_inv_inertia, cross(rb, c.t2), b.w);
@@ -423,19 +429,173 @@ TB_DEV bool friction_racket(const KParams& P, RowR& c, Racket& rk, Ball& b) {
   return moved;
 }
 
-struct Rows { RowR rk; RowS st[3]; bool on[4]; };
+// racket vs the court's ground box (TB_F_RACKET_GROUND; opt-in). Bullet would
+// grow a persistent manifold of up to 4 points over several frames; here the manifold is rebuilt
+// every substep from the hull's 2 x n_hull vertices that are closer to the ground's top face than
+// the manifold threshold (and above the court): the deepest, the one farthest from it, the one
+// spanning the largest triangle with those two and the one spanning the largest triangle on the
+// other side -- Bullet's own reduction rule, applied in the racket frame. Ties: lowest k = 2i+side.
+constexpr int TB_MAX_RG = 4;
+struct RowG {  // racket pushed off the ground: n = +z
+  vec3 rr, an, at1, at2;
+  float target, kn, kt1, kt2, jn, jt1, jt2;
+};
+TB_DEV vec3 hull_vertex(const KParams& P, const float4* hull, int k, float s) {
+  float hx = P.racket_half_thick * s;
+  float4 e0 = hull[2 * (k >> 1)];
+  return mk((k & 1) ? hx : -hx, e0.x * s, e0.y * s);
+}
+TB_DEV float vertex_height(const KParams& P, const Racket& rk, vec3 zr, vec3 v) {
+  float dz = FMA(zr.x, v.x, FMA(zr.z, v.z, zr.y * v.y));
+  return ((rk.p.z + dz) - P.hull_margin) - P.ground_half[2];
+}
+// picks[j] = vertex index or -1; returns the number of picks. zr = world z axis in the racket frame.
+// Pass 1 visits the outline once (both faces share the (y, z) part of every dot product); the
+// selection passes visit candidates only, in ascending k (ties go to the lowest index).
+TB_DEV int racket_vs_ground(const KParams& P, const float4* hull, const Racket& rk, float s, int* picks, vec3& zr) {
+  const float top = P.ground_half[2], thr = P.racket_ground_threshold * s;
+  picks[0] = -1; picks[1] = -1; picks[2] = -1; picks[3] = -1;
+  if ((rk.p.z - (P.hull_bound_radius * s + P.hull_margin)) - top >= thr) return 0;
+  vec3 xr = rotate_inv(rk.q, mk(1.0f, 0.0f, 0.0f)), yr = rotate_inv(rk.q, mk(0.0f, 1.0f, 0.0f));
+  zr = rotate_inv(rk.q, mk(0.0f, 0.0f, 1.0f));
+  const float hx = P.racket_half_thick * s;
+  unsigned long long cand0 = 0ull, cand1 = 0ull;
+  int p0 = -1;
+  float h0 = 0.0f;
+  for (int i = 0; i < P.n_hull; ++i) {
+    float4 e0 = hull[2 * i];
+    float vy = e0.x * s, vz = e0.y * s;
+    float bz = FMA(zr.z, vz, zr.y * vy), bx = FMA(xr.z, vz, xr.y * vy), by = FMA(yr.z, vz, yr.y * vy);
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      float vx = side ? hx : -hx;
+      float h = ((rk.p.z + FMA(zr.x, vx, bz)) - P.hull_margin) - top;
+      if (!(h < thr) || h < -(2.0f * top)) continue;  // above the manifold threshold, or already below the 2*hz thick box
+      float wx = rk.p.x + FMA(xr.x, vx, bx), wy = rk.p.y + FMA(yr.x, vx, by);
+      if (fabsf(wx) > P.ground_half[0] || fabsf(wy) > P.ground_half[1]) continue;
+      if (side) cand1 |= 1ull << i; else cand0 |= 1ull << i;
+      if (p0 < 0 || h < h0) { p0 = 2 * i + side; h0 = h; }
+    }
+  }
+  if (p0 < 0) return 0;
+  picks[0] = p0;
+  const vec3 v0 = hull_vertex(P, hull, p0, s);
+  float best = 0.0f;
+  for (unsigned long long m = cand0 | cand1; m; m &= m - 1ull) {  // farthest from the deepest
+    const int i = __ffsll((long long)m) - 1;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      if (!(((side ? cand1 : cand0) >> i) & 1ull)) continue;
+      vec3 d = hull_vertex(P, hull, 2 * i + side, s) - v0;
+      float d2 = dot(d, d);
+      if (d2 > best) { best = d2; picks[1] = 2 * i + side; }
+    }
+  }
+  if (picks[1] >= 0) {
+    const vec3 e = hull_vertex(P, hull, picks[1], s) - v0;
+    vec3 c2 = mk(0.0f, 0.0f, 0.0f);
+    best = 0.0f;
+    for (unsigned long long m = cand0 | cand1; m; m &= m - 1ull) {  // largest triangle
+      const int i = __ffsll((long long)m) - 1;
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        if (!(((side ? cand1 : cand0) >> i) & 1ull)) continue;
+        vec3 c = cross(hull_vertex(P, hull, 2 * i + side, s) - v0, e);
+        float a2 = dot(c, c);
+        if (a2 > best) { best = a2; picks[2] = 2 * i + side; c2 = c; }
+      }
+    }
+    if (picks[2] >= 0) {
+      best = 0.0f;
+      for (unsigned long long m = cand0 | cand1; m; m &= m - 1ull) {  // largest triangle on the other side of p0-p1
+        const int i = __ffsll((long long)m) - 1;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+          if (!(((side ? cand1 : cand0) >> i) & 1ull)) continue;
+          vec3 c = cross(hull_vertex(P, hull, 2 * i + side, s) - v0, e);
+          if (!(dot(c, c2) < 0.0f)) continue;
+          float a2 = dot(c, c);
+          if (a2 > best) { best = a2; picks[3] = 2 * i + side; }
+        }
+      }
+    }
+  }
+  return (picks[1] >= 0) + (picks[2] >= 0) + (picks[3] >= 0) + 1;
+}
+TB_DEV void setup_ground_row(const KParams& P, const float4* hull, RowG& c, int k, float s, vec3 zr, const Racket& rk) {
+  const vec3 n = mk(0.0f, 0.0f, 1.0f);
+  vec3 t1, t2;
+  plane_space(n, t1, t2);
+  vec3 v = hull_vertex(P, hull, k, s);
+  float dist = vertex_height(P, rk, zr, v);
+  c.rr = rotate(rk.q, v);
+  c.rr.z = c.rr.z - P.hull_margin;  // the point on the inflated hull
+  c.jn = 0.0f; c.jt1 = 0.0f; c.jt2 = 0.0f;
+  vec3 a;
+  a = cross(c.rr, n);  c.an = racket_invI(P, rk.q, a);  c.kn = 1.0f / (P.racket_inv_mass + dot(a, c.an));
+  a = cross(c.rr, t1); c.at1 = racket_invI(P, rk.q, a); c.kt1 = 1.0f / (P.racket_inv_mass + dot(a, c.at1));
+  a = cross(c.rr, t2); c.at2 = racket_invI(P, rk.q, a); c.kt2 = 1.0f / (P.racket_inv_mass + dot(a, c.at2));
+  c.target = contact_target(P, dot(n, rk.v + cross(rk.w, c.rr)), dist, P.rest_racket_court);
+}
+TB_DEV bool normal_ground(const KParams& P, RowG& c, Racket& rk, float& jref) {
+  const vec3 n = mk(0.0f, 0.0f, 1.0f);
+  float vn = dot(n, rk.v + cross(rk.w, c.rr));
+  float jn = FMA(c.target - vn, c.kn, c.jn);
+  if (jn < 0.0f) jn = 0.0f;
+  float d = jn - c.jn;
+  c.jn = jn;
+  if (jn > jref) jref = jn;
+  if (d == 0.0f) return false;
+  rk.v = fma3(d * P.racket_inv_mass, n, rk.v);
+  rk.w = fma3(d, c.an, rk.w);
+  return fabsf(d) > P.solver_tol * jref;
+}
+TB_DEV bool friction_ground(const KParams& P, RowG& c, Racket& rk, float jref) {
+  float lim = P.fric_racket_court * c.jn;
+  if (!(lim > 0.0f)) return false;
+  bool moved = false;
+  vec3 t1, t2;
+  plane_space(mk(0.0f, 0.0f, 1.0f), t1, t2);
+  float d;
+  bool m = clamp_friction(dot(t1, rk.v + cross(rk.w, c.rr)), c.kt1, lim, P.solver_tol, jref, c.jt1, d);
+  if (d != 0.0f) { moved |= m; rk.v = fma3(d * P.racket_inv_mass, t1, rk.v); rk.w = fma3(d, c.at1, rk.w); }
+  m = clamp_friction(dot(t2, rk.v + cross(rk.w, c.rr)), c.kt2, lim, P.solver_tol, jref, c.jt2, d);
+  if (d != 0.0f) { moved |= m; rk.v = fma3(d * P.racket_inv_mass, t2, rk.v); rk.w = fma3(d, c.at2, rk.w); }
+  return moved;
+}
 
-TB_DEV void solve_contacts(const KParams& P, Rows& R, Racket& rk, Ball& b) {
+// RG = the kernel was instantiated with racket<->court contact. Its rows are statically indexed
+// (registers): unlike ball contacts, a racket resting on the ground is solved on EVERY substep of
+// every such lane, where scratch-resident rows cost ~150 us per substep (measured). The price --
+// ~80 more VGPRs -- is paid only by the RG instantiations, which the host launches only when
+// TB_F_RACKET_GROUND is set; the default kernels do not contain any of this.
+template <bool RG> struct Rows;
+template <> struct Rows<false> { RowR rk; RowS st[3]; bool on[4]; };
+template <> struct Rows<true> { RowR rk; RowS st[3]; bool on[4]; RowG rg[TB_MAX_RG]; int nrg; };
+
+template <bool RG>
+TB_DEV void solve_contacts(const KParams& P, Rows<RG>& R, Racket& rk, Ball& b) {
+  float jref = 0.0f;
   for (int it = 0; it < P.solver_iters; ++it) {
     bool moved = false;
-    if (R.on[0]) moved |= normal_racket(P, R.rk, rk, b);
+    if (R.on[0]) moved |= normal_racket(P, R.rk, rk, b, jref);
 #pragma unroll 1
     for (int i = 0; i < 3; ++i)
-      if (R.on[i + 1]) moved |= normal_static(P, R.st[i], b);
-    if (R.on[0]) moved |= friction_racket(P, R.rk, rk, b);
+      if (R.on[i + 1]) moved |= normal_static(P, R.st[i], b, jref);
+    if constexpr (RG) {
+#pragma unroll
+      for (int j = 0; j < TB_MAX_RG; ++j)
+        if (j < R.nrg) moved |= normal_ground(P, R.rg[j], rk, jref);
+    }
+    if (R.on[0]) moved |= friction_racket(P, R.rk, rk, b, jref);
 #pragma unroll 1
     for (int i = 0; i < 3; ++i)
-      if (R.on[i + 1]) moved |= friction_static(P, R.st[i], b);
+      if (R.on[i + 1]) moved |= friction_static(P, R.st[i], b, jref);
+    if constexpr (RG) {
+#pragma unroll
+      for (int j = 0; j < TB_MAX_RG; ++j)
+        if (j < R.nrg) moved |= friction_ground(P, R.rg[j], rk, jref);
+    }
     if (!moved) break;
   }
 }
@@ -514,7 +674,7 @@ TB_DEV void integrate_pose(const KParams& P, Racket& rk, Ball& b) {
 // the narrowphase is arranged as cheap per-lane culls + wave votes: a wave runs the outline
 // sweep / the static tests / the impulse solver only if __any lane needs them, and those
 // branches are wave-uniform (s_cbranch on the ballot), never if-converted into the hot path.
-template <int KIND>
+template <int KIND, bool RG>
 TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, vec3 Fr, vec3 Tr, vec3 Fb, float goal_x, float goal_y, float scale TB_STAMP_ARG) {
   int bits = 0;
   TB_STAMP(st, 0);  // everything between two substeps (loop control, env logic)
@@ -558,10 +718,22 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, ve
   if (hg.hit) bits |= CT_GROUND;
   if (hn.hit) bits |= CT_NET;
   if (hc.hit) bits |= CT_GOAL;
+  int rg_picks[TB_MAX_RG] = {-1, -1, -1, -1};
+  vec3 rg_zr = mk(0.0f, 0.0f, 0.0f);
+  if constexpr (RG) {
+    if (racket_vs_ground(P, hull, rk, scale, rg_picks, rg_zr) > 0) bits |= CT_RACKET_COURT;
+  }
 
   if (__any(bits != 0)) {
-    if (bits) {  // only lanes whose ball touches something enter the solver
-      Rows R;
+    if (bits) {  // only lanes that touch something enter the solver
+      Rows<RG> R;
+      if constexpr (RG) {
+        R.nrg = (rg_picks[0] >= 0) + (rg_picks[1] >= 0) + (rg_picks[2] >= 0) + (rg_picks[3] >= 0);
+        // picks are found in order 0..3 and a later one exists only if the earlier ones do: compact already
+#pragma unroll
+        for (int j = 0; j < TB_MAX_RG; ++j)
+          if (rg_picks[j] >= 0) setup_ground_row(P, hull, R.rg[j], rg_picks[j], scale, rg_zr, rk);
+      }
       R.on[0] = bits & CT_RACKET; R.on[1] = bits & CT_GROUND; R.on[2] = bits & CT_NET; R.on[3] = bits & CT_GOAL;
       if (R.on[0]) setup_racket(P, R.rk, hr, rk, b);
       if (R.on[1]) setup_static(P, R.st[0], hg, P.rest_court, P.fric_court, b);

@@ -203,12 +203,13 @@ TB_DEV vec3 restoring_force(const EnvRegs& e) {  // swingracket_env.py:135-141
 //                    later ones with the restoring force of :135-141.
 // `in_ff` = start inside the fast-forward (tb_ff_kernel resuming a parked env).
 // `defer`  = leave the fast-forward to tb_ff_kernel: sets `parked` instead of looping.
+template <bool RG>
 TB_DEV float swing_loop(const KParams& P, const float4* hull, EnvRegs& e, vec3 F, vec3 T, bool in_ff, bool defer, bool& parked,
                         int& ns, uint32_t* cnt TB_STAMP_ARG) {
   const vec3 zero = mk(0.0f, 0.0f, 0.0f);
   float reward = 0.0f;
   for (;;) {
-    int bits = substep<TB_ENV_SWING>(P, hull, e.r, e.b, F, T, zero, e.aux[0], e.aux[1], 1.0f TB_STAMP_PASS);  // :82 / :107
+    int bits = substep<TB_ENV_SWING, RG>(P, hull, e.r, e.b, F, T, zero, e.aux[0], e.aux[1], 1.0f TB_STAMP_PASS);  // :82 / :107
     e.step_count += 1; ns++;                                                                                   // :83 / :108
     if (bits & CT_RACKET) cnt[0]++;
     if (!in_ff) {
@@ -227,6 +228,7 @@ TB_DEV float swing_loop(const KParams& P, const float4* hull, EnvRegs& e, vec3 F
   return reward;
 }
 
+template <bool RG>
 TB_DEV float swing_step(const KParams& P, const float4* hull, EnvRegs& e, const float* a, int& ns, uint32_t* cnt, bool defer, bool& parked TB_STAMP_ARG) {
   vec3 F = mk(a[0] * 400.0f, a[1] * 400.0f, FMA(a[2], 400.0f, 4.0f * 9.81f));  // :76-77
   vec3 T = mk(a[3] * 5.0f, a[4] * 5.0f, a[5] * 5.0f);                          // :78
@@ -235,7 +237,7 @@ TB_DEV float swing_step(const KParams& P, const float4* hull, EnvRegs& e, const 
     e.done = TB_DONE_YES;
   }
   ns = 0;
-  return swing_loop(P, hull, e, F, T, false, defer, parked, ns, cnt TB_STAMP_PASS);
+  return swing_loop<RG>(P, hull, e, F, T, false, defer, parked, ns, cnt TB_STAMP_PASS);
 }
 
 // tennisbot_env.py:90-102
@@ -244,12 +246,13 @@ TB_DEV float dist_to_reward(float d) {
 }
 
 // tennisbot_env.py:104-207 (the DELAY_MODE sleep at :124-126 is dropped on purpose)
+template <bool RG>
 TB_DEV float tennis_step(const KParams& P, const float4* hull, EnvRegs& e, const float* a, float* obs, bool& ret_done, uint32_t* cnt TB_STAMP_ARG) {
   const vec3 zero = mk(0.0f, 0.0f, 0.0f);
   vec3 F = mk(a[0] * 10.0f, a[1] * 10.0f, 4.0f * 9.81f);  // :112-115
   vec3 Fb = zero;
   if (e.step_count < 5) Fb = mk(e.aux[0], e.aux[1], e.aux[2]);  // :118-119
-  int bits = substep<TB_ENV_TENNIS>(P, hull, e.r, e.b, F, zero, Fb, 0.0f, 0.0f, e.aux[3] TB_STAMP_PASS);  // :121
+  int bits = substep<TB_ENV_TENNIS, RG>(P, hull, e.r, e.b, F, zero, Fb, 0.0f, 0.0f, e.aux[3] TB_STAMP_PASS);  // :121
   e.step_count += 1;                                                                // :122
   if (bits & CT_RACKET) cnt[0]++;
   make_obs<TB_ENV_TENNIS>(e, obs);  // :134-136
@@ -301,7 +304,7 @@ TB_DEV void stage_hull(float4* s_hull, const KArgs& A) {
 // MULTI: A.T agent steps in one launch (tb_rollout); otherwise exactly one (tb_step). A compile-time
 // trip count of 1 is worth ~50-100 VGPRs (no loop-carried copies of the per-step bookkeeping), i.e.
 // one to two more waves per SIMD for the kernel every RL step launches.
-template <int KIND, bool LEAN, bool MULTI>
+template <int KIND, bool LEAN, bool MULTI, bool RG>
 __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
   constexpr int NA = Dims<KIND>::A, NO = Dims<KIND>::O;
   __shared__ float4 s_hull[TB_MAX_HULL * 2];
@@ -347,7 +350,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
       bool d, parked = false;
       float rew;
       if (KIND == TB_ENV_SWING) {
-        rew = swing_step(A.P, s_hull, e, a, ns, cnt, LEAN || A.defer != 0, parked TB_STAMP_PASS);
+        rew = swing_step<RG>(A.P, s_hull, e, a, ns, cnt, LEAN || A.defer != 0, parked TB_STAMP_PASS);
         make_obs<TB_ENV_SWING>(e, o);
         d = e.done != TB_DONE_NO;  // swingracket_env.py:145 returns self.done
         if (parked) {
@@ -363,7 +366,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
           d = true;
         }
       } else {
-        rew = tennis_step(A.P, s_hull, e, a, o, d, cnt TB_STAMP_PASS);
+        rew = tennis_step<RG>(A.P, s_hull, e, a, o, d, cnt TB_STAMP_PASS);
       }
       cnt[6] += (uint32_t)(ns - 1);  // substeps beyond the first of each agent step
       ns_total += ns;
@@ -405,6 +408,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
 }
 
 // finishes parked SwingRacket fast-forwards (side stream): same device code as the in-step loop
+template <bool RG>
 __global__ void __launch_bounds__(256) tb_ff_kernel(KArgs A) {
   __shared__ float4 s_hull[TB_MAX_HULL * 2];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -425,7 +429,7 @@ __global__ void __launch_bounds__(256) tb_ff_kernel(KArgs A) {
     int ns = 1;           // the step kernel ran the first substep of this agent step
     bool parked = false;
     const vec3 zero = mk(0.0f, 0.0f, 0.0f);
-    float rew = swing_loop(A.P, s_hull, e, zero, zero, true, false, parked, ns, cnt TB_STAMP_PASS);
+    float rew = swing_loop<RG>(A.P, s_hull, e, zero, zero, true, false, parked, ns, cnt TB_STAMP_PASS);
     cnt[6] += (uint32_t)(ns - 1);
     if (!(finite3(e.r.p) && finite3(e.r.v) && finite3(e.r.w) && finite3(e.b.p) && finite3(e.b.v) && finite3(e.b.w) &&
           isfinite(e.r.q.x) && isfinite(e.r.q.y) && isfinite(e.r.q.z) && isfinite(e.r.q.w)))
@@ -529,6 +533,7 @@ void to_kparams(const TbParams* p, KParams* k) {
   k->magnus_k = p->magnus_k; k->ball_spin_max = p->ball_spin_max;
   k->rest_racket = p->rest_racket; k->rest_court = p->rest_court; k->rest_goal = p->rest_goal;
   k->fric_racket = p->fric_racket; k->fric_court = p->fric_court; k->fric_goal = p->fric_goal;
+  k->rest_racket_court = p->rest_racket_court; k->fric_racket_court = p->fric_racket_court; k->racket_ground_threshold = p->racket_ground_threshold;
   k->goal_radius = p->goal_radius; k->goal_half_len = p->goal_half_len;
   k->n_hull = p->n_hull;
   float top = p->ground_half[2] > p->goal_half_len ? p->ground_half[2] : p->goal_half_len;
@@ -637,19 +642,26 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
     if (h->ff_busy[slot]) HIP_TRY(hipStreamWaitEvent(s, h->ev_ff[slot], 0));  // slot still in use by an older fast-forward
     a.defer = 1; a.ff_words = h->d_ff_words[slot]; a.ff_flag = h->d_ff_flag[slot];
   }
+  const bool rg = (h->kp.flags & TB_F_RACKET_GROUND) != 0;  // selects the instantiation that contains racket<->court contact
+#define TB_LAUNCH_STEP(KIND, LEAN, MULTI)                                                                      \
+  do {                                                                                                         \
+    if (rg) hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, MULTI, true>), grid, block, 0, s, a);                \
+    else hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, MULTI, false>), grid, block, 0, s, a);                  \
+  } while (0)
   if (T > 1) {
-    if (h->kind == TB_ENV_TENNIS) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((tb_step_kernel<TB_ENV_SWING, false, true>), grid, block, 0, s, a);
-  } else if (h->kind == TB_ENV_TENNIS) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, false>), grid, block, 0, s, a);
-  else if (may_park) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_SWING, true, false>), grid, block, 0, s, a);
+    if (h->kind == TB_ENV_TENNIS) TB_LAUNCH_STEP(TB_ENV_TENNIS, false, true);
+    else TB_LAUNCH_STEP(TB_ENV_SWING, false, true);
+  } else if (h->kind == TB_ENV_TENNIS) TB_LAUNCH_STEP(TB_ENV_TENNIS, false, false);
+  else if (may_park) TB_LAUNCH_STEP(TB_ENV_SWING, true, false);
   else if (piped) {
     // phase known and not the 26th step: every env has step_count = phase < 25 (all were reset
     // together and every library call that could break lockstep clears phase_valid), so no lane
     // can start a fast-forward in this launch and the lean kernel needs no slot. Should the
     // invariant ever be broken, the lane is counted in counters[7] instead of being dropped silently.
     a.ff_words = nullptr; a.ff_flag = nullptr;
-    hipLaunchKernelGGL((tb_step_kernel<TB_ENV_SWING, true, false>), grid, block, 0, s, a);
-  } else hipLaunchKernelGGL((tb_step_kernel<TB_ENV_SWING, false, false>), grid, block, 0, s, a);
+    TB_LAUNCH_STEP(TB_ENV_SWING, true, false);
+  } else TB_LAUNCH_STEP(TB_ENV_SWING, false, false);
+#undef TB_LAUNCH_STEP
   HIP_TRY(hipGetLastError());
   if (may_park) {
     HIP_TRY(hipEventRecord(h->ev_step[slot], s));
@@ -657,7 +669,8 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
     // two fast-forwards that write the same terminal-obs / substeps buffer must finish in order
     if (h->last_slot >= 0 && h->last_slot != slot && ((term && term == h->last_term) || (substeps && substeps == h->last_sub)))
       HIP_TRY(hipStreamWaitEvent(h->side[slot], h->ev_ff[h->last_slot], 0));
-    hipLaunchKernelGGL(tb_ff_kernel, grid, block, 0, h->side[slot], a);
+    if (rg) hipLaunchKernelGGL(tb_ff_kernel<true>, grid, block, 0, h->side[slot], a);
+    else hipLaunchKernelGGL(tb_ff_kernel<false>, grid, block, 0, h->side[slot], a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev_ff[slot], h->side[slot]));
     h->ff_busy[slot] = 1; h->last_slot = slot; h->last_term = term; h->last_sub = substeps;

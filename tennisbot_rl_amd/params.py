@@ -21,6 +21,7 @@ ENV_TENNIS = 1  # Tennisbot-v0,   tennisbot/__init__.py:3-6
 F_AUTO_RESET = 0x1
 F_NET = 0x2
 F_RACKET_BALL = 0x4
+F_RACKET_GROUND = 0x8  # opt-in racket<->court contact (row f3)
 F_DEFAULT = F_NET | F_RACKET_BALL
 
 DONE_NO, DONE_PENDING_FORCE, DONE_YES = 0, 1, 2
@@ -58,6 +59,7 @@ class TbParams(ctypes.Structure):
         ("ball_radius", ctypes.c_float), ("magnus_k", ctypes.c_float), ("ball_spin_max", ctypes.c_float),
         ("rest_racket", ctypes.c_float), ("rest_court", ctypes.c_float), ("rest_goal", ctypes.c_float),
         ("fric_racket", ctypes.c_float), ("fric_court", ctypes.c_float), ("fric_goal", ctypes.c_float),
+        ("rest_racket_court", ctypes.c_float), ("fric_racket_court", ctypes.c_float), ("racket_ground_threshold", ctypes.c_float),
         ("ground_half", ctypes.c_float * 3), ("net_half", ctypes.c_float * 3),
         ("goal_radius", ctypes.c_float), ("goal_half_len", ctypes.c_float),
         ("n_hull", ctypes.c_int32), ("hull_edges", (ctypes.c_float * TB_HULL_REC) * TB_MAX_HULL),
@@ -120,6 +122,7 @@ def default_params(racket_scale=1.0, flags=F_DEFAULT, scene=None, **overrides):
         # objects.py:29-31,48-50); the goal keeps Bullet's defaults (0 / 0.5); pair = product
         rest_racket=0.9 * 0.9, rest_court=0.9 * 0.9, rest_goal=0.9 * 0.0,
         fric_racket=0.2 * 0.2, fric_court=0.2 * 0.2, fric_goal=0.2 * 0.5,
+        rest_racket_court=0.9 * 0.9, fric_racket_court=0.2 * 0.2,
         ground_half=tuple(0.5 * x for x in sc["court"]["ground_box_size"]),
         net_half=tuple(0.5 * x for x in sc["court"]["net_box_size"]),
         goal_radius=sc["goal"]["radius"], goal_half_len=0.5 * sc["goal"]["length"],
@@ -133,7 +136,7 @@ def default_params(racket_scale=1.0, flags=F_DEFAULT, scene=None, **overrides):
     for k in ("dt", "gravity", "lin_damp", "ang_damp", "max_ang_step", "rest_vel_threshold", "erp",
               "contact_threshold", "solver_tol", "racket_mass", "hull_margin", "ball_mass", "ball_radius", "magnus_k",
               "ball_spin_max", "rest_racket", "rest_court", "rest_goal", "fric_racket", "fric_court",
-              "fric_goal", "goal_radius", "goal_half_len"):
+              "fric_goal", "rest_racket_court", "fric_racket_court", "goal_radius", "goal_half_len"):
         setattr(p, k, float(prim[k]))
     p.inv_dt = 1.0 / float(prim["dt"])
     p.solver_iters = int(prim["solver_iters"])
@@ -160,4 +163,5 @@ def default_params(racket_scale=1.0, flags=F_DEFAULT, scene=None, **overrides):
     # bound radius about the COM at scale 1, x extent included (slightly rounded up)
     vmax = float(np.sqrt((rec[:, :2].astype(np.float64) ** 2).sum(1).max() + float(p.racket_half_thick) ** 2))
     p.hull_bound_radius = vmax * 1.0001
+    p.racket_ground_threshold = 0.02 * vmax
     return p

@@ -11,7 +11,7 @@ import pytest
 
 from helpers import make_words
 from oracle import OracleBatch
-from tennisbot_rl_amd.params import (ENV_SWING, ENV_TENNIS, F_AUTO_RESET, F_DEFAULT, F_NET, STATE_WORDS, default_params)
+from tennisbot_rl_amd.params import (ENV_SWING, ENV_TENNIS, F_AUTO_RESET, F_DEFAULT, F_NET, F_RACKET_GROUND, STATE_WORDS, default_params)
 
 pytestmark = pytest.mark.gpu
 
@@ -387,4 +387,43 @@ def test_curriculum_scale_applies_at_each_envs_own_reset(torch):
             assert set(np.unique(sc)) <= {1.0, np.float32(3.0), np.float32(2.3), np.float32(1.3)}
     st = env.get_state()
     assert len(np.unique(st["racket_scale"])) >= 2   # envs are at different curriculum stages at the same time
+    env.close()
+
+
+def test_racket_ground_contact_opt_in(torch):
+    """row f3: racket<->court contact (TB_F_RACKET_GROUND). Whole SwingRacket episodes (the racket
+    lands during the fast-forward) and injected states with the racket on / in the ground at random
+    orientations, in lockstep with the oracle"""
+    env, ref = make_pair(torch, ENV_SWING, 1024, flags=F_DEFAULT | F_RACKET_GROUND)
+    run_lockstep(torch, env, ref, 54, np.random.default_rng(61), "swing racket-ground", check_state_every=1)
+    st = env.get_state()
+    env.close()
+    n = 512
+    rng = np.random.default_rng(62)
+    env, ref = make_pair(torch, ENV_SWING, n, auto_reset=False, flags=F_DEFAULT | F_RACKET_GROUND)
+    q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q[: n // 4] = (0, 0, 0, 1)                                   # upright
+    q[n // 4: n // 2] = (0, np.sqrt(0.5), 0, np.sqrt(0.5))       # lying on a face
+    # COM height that puts the LOWEST hull vertex within [-4 mm, +12 mm] of the ground's top face
+    p = default_params()
+    hv = p.hull_vertices()
+    verts = np.concatenate([np.c_[np.full(len(hv), sx * p.racket_half_thick), hv] for sx in (-1, 1)])   # [76, 3] racket frame
+
+    def rot(qq, v):
+        u, w0 = qq[:, None, :3], qq[:, None, 3:4]
+        tt = 2 * np.cross(u, v[None])
+        return v[None] + w0 * tt + np.cross(u, tt)
+    lowest = rot(q, verts)[:, :, 2].min(1)
+    z = -lowest + 0.005 + 0.001 + rng.uniform(-0.004, 0.012, n)
+    w, d = make_words(ENV_SWING, n, racket_pos=np.stack([rng.uniform(6, 13.9, n), rng.uniform(-6.9, 7.2, n), z], 1), racket_quat=q,
+                      racket_vel=rng.uniform(-2, 2, (n, 3)), racket_angvel=rng.uniform(-3, 3, (n, 3)), ball_pos=(0.0, 3.0, 50.0),
+                      goal=(-6, 0), spawn_pos=(9, 0, 0.6), init_dist=10.0, step_count=rng.integers(0, 20, n))
+    env.set_state_words(w.view(np.int32), d); ref.set_state_words(w, d)
+    for t in range(12):
+        a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
+        obs, rew, done = env.step(torch.from_numpy(a).cuda())
+        o2, r2, d2, s2 = ref.step(a)
+        same(obs.cpu().numpy(), o2, "racket-ground obs %d" % t)
+        compare_state(env, ref, "racket-ground forced %d" % t)
+    assert env.counters()["nonfinite_states"] == 0
     env.close()

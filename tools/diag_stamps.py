@@ -24,7 +24,9 @@ L.tb_diag_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 rng = np.random.Generator(np.random.PCG64(0))
 acts = torch.from_numpy(rng.uniform(-1, 1, (104, n, 6)).astype(np.float32)).cuda()
-env = stepper.BatchedEnv(ENV_SWING, n, seed=0, reuse_buffers=True)
+from tennisbot_rl_amd.params import F_DEFAULT, F_RACKET_GROUND, default_params  # noqa: E402
+flags = F_DEFAULT | (F_RACKET_GROUND if os.environ.get("TB_DIAG_RACKET_GROUND") == "1" else 0)
+env = stepper.BatchedEnv(ENV_SWING, n, seed=0, reuse_buffers=True, params=default_params(flags=flags))
 env.reset()
 names = ["between substeps", "racket narrowphase", "static narrowphase", "velocity update", "contact solve", "pose update"]
 buf = (ctypes.c_ulonglong * 16)()
