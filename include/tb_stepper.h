@@ -204,6 +204,24 @@ int tb_rollout(TbHandle *h, int n_steps, const float *actions_dev, float *obs_de
                float *reward_dev, uint8_t *done_dev, int32_t *substeps_total_dev, void *stream);
 
 /*
+ * step() with the policy inside ("policy inference on device ... so collect never
+ * leaves the GPU"): SB3's MlpPolicy as the reference configures it (train_swing.py:80-82: pi = vf =
+ * [32, 64, 32], tanh; Tennisbot-v0: SB3's default [64, 64], train.py:104-110), a = mean + exp(log_std)
+ * * eps, clipped to the action space before the env sees it, as SB3 does. Per env i:
+ *   obs_in_dev [N][O] the observation acted on  ->  actions_dev [N][A] (clipped), raw_actions_dev [N][A],
+ *   logp_dev [N] (log-probability of the raw sample), value_dev [N]; then exactly tb_step on those actions.
+ * weights_dev: tb_policy_floats(kind) floats, 16-byte aligned: the pi tower's layers, the action head,
+ * the vf tower's layers, the value head, log_std[A]; each layer = bias[out] then W transposed to
+ * [in][out], zero-padded to a multiple of 4 floats. tanh is evaluated as 1 - 2/(exp(2x)+1) on the
+ * hardware exp2/rcp units (absolute error < 3e-7). eps is drawn in-kernel from Philox keyed by (noise_seed, global env id, episode, step), so
+ * a captured graph draws fresh noise on every replay; deterministic != 0 uses the mean.
+ */
+int tb_policy_floats(int env_kind);
+int tb_policy_step(TbHandle *h, const float *weights_dev, const float *obs_in_dev, float *actions_dev,
+                   float *raw_actions_dev, float *logp_dev, float *value_dev, float *obs_dev,
+                   float *reward_dev, uint8_t *done_dev, uint64_t noise_seed, int deterministic, void *stream);
+
+/*
  * Pipelined fast-forward (SwingRacket-v0 with TB_F_AUTO_RESET; HIP streams, no reference
  * counterpart). The <= 775-substep fast-forward of swingracket_env.py:105-141 takes no
  * agent input, and the next episode does not depend on its outcome. With the pipeline

@@ -49,6 +49,15 @@ struct KArgs {
   uint32_t* ff_words;     // [W][n] slot
   uint8_t* ff_flag;       // [n]: 1 = parked, waiting for tb_ff_kernel
   int defer;
+  // fused policy inference (tb_policy_step): actions are computed in-kernel from pol_obs
+  const float* pol_weights;  // packed SB3 MlpPolicy towers, see PolicyNet
+  const float* pol_obs;      // [n][O] the observation each env acts on
+  float* pol_actions;        // [n][A] what the env is stepped with (clipped to [-1, 1])
+  float* pol_raw;            // [n][A] the unclipped sample (what the log-probability is of)
+  float* pol_logp;           // [n]
+  float* pol_value;          // [n]
+  unsigned long long pol_seed;
+  int pol_deterministic;
 };
 
 struct EnvRegs {
@@ -298,17 +307,226 @@ TB_DEV void stage_hull(float4* s_hull, const KArgs& A) {
 
 // ------------------------------------------------------------------------------------------
 // step / rollout kernel: T agent steps of every env, state in registers throughout
+// ------------------------------------------------------------------------------------------
+// Policy inference fused into the step kernel: SB3's MlpPolicy with separate pi / vf
+// towers as the reference configures it -- SwingRacket 6 -> 32 -> 64 -> 32 (train_swing.py:80-82),
+// Tennisbot 12 -> 64 -> 64 (SB3 default, train.py:104-110) -- tanh hidden layers, linear action mean,
+// state-independent log_std, a = mean + std * eps. One lane = one env; the towers' weights are staged
+// once per workgroup into LDS. ~9 k FMAs per env-step: VALU work (v_pk_fma_f32) next to a
+// launch-latency-bound step; fp32 MFMA has the same peak as packed fp32 VALU on CDNA, so there is no
+// matrix-core shortcut at 64 envs per wave without dropping the learner's precision.
+// Packed weights: pi tower layers, action head, vf tower layers, value head, log_std[A]; each layer as
+// described at layer_floats() below, exactly as tennisbot_rl_amd/ppo.py pack_policy() writes them.
+template <int KIND> struct PolicyNet;
+template <> struct PolicyNet<TB_ENV_SWING> { static constexpr int NH = 3, H0 = 32, H1 = 64, H2 = 32, LAST = 32; };
+template <> struct PolicyNet<TB_ENV_TENNIS> { static constexpr int NH = 2, H0 = 64, H1 = 64, H2 = 64, LAST = 64; };
+// one dense layer in the blob: bias[OUT], then W transposed to [IN][OUT] (so the weights of adjacent
+// outputs for one input are adjacent: one 16-byte LDS broadcast read feeds two packed FMAs), padded to a
+// multiple of 4 floats so that every layer starts 16-byte aligned
+constexpr int layer_floats(int in, int out) { return (out + in * out + 3) / 4 * 4; }
+template <int KIND> constexpr int tower_floats() {
+  using N = PolicyNet<KIND>;
+  constexpr int O = Dims<KIND>::O;
+  return layer_floats(O, N::H0) + layer_floats(N::H0, N::H1) + (N::NH == 3 ? layer_floats(N::H1, N::H2) : 0);
+}
+template <int KIND> constexpr int policy_floats() {
+  return 2 * tower_floats<KIND>() + layer_floats(PolicyNet<KIND>::LAST, Dims<KIND>::A) + layer_floats(PolicyNet<KIND>::LAST, 1) + Dims<KIND>::A;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// tanh(x) = 1 - 2 / (e^(2x) + 1) on the hardware exp2 / rcp units (1 ulp each): absolute error < 3e-7,
+// saturates correctly at +-inf. 5 instructions instead of libm's ~40: 256 tanh per env-step otherwise
+// cost as much as all the FMAs.
+TB_DEV float fast_tanh(float x) {
+  float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+  return FMA(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+}
+// y = act(b + W x) for the 64 envs of one wave. The activations live in LDS, interleaved per lane in
+// groups of 4 ([k / 4][lane][4]: conflict-free, and each lane only ever touches its own column, so a
+// layer overwrites its input in place without a barrier). The input loop is a REAL loop, software-
+// pipelined by hand: the weights of the next U inputs (U * OUT = 64 floats, wave-wide LDS broadcast
+// reads) are fetched into a second register set before the packed FMAs of the current ones run, with a
+// scheduling barrier between the two -- left to itself the compiler either issues every LDS read of a
+// fully unrolled layer first (34 KB of spills per lane) or one read per two FMAs with a full wait on
+// each. Per input: OUT independent accumulator chains (a lone wave per SIMD has no other wave to hide
+// FMA latency behind), two outputs per v_pk_fma_f32.
+TB_DEV int act_index(int k, int lane) { return ((k >> 2) * 64 + lane) * 4 + (k & 3); }
+
+template <int N>
+TB_DEV void lds_read_block(const float* p, float (&r)[N]) {  // N contiguous floats, widest aligned vectors
+  if constexpr (N % 4 == 0) {
+#pragma unroll
+    for (int j = 0; j < N / 4; ++j) {
+      float4 q = reinterpret_cast<const float4*>(p)[j];
+      r[4 * j] = q.x; r[4 * j + 1] = q.y; r[4 * j + 2] = q.z; r[4 * j + 3] = q.w;
+    }
+  } else if constexpr (N % 2 == 0) {
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j) { float2 q = reinterpret_cast<const float2*>(p)[j]; r[2 * j] = q.x; r[2 * j + 1] = q.y; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < N; ++j) r[j] = p[j];
+  }
+}
+
+template <int IN, int OUT, bool TANH, bool TO_LDS>
+TB_DEV void dense(const float* w, float* act, int lane, float* y) {
+  constexpr int U = OUT >= 64 ? 1 : OUT >= 32 ? (IN % 4 == 0 ? 2 : 1) : 4;  // inputs per half-trip
+  // a block of U rows starts 16-byte aligned only if OUT is a multiple of 4 (layers are; heads are not)
+  constexpr int BLK = (OUT % 4 == 0) ? U * OUT : (OUT % 2 == 0 ? 2 : 1);
+  static_assert(IN % (2 * U) == 0 && (!TO_LDS || OUT % 4 == 0), "layer shape");
+  float acc[OUT], wa[U * OUT], xa[U], wb[U * OUT], xb[U];
+#pragma unroll
+  for (int o = 0; o < OUT; ++o) acc[o] = w[o];
+  const float* wk = w + OUT;
+  auto fetch = [&](int k, float (&wr)[U * OUT], float (&xr)[U]) {
+    if constexpr (BLK == U * OUT) {
+      lds_read_block<U * OUT>(wk + k * OUT, wr);
+    } else {
+#pragma unroll
+      for (int j = 0; j < U * OUT / BLK; ++j) {
+        float t[BLK];
+        lds_read_block<BLK>(wk + k * OUT + j * BLK, t);
+#pragma unroll
+        for (int q = 0; q < BLK; ++q) wr[j * BLK + q] = t[q];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) xr[u] = act[act_index(k + u, lane)];
+  };
+  auto fmas = [&](const float (&wr)[U * OUT], const float (&xr)[U]) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if constexpr (OUT % 2 == 0) {
+        const f32x2 xk = {xr[u], xr[u]};
+#pragma unroll
+        for (int o = 0; o < OUT; o += 2) {
+          f32x2 a2 = {acc[o], acc[o + 1]}, w2 = {wr[u * OUT + o], wr[u * OUT + o + 1]};
+          a2 = __builtin_elementwise_fma(w2, xk, a2);
+          acc[o] = a2.x; acc[o + 1] = a2.y;
+        }
+      } else {
+#pragma unroll
+        for (int o = 0; o < OUT; ++o) acc[o] = FMA(wr[u * OUT + o], xr[u], acc[o]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  fetch(0, wa, xa);
+#pragma unroll 1
+  for (int k = 0; k < IN; k += 2 * U) {  // two half-trips ping-pong between the register sets
+    fetch(k + U, wb, xb);
+    fmas(wa, xa);
+    fetch(k + 2 * U < IN ? k + 2 * U : k, wa, xa);  // (the last trip re-reads its own block: in bounds)
+    fmas(wb, xb);
+  }
+  if constexpr (TO_LDS) {
+#pragma unroll
+    for (int o = 0; o < OUT / 4; ++o) {
+      float4 q = {acc[4 * o], acc[4 * o + 1], acc[4 * o + 2], acc[4 * o + 3]};
+      if (TANH) { q.x = fast_tanh(q.x); q.y = fast_tanh(q.y); q.z = fast_tanh(q.z); q.w = fast_tanh(q.w); }
+      *reinterpret_cast<float4*>(act + (o * 64 + lane) * 4) = q;
+    }
+  } else {
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) y[o] = TANH ? fast_tanh(acc[o]) : acc[o];
+  }
+}
+// one tower and its head: obs (already in `act`) -> head outputs in registers
+template <int KIND, int NOUT>
+TB_DEV void tower(const float* w, float* act, int lane, float* y) {
+  using N = PolicyNet<KIND>;
+  constexpr int O = Dims<KIND>::O;
+  dense<O, N::H0, true, true>(w, act, lane, nullptr);
+  w += layer_floats(O, N::H0);
+  dense<N::H0, N::H1, true, true>(w, act, lane, nullptr);
+  w += layer_floats(N::H0, N::H1);
+  if constexpr (N::NH == 3) {
+    dense<N::H1, N::H2, true, true>(w, act, lane, nullptr);
+    w += layer_floats(N::H1, N::H2);
+  }
+  dense<N::LAST, NOUT, false, false>(w, act, lane, y);
+}
+// standard normals from Philox bits (Box-Muller); keyed by (seed, global env id, episode, step):
+// no host-side counter, so a captured graph draws fresh noise on every replay
+template <int NA>
+TB_DEV void policy_noise(unsigned long long seed, unsigned long long env_id, uint32_t episode, int step_count, float* eps) {
+  uint32_t u[4];
+#pragma unroll
+  for (int blk = 0; blk < (NA + 3) / 4; ++blk) {
+    philox4x32((uint32_t)env_id, (uint32_t)(env_id >> 32), episode, (uint32_t)step_count * 4u + (uint32_t)blk, (uint32_t)seed,
+               (uint32_t)(seed >> 32) ^ 0x504F4C49u, u);
+#pragma unroll
+    for (int pair = 0; pair < 2; ++pair) {
+      float u1 = ((float)(u[2 * pair] >> 8) + 1.0f) * 5.9604644775390625e-08f;  // (0, 1]
+      float u2 = (float)(u[2 * pair + 1] >> 8) * 5.9604644775390625e-08f;         // [0, 1)
+      float r = sqrtf(-2.0f * logf(u1)), th = 6.283185307179586f * u2;
+      if (4 * blk + 2 * pair < NA) eps[4 * blk + 2 * pair] = r * cosf(th);
+      if (4 * blk + 2 * pair + 1 < NA) eps[4 * blk + 2 * pair + 1] = r * sinf(th);
+    }
+  }
+}
+// The two towers are independent until the very end, so each 64-env group gets TWO waves (one
+// 128-thread workgroup): wave 0 runs the pi tower, samples, and goes on to step the envs; wave 1 runs
+// the vf tower, writes the values and retires.
+template <int KIND>
+TB_DEV void policy_obs_to_lds(const KArgs& A, int i, int lane, float* act) {
+  constexpr int NO = Dims<KIND>::O;
+  if constexpr (NO % 4 == 0) {
+    const float4* p = reinterpret_cast<const float4*>(A.pol_obs + (size_t)i * NO);
+#pragma unroll
+    for (int k = 0; k < NO / 4; ++k) *reinterpret_cast<float4*>(act + (k * 64 + lane) * 4) = p[k];
+  } else {
+    const float2* p = reinterpret_cast<const float2*>(A.pol_obs + (size_t)i * NO);
+#pragma unroll
+    for (int k = 0; k < NO / 2; ++k) *reinterpret_cast<float2*>(act + act_index(2 * k, lane)) = p[k];
+  }
+}
+template <int KIND>
+TB_DEV void policy_value(const KArgs& A, const float* s_w, float* act, int i, int lane) {
+  constexpr int NA = Dims<KIND>::A, LAST = PolicyNet<KIND>::LAST;
+  float v[1];
+  policy_obs_to_lds<KIND>(A, i, lane, act);
+  tower<KIND, 1>(s_w + tower_floats<KIND>() + layer_floats(LAST, NA), act, lane, v);
+  A.pol_value[i] = v[0];
+}
+template <int KIND>
+TB_DEV void policy_act(const KArgs& A, const float* s_w, float* act, int i, int lane, const EnvRegs& e, float* a) {
+  constexpr int NA = Dims<KIND>::A, LAST = PolicyNet<KIND>::LAST;
+  float mean[NA];
+  policy_obs_to_lds<KIND>(A, i, lane, act);
+  tower<KIND, NA>(s_w, act, lane, mean);
+  const float* log_std = s_w + 2 * tower_floats<KIND>() + layer_floats(LAST, NA) + layer_floats(LAST, 1);
+  float eps[NA], logp = 0.0f;
+  if (!A.pol_deterministic) policy_noise<NA>(A.pol_seed, A.env_id_base + (unsigned long long)i, e.episode, e.step_count, eps);
+#pragma unroll
+  for (int k = 0; k < NA; ++k) {
+    float ek = A.pol_deterministic ? 0.0f : eps[k];
+    float raw = FMA(expf(log_std[k]), ek, mean[k]);
+    logp += FMA(-0.5f * ek, ek, -log_std[k]) - 0.9189385332046727f;  // -(eps^2)/2 - log_std - ln(2 pi)/2
+    A.pol_raw[(size_t)i * NA + k] = raw;
+    a[k] = fminf(fmaxf(raw, -1.0f), 1.0f);  // SB3 clips Box actions before env.step
+    A.pol_actions[(size_t)i * NA + k] = a[k];
+  }
+  A.pol_logp[i] = logp;
+}
+
 // LEAN (SwingRacket only): every lane that would start a fast-forward is parked for tb_ff_kernel, so
 // the loop is not compiled into this kernel at all -- the pipelined path's step kernel. Its code is
 // a third of the full kernel's, which is worth ~1.5 us of a ~7 us launch at 4096 envs.
 // MULTI: A.T agent steps in one launch (tb_rollout); otherwise exactly one (tb_step). A compile-time
 // trip count of 1 is worth ~50-100 VGPRs (no loop-carried copies of the per-step bookkeeping), i.e.
 // one to two more waves per SIMD for the kernel every RL step launches.
-template <int KIND, bool LEAN, bool MULTI, bool RG>
+// POLICY: the actions are not read from memory but inferred in-kernel (tb_policy_step).
+template <int KIND, bool LEAN, bool MULTI, bool RG, bool POLICY = false>
 __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
   constexpr int NA = Dims<KIND>::A, NO = Dims<KIND>::O;
   __shared__ float4 s_hull[TB_MAX_HULL * 2];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float s_pol[POLICY ? (policy_floats<KIND>() + 3) / 4 * 4 : 4];
+  __shared__ __attribute__((aligned(16))) float s_act[POLICY ? 2 * 64 * 64 : 4];  // [role][k / U][lane][U]
+  // POLICY: 128-thread workgroups, two waves ("roles") per 64 envs -- see policy_act
+  const int i = POLICY ? blockIdx.x * 64 + (threadIdx.x & 63) : blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < A.n;
   EnvRegs e;
 #ifdef TB_DIAG_STAMPS
@@ -317,11 +535,23 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
   // issue every load this launch depends on back to back -- state rows, the first step's actions,
   // the outline table -- so that their latencies overlap instead of queueing behind the barrier
   float a[NA];
-  if (live) {
+  if (live && !(POLICY && threadIdx.x >= 64)) {
     load_env<KIND>(A.words, A.done_state, A.n, i, e);
-    load_actions<KIND>(A.actions, (size_t)i, a);
+    if (!POLICY) load_actions<KIND>(A.actions, (size_t)i, a);
   }
-  stage_hull(s_hull, A);
+  if (POLICY) {  // stage the packed towers (16-byte chunks; the blob is padded to a multiple of 4 floats)
+    const float4* src = reinterpret_cast<const float4*>(A.pol_weights);
+    float4* dst = reinterpret_cast<float4*>(s_pol);
+    for (int k = threadIdx.x; k < (policy_floats<KIND>() + 3) / 4; k += blockDim.x) dst[k] = src[k];
+  }
+  stage_hull(s_hull, A);  // (its barrier also publishes s_pol)
+  if (POLICY) {
+    if (threadIdx.x >= 64) {  // the vf wave: no barrier below this point, so it may simply leave
+      if (live) policy_value<KIND>(A, s_pol, s_act + 64 * 64, i, threadIdx.x & 63);
+      return;
+    }
+    if (live) policy_act<KIND>(A, s_pol, s_act, i, threadIdx.x, e, a);
+  }
 #ifdef TB_DIAG_STAMPS
   if (live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const unsigned long long t_loaded = stamp_now();
@@ -344,7 +574,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
     const int n_steps = MULTI ? A.T : 1;
     for (int t = 0; t < n_steps; ++t) {
       const size_t row = (size_t)t * A.n + i;
-      if (t > 0) load_actions<KIND>(A.actions, row, a);
+      if (!POLICY && t > 0) load_actions<KIND>(A.actions, row, a);
       float o[NO];
       int ns = 1;
       bool d, parked = false;
@@ -624,10 +854,21 @@ int wait_side(TbHandle* h, hipStream_t s) {
   return TB_OK;
 }
 
-int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* reward, uint8_t* done, float* term, int32_t* substeps, hipStream_t s) {
+struct PolicyIO {  // non-null weights = fused policy step
+  const float* weights; const float* obs_in; float* actions; float* raw; float* logp; float* value;
+  unsigned long long seed; int deterministic;
+};
+
+int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* reward, uint8_t* done, float* term, int32_t* substeps, hipStream_t s,
+                const PolicyIO* pol = nullptr) {
   KArgs a = base_args(h);
+  if (pol) {
+    a.pol_weights = pol->weights; a.pol_obs = pol->obs_in; a.pol_actions = pol->actions; a.pol_raw = pol->raw; a.pol_logp = pol->logp;
+    a.pol_value = pol->value; a.pol_seed = pol->seed; a.pol_deterministic = pol->deterministic;
+  }
   a.actions = actions; a.obs = obs; a.reward = reward; a.done_out = done; a.term_obs = term; a.substeps = substeps; a.T = T;
   dim3 grid((unsigned)((h->n + h->block - 1) / h->block)), block((unsigned)h->block);
+  if (pol) { grid = dim3((unsigned)((h->n + 63) / 64)); block = dim3(128); }  // two waves per 64 envs
   // Pipelined SwingRacket: the step kernel never loops (LEAN); a lane that starts a fast-forward is
   // parked and tb_ff_kernel finishes it on a side stream. When the host knows the episode phase (all
   // envs were reset together; episodes are exactly 26 steps) only the 26th call can park anything, so
@@ -645,7 +886,8 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
   const bool rg = (h->kp.flags & TB_F_RACKET_GROUND) != 0;  // selects the instantiation that contains racket<->court contact
 #define TB_LAUNCH_STEP(KIND, LEAN, MULTI)                                                                      \
   do {                                                                                                         \
-    if (rg) hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, MULTI, true>), grid, block, 0, s, a);                \
+    if (pol) hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, false, false, true>), grid, block, 0, s, a);        \
+    else if (rg) hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, MULTI, true>), grid, block, 0, s, a);           \
     else hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, MULTI, false>), grid, block, 0, s, a);                  \
   } while (0)
   if (T > 1) {
@@ -819,6 +1061,20 @@ int tb_step(TbHandle* h, const float* actions_dev, float* obs_dev, float* reward
   if (!h || !actions_dev || !obs_dev || !reward_dev || !done_dev) return fail(TB_E_INVAL, "tb_step: null argument");
   DeviceGuard g(h->device);
   return launch_step(h, 1, actions_dev, obs_dev, reward_dev, done_dev, terminal_obs_dev, substeps_dev, (hipStream_t)stream);
+}
+
+int tb_policy_floats(int env_kind) {
+  return env_kind == TB_ENV_SWING ? policy_floats<TB_ENV_SWING>() : env_kind == TB_ENV_TENNIS ? policy_floats<TB_ENV_TENNIS>() : TB_E_INVAL;
+}
+
+int tb_policy_step(TbHandle* h, const float* weights_dev, const float* obs_in_dev, float* actions_dev, float* raw_actions_dev, float* logp_dev,
+                   float* value_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, uint64_t noise_seed, int deterministic, void* stream) {
+  if (!h || !weights_dev || !obs_in_dev || !actions_dev || !raw_actions_dev || !logp_dev || !value_dev || !obs_dev || !reward_dev || !done_dev)
+    return fail(TB_E_INVAL, "tb_policy_step: null argument");
+  if (h->kp.flags & TB_F_RACKET_GROUND) return fail(TB_E_UNSUPPORTED, "tb_policy_step is not instantiated with TB_F_RACKET_GROUND");
+  DeviceGuard g(h->device);
+  PolicyIO pol = {weights_dev, obs_in_dev, actions_dev, raw_actions_dev, logp_dev, value_dev, noise_seed, deterministic};
+  return launch_step(h, 1, nullptr, obs_dev, reward_dev, done_dev, nullptr, nullptr, (hipStream_t)stream, &pol);
 }
 
 int tb_rollout(TbHandle* h, int n_steps, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev,

@@ -81,11 +81,37 @@ def build_actor_critic(obs_dim, act_dim, net_arch=(32, 64, 32)):
     return ActorCritic()
 
 
+def pack_policy(policy, out=None):
+    """The blob `tb_policy_step` reads (include/tb_stepper.h): pi tower layers, action head, vf tower
+    layers, value head, log_std; each layer = bias[out] then W transposed to [in][out], zero-padded to
+    a multiple of 4 floats (16-byte aligned layers for the kernel's LDS vector reads).
+    `out`: a preallocated device tensor to refresh in place (its address is baked into captured graphs)."""
+    import torch
+    parts = []
+
+    def layer(m):
+        n = m.bias.numel() + m.weight.numel()
+        parts.extend([m.bias.detach().float(), m.weight.detach().float().t().reshape(-1), torch.zeros(-n % 4, device=m.weight.device)])
+    for body, head in ((policy.policy_net, policy.action_net), (policy.value_net_body, policy.value_net)):
+        for m in body:
+            if isinstance(m, torch.nn.Linear):
+                layer(m)
+        layer(head)
+    parts.append(policy.log_std.detach().float())
+    n = sum(p.numel() for p in parts)
+    parts.append(torch.zeros(-n % 4, device=parts[0].device))
+    flat = torch.cat(parts)
+    if out is None:
+        return flat.contiguous()
+    out.copy_(flat)
+    return out
+
+
 class PPOTrainer:
     """clipped-surrogate PPO over a BatchedEnv; one process per GPU when distributed"""
 
     def __init__(self, env_id="SwingRacket-v0", num_envs=4096, n_steps=104, device=None, seed=0, batch_size=None,
-                 pipeline=True, graph=True, **hp):
+                 pipeline=True, graph=True, fused=True, **hp):
         import torch
         self.torch = torch
         kind = ENV_IDS[env_id]
@@ -114,10 +140,40 @@ class PPOTrainer:
         self.obs_in = self.env.reset().clone()  # static input of the (captured) rollout
         self.use_graph, self._graph = bool(graph), None
         self.num_timesteps = 0
+        # fused=True: the policy runs inside the step kernel (tb_policy_step); the torch module is
+        # then only the learner's view of the same weights, repacked once per rollout
+        self.fused = bool(fused) and tuple(d["net_arch"]) == tuple((SWING_DEFAULTS if kind == ENV_SWING else TENNIS_DEFAULTS)["net_arch"])
+        self.noise_seed = (seed * 1000003 + 7919 * (self.rank + 1)) & 0xFFFFFFFF
+        self._rollouts = 0
+        if self.fused:
+            self.packed = pack_policy(self.policy)
+            assert self.packed.numel() == (self.env.policy_floats() + 3) // 4 * 4
 
     # ------------------------------------------------------------------ collect
+    def _collect_fused(self):
+        """the rollout as n_steps launches of the fused policy+step kernel (plus the side-stream
+        fast-forwards): no library GEMM, no sampling kernels, nothing between two env steps"""
+        buf, env = self.buf, self.env
+        n, O, A = self.num_envs, env.obs_dim, env.act_dim
+        wp, cur = self.packed.data_ptr(), self.obs_in.data_ptr()
+        self.obs_seq[0].copy_(self.obs_in)
+        for k in range(self.n_steps):
+            obs_k = buf.obs[k]
+            # exploration noise is keyed by (seed, env, episode, step) inside the kernel: replaying
+            # the captured graph draws fresh noise because episodes / steps advance
+            env.policy_step_ptrs(wp, cur, buf.actions[k].data_ptr(), self._raw_actions[k].data_ptr(), self.logps[k].data_ptr(),
+                                 self.values[k].data_ptr(), obs_k.data_ptr(), buf.rewards[k].data_ptr(), buf.dones[k].data_ptr(), self.noise_seed)
+            cur = obs_k.data_ptr()
+        env.flush()
+        self.obs_seq[1:].copy_(buf.obs[:-1])
+        last = buf.obs[self.n_steps - 1]
+        self.last_value.copy_(self.policy(last)[1])
+        self.obs_in.copy_(last)
+
     def _collect_body(self):
         t = self.torch
+        if self.fused:
+            return self._collect_fused()
         buf, env = self.buf, self.env
         cur = self.obs_in
         for k in range(self.n_steps):
@@ -138,6 +194,8 @@ class PPOTrainer:
         the whole rollout -- policy forward, sampling, env step, side-stream fast-forwards -- is
         captured once as a hipGraph and replayed (fixed buffers, in-place parameter updates)."""
         t = self.torch
+        if self.fused:
+            pack_policy(self.policy, out=self.packed)
         with t.no_grad():
             if self.use_graph and self._graph is None:
                 try:

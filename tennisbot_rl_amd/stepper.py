@@ -63,6 +63,10 @@ def load_library():
     L.tb_flush.restype = i32
     L.tb_pipeline_sync.argtypes = [vp, i32]
     L.tb_pipeline_sync.restype = i32
+    L.tb_policy_floats.argtypes = [i32]
+    L.tb_policy_floats.restype = i32
+    L.tb_policy_step.argtypes = [vp] * 10 + [u64, i32, vp]
+    L.tb_policy_step.restype = i32
     L.tb_diag_stream_copy.argtypes = [vp, vp, i32, i32, i32, vp]
     L.tb_diag_stream_copy.restype = i32
     for f in ("tb_create", "tb_destroy", "tb_set_params", "tb_reset", "tb_step", "tb_rollout", "tb_get_state",
@@ -217,6 +221,46 @@ class BatchedEnv:
                             self.torch.cuda.current_stream(self.device).cuda_stream)
         if rc:
             _check(self.L, rc, "tb_step")
+
+    def policy_floats(self):
+        """length of the packed MlpPolicy blob tb_policy_step expects for this env kind"""
+        return int(self.L.tb_policy_floats(self.kind))
+
+    def policy_step(self, weights, obs_in, seed=0, deterministic=False, out=None, policy_out=None):
+        """step() with SB3's MlpPolicy evaluated inside the step kernel (tb_policy_step): each env
+        acts on its row of `obs_in`. weights: the packed blob of `ppo.pack_policy` (padded to a
+        multiple of 4 floats). Returns ((obs, reward, done), (actions, raw_actions, logp, value));
+        `out` / `policy_out` are optional tuples of preallocated tensors of those shapes."""
+        t, n = self.torch, self.num_envs
+        nf = (self.policy_floats() + 3) // 4 * 4
+        w = self._check_tensor(weights, (nf,), t.float32, "weights")
+        if w.data_ptr() % 16:
+            raise ValueError("weights must be 16-byte aligned")
+        oi = self._check_tensor(obs_in, (n, self.obs_dim), t.float32, "obs_in")
+        obs, rew, done = self._out() if out is None else out
+        self._check_tensor(obs, (n, self.obs_dim), t.float32, "out[0]")
+        self._check_tensor(rew, (n,), t.float32, "out[1]")
+        self._check_tensor(done, (n,), t.uint8, "out[2]")
+        if policy_out is None:
+            policy_out = (t.empty((n, self.act_dim), dtype=t.float32, device=self.device), t.empty((n, self.act_dim), dtype=t.float32, device=self.device),
+                          t.empty(n, dtype=t.float32, device=self.device), t.empty(n, dtype=t.float32, device=self.device))
+        act, raw, logp, value = policy_out
+        self._check_tensor(act, (n, self.act_dim), t.float32, "policy_out[0]")
+        self._check_tensor(raw, (n, self.act_dim), t.float32, "policy_out[1]")
+        self._check_tensor(logp, (n,), t.float32, "policy_out[2]")
+        self._check_tensor(value, (n,), t.float32, "policy_out[3]")
+        self.policy_step_ptrs(w.data_ptr(), oi.data_ptr(), act.data_ptr(), raw.data_ptr(), logp.data_ptr(), value.data_ptr(),
+                              obs.data_ptr(), rew.data_ptr(), done.data_ptr(), seed, deterministic)
+        if self.pipeline and out is None:
+            self._inflight.append(rew)
+        return (obs, rew, done), (act, raw, logp, value)
+
+    def policy_step_ptrs(self, weights_ptr, obs_in_ptr, act_ptr, raw_ptr, logp_ptr, value_ptr, obs_ptr, reward_ptr, done_ptr, seed, deterministic=False):
+        """unchecked fast path of policy_step (raw device addresses, validated once by the caller)"""
+        rc = self.L.tb_policy_step(self._h, weights_ptr, obs_in_ptr, act_ptr, raw_ptr, logp_ptr, value_ptr, obs_ptr, reward_ptr, done_ptr,
+                                   int(seed) & 0xFFFFFFFFFFFFFFFF, 1 if deterministic else 0, self.torch.cuda.current_stream(self.device).cuda_stream)
+        if rc:
+            _check(self.L, rc, "tb_policy_step")
 
     def capture(self, fn):
         """Capture `fn()` -- a fixed sequence of step()/step_ptrs()/RolloutBuffer.step_into calls on

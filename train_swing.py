@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--gui", action="store_true", help="accepted for CLI compatibility; there is no GUI")
     ap.add_argument("-s", "--select", default="ppo", help="only ppo is provided (sac / tqc / trpo are third-party learners)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-fused", action="store_true", help="run the policy as torch modules between env steps instead of inside the step kernel")
     ap.add_argument("--log-json", type=str, default=None)
     args = ap.parse_args()
     if args.select != "ppo":
@@ -58,7 +59,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.distributed.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     total = args.total_timesteps or (2e6 if args.env == "SwingRacket-v0" else 1e6)
-    tr = PPOTrainer(args.env, num_envs=args.num_envs, n_steps=args.n_steps, device=torch.device("cuda", local_rank), seed=args.seed)
+    tr = PPOTrainer(args.env, num_envs=args.num_envs, n_steps=args.n_steps, device=torch.device("cuda", local_rank), seed=args.seed,
+                    fused=not args.no_fused)
     if args.load_reference:
         import numpy as np
         tr.policy.load_sb3_arrays(dict(np.load(os.path.join(ROOT, "tests", "golden", "ppo_swing_policy.npz"))))
