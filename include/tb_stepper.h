@@ -210,10 +210,17 @@ int tb_rollout(TbHandle *h, int n_steps, const float *actions_dev, float *obs_de
  * * eps, clipped to the action space before the env sees it, as SB3 does. Per env i:
  *   obs_in_dev [N][O] the observation acted on  ->  actions_dev [N][A] (clipped), raw_actions_dev [N][A],
  *   logp_dev [N] (log-probability of the raw sample), value_dev [N]; then exactly tb_step on those actions.
- * weights_dev: tb_policy_floats(kind) floats, 16-byte aligned: the pi tower's layers, the action head,
- * the vf tower's layers, the value head, log_std[A]; each layer = bias[out] then W transposed to
- * [in][out], zero-padded to a multiple of 4 floats. tanh is evaluated as 1 - 2/(exp(2x)+1) on the
- * hardware exp2/rcp units (absolute error < 3e-7). eps is drawn in-kernel from Philox keyed by (noise_seed, global env id, episode, step), so
+ * The towers run on the matrix cores in exact fp32 (v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain),
+ * one layer's accumulator tile feeding the next layer's operand registers directly; tanh is evaluated
+ * as 1 - 2/(exp(2x)+1) on the hardware exp2/rcp units (absolute error < 3e-7).
+ * weights_dev: tb_policy_floats(kind) floats, 16-byte aligned, in the fragment order the kernel loads:
+ * per tower (pi, then vf) its hidden layers and its head (padded to 32 outputs), each layer as
+ *   bias tiles     [ceil(out/32)][2][16]: value (t, h, r) = bias[32t + (r&3) + 8(r>>2) + 4h]
+ *   weight frags   [ceil(out/32)][pairs][2][32]: value (t, p, h, j) = W[out 32t + j][in k(p, h)]
+ * with k(p, h) = 2p + h for the first layer and k(16u + r, h) = 32u + (r&3) + 8(r>>2) + 4h after it
+ * (W = torch's nn.Linear.weight, zero beyond `out`); then log_std[A] padded to a multiple of 4.
+ * tennisbot_rl_amd/ppo.py pack_policy() is the reference packer. eps is drawn in-kernel from Philox
+ * keyed by (noise_seed, global env id, episode, step), so
  * a captured graph draws fresh noise on every replay; deterministic != 0 uses the mean.
  */
 int tb_policy_floats(int env_kind);

@@ -311,143 +311,116 @@ TB_DEV void stage_hull(float4* s_hull, const KArgs& A) {
 // Policy inference fused into the step kernel: SB3's MlpPolicy with separate pi / vf
 // towers as the reference configures it -- SwingRacket 6 -> 32 -> 64 -> 32 (train_swing.py:80-82),
 // Tennisbot 12 -> 64 -> 64 (SB3 default, train.py:104-110) -- tanh hidden layers, linear action mean,
-// state-independent log_std, a = mean + std * eps. One lane = one env; the towers' weights are staged
-// once per workgroup into LDS. ~9 k FMAs per env-step: VALU work (v_pk_fma_f32) next to a
-// launch-latency-bound step; fp32 MFMA has the same peak as packed fp32 VALU on CDNA, so there is no
-// matrix-core shortcut at 64 envs per wave without dropping the learner's precision.
-// Packed weights: pi tower layers, action head, vf tower layers, value head, log_std[A]; each layer as
-// described at layer_floats() below, exactly as tennisbot_rl_amd/ppo.py pack_policy() writes them.
+// state-independent log_std, a = mean + std * eps.
+//
+// The towers run on the matrix cores in exact fp32 (v_mfma_f32_32x32x2_f32: bitwise a k-ordered fmaf
+// chain, same peak as packed VALU FMA, but ONE VGPR per operand fragment instead of a broadcast weight
+// per FMA -- a first VALU version spent its time re-reading weights out of LDS). Each layer is computed
+// TRANSPOSED, H^T[out][env] = W^T[out][k] * X^T[k][env], 32 envs per wave: the weight fragment is the A
+// operand, the activations the B operand, and -- the point of the transposition -- the C/D layout of one
+// layer's output (lane = env, 16 registers = rows (r&3) + 8(r>>2) + 4(lane>>5)) IS the B layout of the
+// next layer's input if the k-pairs are taken in that row order: register r of the output tile feeds
+// "pair r" (k = row(r) on lanes 0-31, row(r)+4 on lanes 32-63). pack_policy() permutes the weights to
+// match, so activations never leave the registers: no LDS, no shuffles, no barrier between layers. The
+// k-sum order is that permutation (a fixed order; vs. torch within 1e-6).
+// Four waves per 64 envs: {pi, vf} x {envs 0-31, 32-63}, independent until the pi waves hand the action
+// means to wave 0 through LDS; wave 0 then samples and steps all 64 envs, the others retire.
+// Blob, per tower and layer: bias tiles [out/32][2 halves][16 regs], then weight fragments
+// [out/32][pairs][2][32] -- i.e. exactly what lane l loads at index l; heads padded to 32 outputs.
 template <int KIND> struct PolicyNet;
 template <> struct PolicyNet<TB_ENV_SWING> { static constexpr int NH = 3, H0 = 32, H1 = 64, H2 = 32, LAST = 32; };
 template <> struct PolicyNet<TB_ENV_TENNIS> { static constexpr int NH = 2, H0 = 64, H1 = 64, H2 = 64, LAST = 64; };
-// one dense layer in the blob: bias[OUT], then W transposed to [IN][OUT] (so the weights of adjacent
-// outputs for one input are adjacent: one 16-byte LDS broadcast read feeds two packed FMAs), padded to a
-// multiple of 4 floats so that every layer starts 16-byte aligned
-constexpr int layer_floats(int in, int out) { return (out + in * out + 3) / 4 * 4; }
-template <int KIND> constexpr int tower_floats() {
+constexpr int layer_floats(int in, int out) { return ((out + 31) / 32) * (32 + (in / 2) * 64); }
+template <int KIND> constexpr int tower_floats() {  // hidden layers + the (padded) head
   using N = PolicyNet<KIND>;
-  constexpr int O = Dims<KIND>::O;
-  return layer_floats(O, N::H0) + layer_floats(N::H0, N::H1) + (N::NH == 3 ? layer_floats(N::H1, N::H2) : 0);
+  return layer_floats(Dims<KIND>::O, N::H0) + layer_floats(N::H0, N::H1) + (N::NH == 3 ? layer_floats(N::H1, N::H2) : 0) + layer_floats(N::LAST, 32);
 }
-template <int KIND> constexpr int policy_floats() {
-  return 2 * tower_floats<KIND>() + layer_floats(PolicyNet<KIND>::LAST, Dims<KIND>::A) + layer_floats(PolicyNet<KIND>::LAST, 1) + Dims<KIND>::A;
-}
+template <int KIND> constexpr int policy_floats() { return 2 * tower_floats<KIND>() + (Dims<KIND>::A + 3) / 4 * 4; }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 // tanh(x) = 1 - 2 / (e^(2x) + 1) on the hardware exp2 / rcp units (1 ulp each): absolute error < 3e-7,
-// saturates correctly at +-inf. 5 instructions instead of libm's ~40: 256 tanh per env-step otherwise
-// cost as much as all the FMAs.
+// saturates correctly at +-inf; 5 instructions instead of libm's ~40
 TB_DEV float fast_tanh(float x) {
   float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
   return FMA(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
-// y = act(b + W x) for the 64 envs of one wave. The activations live in LDS, interleaved per lane in
-// groups of 4 ([k / 4][lane][4]: conflict-free, and each lane only ever touches its own column, so a
-// layer overwrites its input in place without a barrier). The input loop is a REAL loop, software-
-// pipelined by hand: the weights of the next U inputs (U * OUT = 64 floats, wave-wide LDS broadcast
-// reads) are fetched into a second register set before the packed FMAs of the current ones run, with a
-// scheduling barrier between the two -- left to itself the compiler either issues every LDS read of a
-// fully unrolled layer first (34 KB of spills per lane) or one read per two FMAs with a full wait on
-// each. Per input: OUT independent accumulator chains (a lone wave per SIMD has no other wave to hide
-// FMA latency behind), two outputs per v_pk_fma_f32.
-TB_DEV int act_index(int k, int lane) { return ((k >> 2) * 64 + lane) * 4 + (k & 3); }
 
-template <int N>
-TB_DEV void lds_read_block(const float* p, float (&r)[N]) {  // N contiguous floats, widest aligned vectors
-  if constexpr (N % 4 == 0) {
+// one layer's operands for this lane: NT bias tiles (16 floats each) and NT * NP weight fragments
+template <int NT, int NP>
+struct LayerRegs {
+  f32x16 bias[NT];
+  float frag[NT * NP];
+  TB_DEV void load(const float* g, int lane) {
+    const int h = lane >> 5;
 #pragma unroll
-    for (int j = 0; j < N / 4; ++j) {
-      float4 q = reinterpret_cast<const float4*>(p)[j];
-      r[4 * j] = q.x; r[4 * j + 1] = q.y; r[4 * j + 2] = q.z; r[4 * j + 3] = q.w;
-    }
-  } else if constexpr (N % 2 == 0) {
+    for (int t = 0; t < NT; ++t) {
+      const float4* p = reinterpret_cast<const float4*>(g + t * 32 + h * 16);
 #pragma unroll
-    for (int j = 0; j < N / 2; ++j) { float2 q = reinterpret_cast<const float2*>(p)[j]; r[2 * j] = q.x; r[2 * j + 1] = q.y; }
-  } else {
-#pragma unroll
-    for (int j = 0; j < N; ++j) r[j] = p[j];
-  }
-}
-
-template <int IN, int OUT, bool TANH, bool TO_LDS>
-TB_DEV void dense(const float* w, float* act, int lane, float* y) {
-  constexpr int U = OUT >= 64 ? 1 : OUT >= 32 ? (IN % 4 == 0 ? 2 : 1) : 4;  // inputs per half-trip
-  // a block of U rows starts 16-byte aligned only if OUT is a multiple of 4 (layers are; heads are not)
-  constexpr int BLK = (OUT % 4 == 0) ? U * OUT : (OUT % 2 == 0 ? 2 : 1);
-  static_assert(IN % (2 * U) == 0 && (!TO_LDS || OUT % 4 == 0), "layer shape");
-  float acc[OUT], wa[U * OUT], xa[U], wb[U * OUT], xb[U];
-#pragma unroll
-  for (int o = 0; o < OUT; ++o) acc[o] = w[o];
-  const float* wk = w + OUT;
-  auto fetch = [&](int k, float (&wr)[U * OUT], float (&xr)[U]) {
-    if constexpr (BLK == U * OUT) {
-      lds_read_block<U * OUT>(wk + k * OUT, wr);
-    } else {
-#pragma unroll
-      for (int j = 0; j < U * OUT / BLK; ++j) {
-        float t[BLK];
-        lds_read_block<BLK>(wk + k * OUT + j * BLK, t);
-#pragma unroll
-        for (int q = 0; q < BLK; ++q) wr[j * BLK + q] = t[q];
+      for (int q = 0; q < 4; ++q) {
+        float4 v = p[q];
+        bias[t][4 * q] = v.x; bias[t][4 * q + 1] = v.y; bias[t][4 * q + 2] = v.z; bias[t][4 * q + 3] = v.w;
       }
     }
+    g += NT * 32;
 #pragma unroll
-    for (int u = 0; u < U; ++u) xr[u] = act[act_index(k + u, lane)];
-  };
-  auto fmas = [&](const float (&wr)[U * OUT], const float (&xr)[U]) {
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if constexpr (OUT % 2 == 0) {
-        const f32x2 xk = {xr[u], xr[u]};
-#pragma unroll
-        for (int o = 0; o < OUT; o += 2) {
-          f32x2 a2 = {acc[o], acc[o + 1]}, w2 = {wr[u * OUT + o], wr[u * OUT + o + 1]};
-          a2 = __builtin_elementwise_fma(w2, xk, a2);
-          acc[o] = a2.x; acc[o + 1] = a2.y;
-        }
-      } else {
-#pragma unroll
-        for (int o = 0; o < OUT; ++o) acc[o] = FMA(wr[u * OUT + o], xr[u], acc[o]);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  fetch(0, wa, xa);
-#pragma unroll 1
-  for (int k = 0; k < IN; k += 2 * U) {  // two half-trips ping-pong between the register sets
-    fetch(k + U, wb, xb);
-    fmas(wa, xa);
-    fetch(k + 2 * U < IN ? k + 2 * U : k, wa, xa);  // (the last trip re-reads its own block: in bounds)
-    fmas(wb, xb);
+    for (int f = 0; f < NT * NP; ++f) frag[f] = g[f * 64 + lane];
   }
-  if constexpr (TO_LDS) {
+  // y[t * 16 + r] = act(bias + sum over pairs): the next layer's B operands, in place
+  template <bool TANH>
+  TB_DEV void apply(const float (&x)[NP], float (&y)[NT * 16]) const {
 #pragma unroll
-    for (int o = 0; o < OUT / 4; ++o) {
-      float4 q = {acc[4 * o], acc[4 * o + 1], acc[4 * o + 2], acc[4 * o + 3]};
-      if (TANH) { q.x = fast_tanh(q.x); q.y = fast_tanh(q.y); q.z = fast_tanh(q.z); q.w = fast_tanh(q.w); }
-      *reinterpret_cast<float4*>(act + (o * 64 + lane) * 4) = q;
+    for (int t = 0; t < NT; ++t) {
+      f32x16 c = bias[t];
+#pragma unroll
+      for (int pr = 0; pr < NP; ++pr) c = __builtin_amdgcn_mfma_f32_32x32x2f32(frag[t * NP + pr], x[pr], c, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) y[t * 16 + r] = TANH ? fast_tanh(c[r]) : c[r];
     }
-  } else {
-#pragma unroll
-    for (int o = 0; o < OUT; ++o) y[o] = TANH ? fast_tanh(acc[o]) : acc[o];
   }
-}
-// one tower and its head: obs (already in `act`) -> head outputs in registers
-template <int KIND, int NOUT>
-TB_DEV void tower(const float* w, float* act, int lane, float* y) {
+};
+
+// one tower for 32 envs: lane l works on env (l & 31); out[0..3] = head rows 0-3 (lanes 0-31) or 4-7
+// (lanes 32-63) of that env. `obs_row`: this lane's env's observation (clamped to a valid env).
+template <int KIND>
+TB_DEV void policy_tower(const float* g, const float* obs_row, int lane, float (&out)[4]) {
   using N = PolicyNet<KIND>;
-  constexpr int O = Dims<KIND>::O;
-  dense<O, N::H0, true, true>(w, act, lane, nullptr);
-  w += layer_floats(O, N::H0);
-  dense<N::H0, N::H1, true, true>(w, act, lane, nullptr);
-  w += layer_floats(N::H0, N::H1);
+  constexpr int O = Dims<KIND>::O, NP0 = O / 2, NT0 = N::H0 / 32, NT1 = N::H1 / 32, NT2 = N::H2 / 32;
+  LayerRegs<NT0, NP0> l0;
+  LayerRegs<NT1, NT0 * 16> l1;
+  // every operand of the tower is requested up front (one VGPR per fragment): the loads of the later
+  // layers land while the earlier ones compute; the barrier keeps the scheduler from sinking each load
+  // down to its MFMA
+  float x0[NP0];
+#pragma unroll
+  for (int pr = 0; pr < NP0; ++pr) x0[pr] = obs_row[2 * pr + (lane >> 5)];
+  l0.load(g, lane);
+  g += layer_floats(O, N::H0);
+  l1.load(g, lane);
+  g += layer_floats(N::H0, N::H1);
+  float h0[NT0 * 16], h1[NT1 * 16], y[16];
   if constexpr (N::NH == 3) {
-    dense<N::H1, N::H2, true, true>(w, act, lane, nullptr);
-    w += layer_floats(N::H1, N::H2);
+    LayerRegs<NT2, NT1 * 16> l2;
+    LayerRegs<1, NT2 * 16> lh;
+    l2.load(g, lane);
+    g += layer_floats(N::H1, N::H2);
+    lh.load(g, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    float h2[NT2 * 16];
+    l0.template apply<true>(x0, h0);
+    l1.template apply<true>(h0, h1);
+    l2.template apply<true>(h1, h2);
+    lh.template apply<false>(h2, y);
+  } else {
+    LayerRegs<1, NT1 * 16> lh;
+    lh.load(g, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    l0.template apply<true>(x0, h0);
+    l1.template apply<true>(h0, h1);
+    lh.template apply<false>(h1, y);
   }
-  dense<N::LAST, NOUT, false, false>(w, act, lane, y);
+  out[0] = y[0]; out[1] = y[1]; out[2] = y[2]; out[3] = y[3];
 }
+
 // standard normals from Philox bits (Box-Muller); keyed by (seed, global env id, episode, step):
 // no host-side counter, so a captured graph draws fresh noise on every replay
 template <int NA>
@@ -467,37 +440,28 @@ TB_DEV void policy_noise(unsigned long long seed, unsigned long long env_id, uin
     }
   }
 }
-// The two towers are independent until the very end, so each 64-env group gets TWO waves (one
-// 128-thread workgroup): wave 0 runs the pi tower, samples, and goes on to step the envs; wave 1 runs
-// the vf tower, writes the values and retires.
+// the tower part: wave w of the workgroup = (tower w >> 1, env half w & 1); the pi waves leave the
+// action means in s_mean[64][8], the vf waves write the values
 template <int KIND>
-TB_DEV void policy_obs_to_lds(const KArgs& A, int i, int lane, float* act) {
+TB_DEV void policy_towers(const KArgs& A, float* s_mean) {
   constexpr int NO = Dims<KIND>::O;
-  if constexpr (NO % 4 == 0) {
-    const float4* p = reinterpret_cast<const float4*>(A.pol_obs + (size_t)i * NO);
-#pragma unroll
-    for (int k = 0; k < NO / 4; ++k) *reinterpret_cast<float4*>(act + (k * 64 + lane) * 4) = p[k];
-  } else {
-    const float2* p = reinterpret_cast<const float2*>(A.pol_obs + (size_t)i * NO);
-#pragma unroll
-    for (int k = 0; k < NO / 2; ++k) *reinterpret_cast<float2*>(act + act_index(2 * k, lane)) = p[k];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tower = wave >> 1, half = wave & 1;
+  const int slot = half * 32 + (lane & 31), env = blockIdx.x * 64 + slot;
+  const int env_c = env < A.n ? env : A.n - 1;
+  float out[4];
+  policy_tower<KIND>(A.pol_weights + tower * tower_floats<KIND>(), A.pol_obs + (size_t)env_c * NO, lane, out);
+  if (tower == 0) {
+    *reinterpret_cast<float4*>(s_mean + slot * 8 + (lane >> 5) * 4) = make_float4(out[0], out[1], out[2], out[3]);
+  } else if (lane < 32 && env < A.n) {
+    A.pol_value[env] = out[0];
   }
 }
+// wave 0, after the workgroup barrier: sample, report, and hand the clipped actions to the env step
 template <int KIND>
-TB_DEV void policy_value(const KArgs& A, const float* s_w, float* act, int i, int lane) {
-  constexpr int NA = Dims<KIND>::A, LAST = PolicyNet<KIND>::LAST;
-  float v[1];
-  policy_obs_to_lds<KIND>(A, i, lane, act);
-  tower<KIND, 1>(s_w + tower_floats<KIND>() + layer_floats(LAST, NA), act, lane, v);
-  A.pol_value[i] = v[0];
-}
-template <int KIND>
-TB_DEV void policy_act(const KArgs& A, const float* s_w, float* act, int i, int lane, const EnvRegs& e, float* a) {
-  constexpr int NA = Dims<KIND>::A, LAST = PolicyNet<KIND>::LAST;
-  float mean[NA];
-  policy_obs_to_lds<KIND>(A, i, lane, act);
-  tower<KIND, NA>(s_w, act, lane, mean);
-  const float* log_std = s_w + 2 * tower_floats<KIND>() + layer_floats(LAST, NA) + layer_floats(LAST, 1);
+TB_DEV void policy_sample(const KArgs& A, const float* s_mean, int i, const EnvRegs& e, float* a) {
+  constexpr int NA = Dims<KIND>::A;
+  const float* log_std = A.pol_weights + 2 * tower_floats<KIND>();
+  const float* mean = s_mean + (threadIdx.x & 63) * 8;
   float eps[NA], logp = 0.0f;
   if (!A.pol_deterministic) policy_noise<NA>(A.pol_seed, A.env_id_base + (unsigned long long)i, e.episode, e.step_count, eps);
 #pragma unroll
@@ -523,9 +487,8 @@ template <int KIND, bool LEAN, bool MULTI, bool RG, bool POLICY = false>
 __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
   constexpr int NA = Dims<KIND>::A, NO = Dims<KIND>::O;
   __shared__ float4 s_hull[TB_MAX_HULL * 2];
-  __shared__ __attribute__((aligned(16))) float s_pol[POLICY ? (policy_floats<KIND>() + 3) / 4 * 4 : 4];
-  __shared__ __attribute__((aligned(16))) float s_act[POLICY ? 2 * 64 * 64 : 4];  // [role][k / U][lane][U]
-  // POLICY: 128-thread workgroups, two waves ("roles") per 64 envs -- see policy_act
+  __shared__ __attribute__((aligned(16))) float s_mean[POLICY ? 64 * 8 : 4];
+  // POLICY: 256-thread workgroups, four waves per 64 envs (see policy_towers); wave 0 steps the envs
   const int i = POLICY ? blockIdx.x * 64 + (threadIdx.x & 63) : blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < A.n;
   EnvRegs e;
@@ -539,18 +502,20 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
     load_env<KIND>(A.words, A.done_state, A.n, i, e);
     if (!POLICY) load_actions<KIND>(A.actions, (size_t)i, a);
   }
-  if (POLICY) {  // stage the packed towers (16-byte chunks; the blob is padded to a multiple of 4 floats)
-    const float4* src = reinterpret_cast<const float4*>(A.pol_weights);
-    float4* dst = reinterpret_cast<float4*>(s_pol);
-    for (int k = threadIdx.x; k < (policy_floats<KIND>() + 3) / 4; k += blockDim.x) dst[k] = src[k];
-  }
-  stage_hull(s_hull, A);  // (its barrier also publishes s_pol)
   if (POLICY) {
-    if (threadIdx.x >= 64) {  // the vf wave: no barrier below this point, so it may simply leave
-      if (live) policy_value<KIND>(A, s_pol, s_act + 64 * 64, i, threadIdx.x & 63);
-      return;
-    }
-    if (live) policy_act<KIND>(A, s_pol, s_act, i, threadIdx.x, e, a);
+    // one barrier for both hand-offs (outline table, action means); the outline rows are requested
+    // before the towers' operands and parked in a register meanwhile
+    static_assert(2 * TB_MAX_HULL <= 256, "one outline row per thread");
+    const bool has_row = (int)threadIdx.x < 2 * A.P.n_hull;
+    float4 row = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (has_row) row = A.hull[threadIdx.x];
+    policy_towers<KIND>(A, s_mean);
+    if (has_row) s_hull[threadIdx.x] = row;
+    __syncthreads();
+    if (threadIdx.x >= 64) return;  // no barrier below this point
+    if (live) policy_sample<KIND>(A, s_mean, i, e, a);
+  } else {
+    stage_hull(s_hull, A);
   }
 #ifdef TB_DIAG_STAMPS
   if (live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -868,7 +833,7 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
   }
   a.actions = actions; a.obs = obs; a.reward = reward; a.done_out = done; a.term_obs = term; a.substeps = substeps; a.T = T;
   dim3 grid((unsigned)((h->n + h->block - 1) / h->block)), block((unsigned)h->block);
-  if (pol) { grid = dim3((unsigned)((h->n + 63) / 64)); block = dim3(128); }  // two waves per 64 envs
+  if (pol) { grid = dim3((unsigned)((h->n + 63) / 64)); block = dim3(256); }  // four waves per 64 envs
   // Pipelined SwingRacket: the step kernel never loops (LEAN); a lane that starts a fast-forward is
   // parked and tb_ff_kernel finishes it on a side stream. When the host knows the episode phase (all
   // envs were reset together; episodes are exactly 26 steps) only the 26th call can park anything, so

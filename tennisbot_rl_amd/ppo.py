@@ -81,26 +81,62 @@ def build_actor_critic(obs_dim, act_dim, net_arch=(32, 64, 32)):
     return ActorCritic()
 
 
+def _row_of(r):
+    """row of a 32x32 MFMA accumulator tile held by register r on lanes 0-31 (lanes 32-63: +4)"""
+    return (r & 3) + 8 * (r >> 2)
+
+
+def _fragment_indices(n_in, n_out, first_layer):
+    """Gather indices into [bias (n_out), W^T (n_in x n_out) row-major, one trailing 0.0] that produce
+    one layer of the blob `tb_policy_step` reads: bias tiles [out/32][2 halves][16 regs], then weight
+    fragments [out/32][pairs][2][32] (include/tb_stepper.h; csrc/tb_stepper.hip, LayerRegs)."""
+    zero = n_out + n_in * n_out
+    if first_layer:
+        pairs = [(2 * p, 2 * p + 1) for p in range(n_in // 2)]
+    else:  # the previous layer's accumulator registers ARE this layer's B operands, in register order
+        pairs = [(32 * t + _row_of(r), 32 * t + _row_of(r) + 4) for t in range(n_in // 32) for r in range(16)]
+    n_tiles = (n_out + 31) // 32
+    idx = []
+    for t in range(n_tiles):
+        for h in range(2):
+            for r in range(16):
+                o = 32 * t + _row_of(r) + 4 * h
+                idx.append(o if o < n_out else zero)
+    for t in range(n_tiles):
+        for pair in pairs:
+            for k in pair:
+                for j in range(32):
+                    o = 32 * t + j
+                    idx.append(n_out + k * n_out + o if o < n_out else zero)
+    return idx
+
+
 def pack_policy(policy, out=None):
-    """The blob `tb_policy_step` reads (include/tb_stepper.h): pi tower layers, action head, vf tower
-    layers, value head, log_std; each layer = bias[out] then W transposed to [in][out], zero-padded to
-    a multiple of 4 floats (16-byte aligned layers for the kernel's LDS vector reads).
+    """The blob `tb_policy_step` reads: pi tower layers, action head, vf tower layers, value head (each
+    in MFMA fragment order, see _fragment_indices), then log_std padded to a multiple of 4 floats.
     `out`: a preallocated device tensor to refresh in place (its address is baked into captured graphs)."""
     import torch
-    parts = []
-
-    def layer(m):
-        n = m.bias.numel() + m.weight.numel()
-        parts.extend([m.bias.detach().float(), m.weight.detach().float().t().reshape(-1), torch.zeros(-n % 4, device=m.weight.device)])
+    dev = policy.log_std.device
+    cache = getattr(policy, "_pack_index", None)
+    layers = []
     for body, head in ((policy.policy_net, policy.action_net), (policy.value_net_body, policy.value_net)):
-        for m in body:
-            if isinstance(m, torch.nn.Linear):
-                layer(m)
-        layer(head)
-    parts.append(policy.log_std.detach().float())
-    n = sum(p.numel() for p in parts)
-    parts.append(torch.zeros(-n % 4, device=parts[0].device))
-    flat = torch.cat(parts)
+        layers += [m for m in body if isinstance(m, torch.nn.Linear)] + [head]
+    if cache is None or cache[0].device != dev:
+        cache, first = [], True
+        n_body = (len(layers) - 2) // 2
+        for li, m in enumerate(layers):
+            first = li % (n_body + 1) == 0
+            cache.append(torch.tensor(_fragment_indices(m.in_features, m.out_features, first), dtype=torch.long, device=dev))
+        policy._pack_index = cache
+    parts = []
+    with torch.no_grad():
+        zero = torch.zeros(1, device=dev)
+        for m, idx in zip(layers, cache):
+            src = torch.cat([m.bias.detach().float(), m.weight.detach().float().t().reshape(-1), zero])
+            parts.append(src[idx])
+        parts.append(policy.log_std.detach().float())
+        parts.append(torch.zeros(-policy.log_std.numel() % 4, device=dev))
+        flat = torch.cat(parts)
     if out is None:
         return flat.contiguous()
     out.copy_(flat)
@@ -147,7 +183,7 @@ class PPOTrainer:
         self._rollouts = 0
         if self.fused:
             self.packed = pack_policy(self.policy)
-            assert self.packed.numel() == (self.env.policy_floats() + 3) // 4 * 4
+            assert self.packed.numel() == self.env.policy_floats()
 
     # ------------------------------------------------------------------ collect
     def _collect_fused(self):

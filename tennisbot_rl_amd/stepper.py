@@ -228,11 +228,10 @@ class BatchedEnv:
 
     def policy_step(self, weights, obs_in, seed=0, deterministic=False, out=None, policy_out=None):
         """step() with SB3's MlpPolicy evaluated inside the step kernel (tb_policy_step): each env
-        acts on its row of `obs_in`. weights: the packed blob of `ppo.pack_policy` (padded to a
-        multiple of 4 floats). Returns ((obs, reward, done), (actions, raw_actions, logp, value));
+        acts on its row of `obs_in`. weights: the packed blob of `ppo.pack_policy`. Returns ((obs, reward, done), (actions, raw_actions, logp, value));
         `out` / `policy_out` are optional tuples of preallocated tensors of those shapes."""
         t, n = self.torch, self.num_envs
-        nf = (self.policy_floats() + 3) // 4 * 4
+        nf = self.policy_floats()
         w = self._check_tensor(weights, (nf,), t.float32, "weights")
         if w.data_ptr() % 16:
             raise ValueError("weights must be 16-byte aligned")

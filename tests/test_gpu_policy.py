@@ -60,7 +60,7 @@ def make(torch, kind, n, seed=5, scale=1.0):
 @pytest.mark.parametrize("kind,n", [(ENV_SWING, 4096), (ENV_SWING, 257), (ENV_TENNIS, 4096), (ENV_TENNIS, 65)])
 def test_deterministic_policy_step_matches_module_and_plain_step(torch, kind, n):
     policy, packed, env, twin = make(torch, kind, n)
-    assert packed.numel() == (env.policy_floats() + 3) // 4 * 4
+    assert packed.numel() == env.policy_floats()
     obs_a, obs_b = env.reset(), twin.reset()
     assert torch.equal(obs_a, obs_b)
     for k in range(40):

@@ -89,3 +89,66 @@ def test_ppo_short_run_and_checkpoint(tmp_path):
     for a, b in zip(tr.policy.parameters(), tr2.policy.parameters()):
         assert torch.equal(a, b)
     assert np.isfinite(tr2.evaluate())
+
+
+def _emulate_blob(blob, obs, kind):
+    """What the fused kernel computes from the packed blob, restated with numpy from the MFMA
+    semantics alone (v_mfma_f32_32x32x2_f32: D[i][j] += sum_kk A[i][kk] * B[kk][j]; operand lane
+    l = 32 * kk + index; accumulator register r on lane half h holds row (r&3) + 8(r>>2) + 4h):
+    returns (mean [n, A], value [n], log_std [A]). Independent of the packer's index tables."""
+    from tennisbot_rl_amd.params import ACT_DIM, ENV_SWING, OBS_DIM
+    hidden = (32, 64, 32) if kind == ENV_SWING else (64, 64)
+    n_obs, n_act = OBS_DIM[kind], ACT_DIM[kind]
+    blob = np.asarray(blob, dtype=np.float64)
+    row = lambda r: (r & 3) + 8 * (r >> 2)
+    pos, heads = 0, []
+    for tower in range(2):
+        # B operands of the first layer: pair p, lane half h -> obs[2p + h]
+        x = np.stack([np.stack([obs[:, 2 * p + h] for h in range(2)], 0) for p in range(n_obs // 2)], 0)  # [pairs][h][env]
+        widths = list(hidden) + [32]
+        for li, n_out in enumerate(widths):
+            n_tiles, n_pairs = n_out // 32, x.shape[0]
+            bias = blob[pos:pos + n_tiles * 32].reshape(n_tiles, 2, 16); pos += n_tiles * 32
+            frag = blob[pos:pos + n_tiles * n_pairs * 64].reshape(n_tiles, n_pairs, 2, 32); pos += n_tiles * n_pairs * 64
+            y = []
+            for t in range(n_tiles):
+                d = np.einsum("pki,pke->ie", frag[t], x)  # D[i][env]
+                for r in range(16):
+                    y.append(np.stack([d[row(r) + 4 * h] + bias[t, h, r] for h in range(2)], 0))  # register r: [h][env]
+            x = np.stack(y, 0)
+            if li < len(hidden):
+                x = np.tanh(x)
+        heads.append(x)  # [16 regs][h][env] of the head tile
+    out = lambda head, i: head[i & 3, i >> 2]  # head row i < 8: register i & 3 of lane half i >> 2
+    mean = np.stack([out(heads[0], i) for i in range(n_act)], -1)
+    value = out(heads[1], 0)
+    log_std = blob[pos:pos + n_act]
+    assert pos + (n_act + 3) // 4 * 4 == blob.size
+    return mean, value, log_std
+
+
+@pytest.mark.parametrize("env_id", ["SwingRacket-v0", "Tennisbot-v0"])
+def test_pack_policy_matches_the_module_under_mfma_semantics(env_id):
+    """host logic of the fused policy step: the fragment-ordered blob, pushed through a numpy
+    restatement of the MFMA data flow, reproduces the torch module (float64, 1e-12)"""
+    import torch
+    from tennisbot_rl_amd.params import ACT_DIM, ENV_SWING, ENV_TENNIS, OBS_DIM
+    from tennisbot_rl_amd.ppo import SWING_DEFAULTS, TENNIS_DEFAULTS, build_actor_critic, pack_policy
+    kind = ENV_SWING if env_id == "SwingRacket-v0" else ENV_TENNIS
+    torch.manual_seed(4)
+    arch = (SWING_DEFAULTS if kind == ENV_SWING else TENNIS_DEFAULTS)["net_arch"]
+    policy = build_actor_critic(OBS_DIM[kind], ACT_DIM[kind], tuple(arch))
+    with torch.no_grad():
+        for p in policy.parameters():
+            p.copy_(torch.randn_like(p) * 0.3)
+    blob = pack_policy(policy).numpy()
+    obs = np.random.default_rng(0).normal(size=(32, OBS_DIM[kind])).astype(np.float32)
+    mean, value, log_std = _emulate_blob(blob, obs.astype(np.float64), kind)
+    with torch.no_grad():
+        want_mean, want_value = policy.double()(torch.from_numpy(obs).double())
+    np.testing.assert_allclose(mean, want_mean.numpy(), atol=1e-6)   # blob is float32: weights rounded once
+    np.testing.assert_allclose(value, want_value.numpy(), atol=1e-6)
+    np.testing.assert_allclose(log_std, policy.log_std.detach().numpy(), atol=0)
+    # refreshing in place keeps the address (captured graphs bake it in)
+    buf = torch.zeros(blob.size)
+    assert pack_policy(policy.float(), out=buf).data_ptr() == buf.data_ptr()
