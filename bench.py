@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work per baseline leg (1 core, all cores)")
     ap.add_argument("--sweep", action="store_true", help="also time N = 4096 .. 4M envs on one GPU (extra JSON key)")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--gather-chunks", type=int, default=1, help="N > 1: ship the rollout in this many step-chunks overlapped with the rollout's own compute (1 = ONE all-gather at the collect boundary)")
+    ap.add_argument("--gather-chunks", type=int, default=0, help="N > 1: ship the rollout in this many step-chunks, each all-gather overlapped with the following chunks' steps (1 = ONE all-gather at the collect boundary; 0 = auto: 8 when N > 1 and the step count divides)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of replaying one captured hipGraph")
     ap.add_argument("--no-pipeline", action="store_true", help="run the SwingRacket fast-forward inside the step kernel instead of a side stream")
     return ap.parse_args()
@@ -86,61 +86,85 @@ def fill_actions(buf_actions, seed, torch):
         buf_actions[t0:t0 + n].copy_(a[:n])
 
 
-GRAPH_STATE = {"used": True, "chunks": 1}
+GRAPH_STATE = {"used": True, "chunks": 1, "gather_ok": None}
 
 
-def time_steps(env, buf, steps, warmup, torch, dist_on, tail_gather=True, graph=False, gather_chunks=1):
+def time_steps(env, buf, steps, warmup, torch, dist_on, tail_gather=True, graph=False, gather_chunks=1, force_collective=False):
     """W untimed + K timed steps; returns (wall seconds, HIP-event seconds of the K launches).
-    graph=True: the K timed steps are captured once into hipGraphs (outside the timed region) and
-    the timed region replays them -- same kernels, same buffers, no per-step host work.
-    gather_chunks=C > 1 (multi-rank): the rollout is exchanged in C step-chunks, each all-gather
-    issued asynchronously as soon as its steps are enqueued, instead of one collective at the end."""
+    graph=True: the K timed steps are captured once into a hipGraph (outside the timed region) and
+    the timed region replays it -- same kernels, same buffers, no per-step host work.
+    gather_chunks=C > 1 (multi-rank): the rollout is exchanged in C step-chunks; chunk c's all-gather
+    is issued from a side stream that waits for the chunk's steps and for the fast-forwards that still
+    owe them rewards, while the main stream goes on stepping chunk c+1. With graph=True every chunk is
+    its own hipGraph (RolloutBuffer.capture_chunks: episode ends near a chunk's end are parked and
+    their fast-forwards launched by the next graph, so no graph stalls on a join) and the collectives
+    are issued eagerly between the replays; otherwise the chunks are enqueued by tb_step_sequence."""
     dev = env.device
     T = buf.T
     for t in range(warmup):
         buf.step_into(env, t % T)
-    chunks = gather_chunks if (dist_on and tail_gather and gather_chunks > 1 and steps == T and steps % gather_chunks == 0) else 1
+    collective = dist_on or force_collective
+    chunks = gather_chunks if (collective and tail_gather and gather_chunks > 1 and steps == T and steps % gather_chunks == 0) else 1
     seg = steps // chunks
-    graphs = None
+    if collective and tail_gather:  # RCCL's first use of a collective (channels, buffers) stays outside the timed region
+        if chunks > 1:
+            buf.begin_gather(chunks, force=force_collective)
+            for c in range(chunks):
+                buf.gather_chunk(c, env=env, force=force_collective)
+            buf.finish_gather()
+        else:
+            buf.all_gather(force=force_collective)
+        torch.cuda.synchronize(dev)
+
+    def chunked_body():  # host-issued variant (--no-graph, or capture failed)
+        for c in range(chunks):
+            buf.step_range(env, c * seg, (c + 1) * seg)
+            buf.gather_chunk(c, env=env, force=force_collective)
+        env.flush()
+
+    g, chunk_graphs = None, None
     if graph:
         try:
-            graphs = []
-            for c in range(chunks):
-                def body(c=c):
-                    for t in range(c * seg, (c + 1) * seg):
+            if chunks > 1:
+                chunk_graphs = buf.capture_chunks(env, chunks)  # only this library's kernels are captured; the collectives stay eager
+                g = chunk_graphs[0][0]
+            else:
+                def body():
+                    for t in range(steps):
                         buf.step_into(env, t % T)
-                graphs.append(env.capture(body))
-        except Exception as exc:  # fall back to per-step launches and say so
-            print("hipGraph capture failed (%s: %s); launching every step from the host" % (type(exc).__name__, exc), file=sys.stderr)
-            graphs = None
-            GRAPH_STATE["used"] = False
-    if chunks > 1:
-        buf.begin_gather(chunks)
+                g = env.capture(body)
+        except Exception as exc:  # fall back to host-issued launches and say so
+            print("hipGraph capture failed (%s: %s); issuing the steps from the host" % (type(exc).__name__, exc), file=sys.stderr)
+            g, chunk_graphs = None, None
+    GRAPH_STATE["used"] = g is not None
     if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize(dev)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(torch.cuda.current_stream(dev))  # the stream the step kernel is launched on
-    for c in range(chunks):
-        if graphs is not None:
-            graphs[c].replay()
-        else:
-            for t in range(c * seg, (c + 1) * seg):
-                buf.step_into(env, t % T)
-            env.flush()  # pipelined fast-forwards: every step's outputs are complete from here on
-        if chunks > 1:
-            buf.gather_chunk(c)
+    if chunk_graphs is not None:
+        buf.replay_chunks(chunk_graphs[0], chunk_graphs[1], gather=True, force=force_collective)
+    elif g is not None:
+        g.replay()
+    elif chunks > 1:
+        chunked_body()
+    else:
+        for t0_ in range(0, steps, T):
+            buf.step_range(env, 0, min(T, steps - t0_))
+        env.flush()  # pipelined fast-forwards: every step's outputs are complete from here on
     ev1.record(torch.cuda.current_stream(dev))
     if chunks > 1:
         buf.finish_gather()
     elif tail_gather:
-        buf.all_gather()  # collect boundary: one collective (no-op for a single rank)
+        buf.all_gather(force=force_collective)  # collect boundary: one collective (no-op for a single rank)
     if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
     GRAPH_STATE["chunks"] = chunks
+    if collective and tail_gather:  # after the clock: every rank must hold every shard, starting with its own
+        GRAPH_STATE["gather_ok"] = bool(buf.check_gathered())
     return wall, ev0.elapsed_time(ev1) * 1e-3
 
 
@@ -200,13 +224,20 @@ def main():
     # TB_BENCH_REHEARSAL=1: several ranks share cuda:0 over gloo -- a one-GPU rehearsal of the
     # multi-rank control flow (the numbers mean nothing; RCCL refuses two ranks on one device)
     rehearsal = os.environ.get("TB_BENCH_REHEARSAL") == "1"
+    # TB_BENCH_FORCE_COLLECTIVE=1: a single rank still initialises RCCL and issues every collective
+    # of the multi-rank path (one-GPU rehearsal of the RCCL calls themselves; numbers mean little)
+    force_collective = os.environ.get("TB_BENCH_FORCE_COLLECTIVE") == "1" and world == 1
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if dist_on:
+    if dist_on or force_collective:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if rehearsal:
+        if force_collective:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            torch.distributed.init_process_group(backend="nccl", device_id=dev, rank=0, world_size=1)
+        elif rehearsal:
             torch.distributed.init_process_group(backend="gloo")
         else:
             torch.distributed.init_process_group(backend="nccl", device_id=dev)
@@ -227,11 +258,17 @@ def main():
     env.reset()
     env.counters_reset()
     use_graph = not args.no_graph
-    wall, ev_s = time_steps(env, buf, args.steps, args.warmup, torch, dist_on, graph=use_graph, gather_chunks=args.gather_chunks)
+    chunks = args.gather_chunks
+    if chunks == 0:  # auto: overlap the exchange whenever there is one
+        chunks = 8 if ((dist_on or force_collective) and args.steps == T_buf and args.steps % 8 == 0) else 1
+    wall, ev_s = time_steps(env, buf, args.steps, args.warmup, torch, dist_on, graph=use_graph, gather_chunks=chunks, force_collective=force_collective)
     gather_note = ""
-    if dist_on:
+    if GRAPH_STATE["gather_ok"] is False:
+        sys.exit("the gathered rollout does not match the local shard: result discarded")
+    if dist_on or force_collective:
         gather_note = (", 1 RCCL all-gather of rollouts at the collect boundary" if GRAPH_STATE["chunks"] == 1 else
-                       ", rollouts all-gathered (RCCL) in %d step-chunks overlapped with the rollout" % GRAPH_STATE["chunks"])
+                       ", rollouts all-gathered (RCCL) in %d step-chunks, each overlapped with the next chunk's steps%s" % (
+                           GRAPH_STATE["chunks"], " (one hipGraph per chunk)" if GRAPH_STATE["used"] else " (steps enqueued by tb_step_sequence)"))
     c = env.counters()
 
     wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
@@ -304,7 +341,7 @@ def main():
             "value_1core": cb["1core"]["steps_per_s"], "substeps_per_s": best["substeps_per_s"], "pybullet": cb["pybullet"],
             "substeps_per_s_1core": cb["1core"]["substeps_per_s"],
         }
-    if dist_on:
+    if dist_on or force_collective:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank == 0:

@@ -204,6 +204,18 @@ int tb_rollout(TbHandle *h, int n_steps, const float *actions_dev, float *obs_de
                float *reward_dev, uint8_t *done_dev, int32_t *substeps_total_dev, void *stream);
 
 /*
+ * n_steps consecutive tb_step calls issued from one host call: step t reads actions at
+ * actions_dev + t * actions_stride (bytes) and writes obs / reward / done at their bases + t * their
+ * strides -- e.g. the records of a packed rollout buffer. Same launches, same results and the same
+ * pipelining as n_steps calls of tb_step (no terminal_obs / substeps outputs); it only takes the host
+ * language's per-call cost out of the loop (a ctypes call costs about as much as the step kernel runs).
+ * Strides must keep every row as aligned as tb_step requires.
+ */
+int tb_step_sequence(TbHandle *h, int n_steps, const float *actions_dev, float *obs_dev, float *reward_dev,
+                     uint8_t *done_dev, size_t actions_stride, size_t obs_stride, size_t reward_stride,
+                     size_t done_stride, void *stream);
+
+/*
  * step() with the policy inside ("policy inference on device ... so collect never
  * leaves the GPU"): SB3's MlpPolicy as the reference configures it (train_swing.py:80-82: pi = vf =
  * [32, 64, 32], tanh; Tennisbot-v0: SB3's default [64, 64], train.py:104-110), a = mean + exp(log_std)
@@ -243,12 +255,32 @@ int tb_policy_step(TbHandle *h, const float *weights_dev, const float *obs_in_de
  */
 int tb_set_pipeline(TbHandle *h, int enable);
 int tb_flush(TbHandle *h, void *stream);
+/*
+ * Deferred fast-forwards (for callers that cut a rollout into several hipGraphs). A graph has to join
+ * everything it forks, so a graph that ends right after an episode end would stall on a fast-forward
+ * it has just started. With tb_set_defer(h, 1) the following tb_step calls still park their finished
+ * episodes (obs/done returned at once, as always) but do not launch tb_ff_kernel; the parked lanes are
+ * finished by the next tb_ff_launch_pending(h, stream) -- typically the first call inside the NEXT
+ * graph, where the fast-forward then has that whole graph to overlap with -- or by tb_flush, or as soon
+ * as their slot is needed again. tb_pipeline_join makes `stream` wait for the fast-forwards already
+ * launched only (what a capture must do before it ends); tb_flush = launch pending + join, i.e. after
+ * it every result is in place. Results are bit-identical in every mode.
+ */
+int tb_set_defer(TbHandle *h, int on);
+int tb_ff_launch_pending(TbHandle *h, void *stream);
+int tb_pipeline_join(TbHandle *h, void *stream);
 /* Stream-capture support (hipGraph): events recorded inside a capture are meaningless outside
  * it and vice versa. Call with host_wait = 1 right BEFORE beginning a capture that will contain
  * tb_step calls (drains the side streams on the host and forgets their events), capture
  * ... tb_step x K ... tb_flush on the capturing stream, end the capture, then call with
  * host_wait = 0 (forget the capture-local events). */
 int tb_pipeline_sync(TbHandle *h, int host_wait);
+/* After a capture that contained tb_step calls was ABANDONED (it failed, e.g. because something else
+ * in it was not capturable): the handle's side streams were forked into that capture and stay
+ * invalidated, and the host's episode-phase hint ran ahead of the device. Replaces the side streams
+ * and their events, restores the phase of the last tb_pipeline_sync(h, 1), clears the sticky HIP
+ * error. The env state itself is untouched (nothing captured ever ran). */
+int tb_pipeline_recover(TbHandle *h);
 
 /* Snapshot / restore the persistent state (the reference never checkpoints env state;
  * SURVEY.md section 5). words: [tb_state_words][N] uint32 bit patterns, done: [N] bytes.

@@ -762,7 +762,7 @@ void to_kparams(const TbParams* p, KParams* k) {
 
 }  // namespace
 
-#define TB_FF_SLOTS 4
+#define TB_FF_SLOTS 8  // parked-state buffers + side streams: ~2.5 fast-forwards are in flight in steady state, up to 3 more are deferred across a graph boundary
 
 struct TbHandle {
   int device, kind, n, block;
@@ -777,6 +777,10 @@ struct TbHandle {
   // pipelined fast-forward
   int pipeline;            // enabled by tb_set_pipeline
   int phase, phase_valid;  // agent steps since the last full reset (SwingRacket episodes are exactly 26 steps)
+  int phase_at_capture, phase_valid_at_capture;  // snapshot taken by tb_pipeline_sync(h, 1), see tb_pipeline_recover
+  // deferred fast-forwards (tb_set_defer): parked, not yet launched
+  int defer, n_pending, n_pending_at_capture;
+  struct Pending { KArgs a; int slot; const void *term, *sub; } pending[TB_FF_SLOTS], pending_at_capture[TB_FF_SLOTS];
   hipStream_t side[TB_FF_SLOTS];  // one stream per slot: consecutive fast-forwards overlap each other too
   const void *last_term, *last_sub;  // shared late-written buffers force ordering between fast-forwards
   int last_slot;
@@ -819,6 +823,38 @@ int wait_side(TbHandle* h, hipStream_t s) {
   return TB_OK;
 }
 
+// finish the lanes parked in `slot` on that slot's side stream, ordered after everything issued to `s` so far
+int launch_ff(TbHandle* h, int slot, const KArgs& a, const void* term, const void* substeps, hipStream_t s) {
+  dim3 grid((unsigned)((h->n + h->block - 1) / h->block)), block((unsigned)h->block);
+  HIP_TRY(hipEventRecord(h->ev_step[slot], s));
+  HIP_TRY(hipStreamWaitEvent(h->side[slot], h->ev_step[slot], 0));
+  // two fast-forwards that write the same terminal-obs / substeps buffer must finish in order
+  if (h->last_slot >= 0 && h->last_slot != slot && ((term && term == h->last_term) || (substeps && substeps == h->last_sub)))
+    HIP_TRY(hipStreamWaitEvent(h->side[slot], h->ev_ff[h->last_slot], 0));
+  if (h->kp.flags & TB_F_RACKET_GROUND) hipLaunchKernelGGL(tb_ff_kernel<true>, grid, block, 0, h->side[slot], a);
+  else hipLaunchKernelGGL(tb_ff_kernel<false>, grid, block, 0, h->side[slot], a);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(h->ev_ff[slot], h->side[slot]));
+  h->ff_busy[slot] = 1; h->last_slot = slot; h->last_term = term; h->last_sub = substeps;
+  return TB_OK;
+}
+
+// launch every deferred fast-forward (oldest first), ordered after what `s` holds so far
+int launch_pending(TbHandle* h, hipStream_t s) {
+  for (int i = 0; i < h->n_pending; ++i) {
+    const TbHandle::Pending& p = h->pending[i];
+    if (int rc = launch_ff(h, p.slot, p.a, p.term, p.sub, s)) return rc;
+  }
+  h->n_pending = 0;
+  return TB_OK;
+}
+
+// every result of every fast-forward, parked or running, is in place once `s` gets past this point
+int flush_all(TbHandle* h, hipStream_t s) {
+  if (int rc = launch_pending(h, s)) return rc;
+  return wait_side(h, s);
+}
+
 struct PolicyIO {  // non-null weights = fused policy step
   const float* weights; const float* obs_in; float* actions; float* raw; float* logp; float* value;
   unsigned long long seed; int deterministic;
@@ -845,10 +881,13 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
   if (may_park) {
     slot = h->next_slot;
     h->next_slot = (slot + 1) % TB_FF_SLOTS;
+    for (int i = 0; i < h->n_pending; ++i)  // the slot still holds lanes whose fast-forward was deferred: it cannot wait any longer
+      if (h->pending[i].slot == slot) { if (int rc = launch_pending(h, s)) return rc; break; }
     if (h->ff_busy[slot]) HIP_TRY(hipStreamWaitEvent(s, h->ev_ff[slot], 0));  // slot still in use by an older fast-forward
     a.defer = 1; a.ff_words = h->d_ff_words[slot]; a.ff_flag = h->d_ff_flag[slot];
   }
   const bool rg = (h->kp.flags & TB_F_RACKET_GROUND) != 0;  // selects the instantiation that contains racket<->court contact
+  (void)hipGetLastError();  // the check below is about THIS launch, not about whatever another library left behind
 #define TB_LAUNCH_STEP(KIND, LEAN, MULTI)                                                                      \
   do {                                                                                                         \
     if (pol) hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, false, false, true>), grid, block, 0, s, a);        \
@@ -871,16 +910,12 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
 #undef TB_LAUNCH_STEP
   HIP_TRY(hipGetLastError());
   if (may_park) {
-    HIP_TRY(hipEventRecord(h->ev_step[slot], s));
-    HIP_TRY(hipStreamWaitEvent(h->side[slot], h->ev_step[slot], 0));
-    // two fast-forwards that write the same terminal-obs / substeps buffer must finish in order
-    if (h->last_slot >= 0 && h->last_slot != slot && ((term && term == h->last_term) || (substeps && substeps == h->last_sub)))
-      HIP_TRY(hipStreamWaitEvent(h->side[slot], h->ev_ff[h->last_slot], 0));
-    if (rg) hipLaunchKernelGGL(tb_ff_kernel<true>, grid, block, 0, h->side[slot], a);
-    else hipLaunchKernelGGL(tb_ff_kernel<false>, grid, block, 0, h->side[slot], a);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(h->ev_ff[slot], h->side[slot]));
-    h->ff_busy[slot] = 1; h->last_slot = slot; h->last_term = term; h->last_sub = substeps;
+    if (h->defer) {  // tb_set_defer: park now, finish when the caller says so (tb_ff_launch_pending / tb_flush)
+      TbHandle::Pending& p = h->pending[h->n_pending++];  // (a slot is never parked into twice: n_pending <= TB_FF_SLOTS)
+      p.a = a; p.slot = slot; p.term = term; p.sub = substeps;
+    } else if (int rc = launch_ff(h, slot, a, term, substeps, s)) {
+      return rc;
+    }
   }
   if (h->phase_valid) h->phase = (h->phase + T) % 26;
   return TB_OK;
@@ -981,11 +1016,59 @@ int tb_pipeline_sync(TbHandle* h, int host_wait) {
     h->ff_busy[k] = 0;
   }
   h->last_slot = -1;
+  if (host_wait) {
+    h->phase_at_capture = h->phase; h->phase_valid_at_capture = h->phase_valid;
+    h->n_pending_at_capture = h->n_pending;
+    memcpy(h->pending_at_capture, h->pending, sizeof h->pending);
+  }
+  return TB_OK;
+}
+
+int tb_pipeline_recover(TbHandle* h) {
+  if (!h) return fail(TB_E_INVAL, "tb_pipeline_recover: null handle");
+  DeviceGuard g(h->device);
+  (void)hipGetLastError();  // the abandoned capture leaves a sticky hipErrorStreamCaptureInvalidated behind
+  // the captured tb_step calls advanced the host's episode phase, but none of them ran
+  h->phase = h->phase_at_capture; h->phase_valid = h->phase_valid_at_capture;
+  h->n_pending = h->n_pending_at_capture;  // parks deferred by the abandoned capture never happened; older ones did
+  memcpy(h->pending, h->pending_at_capture, sizeof h->pending);
+  for (int k = 0; k < TB_FF_SLOTS; ++k) {
+    h->ff_busy[k] = 0;
+    if (!h->side[k]) continue;
+    // a side stream that was forked into the capture stays invalidated: replace it and its events
+    (void)hipStreamDestroy(h->side[k]);
+    (void)hipEventDestroy(h->ev_step[k]);
+    (void)hipEventDestroy(h->ev_ff[k]);
+    (void)hipGetLastError();
+    HIP_TRY(hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_step[k], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_ff[k], hipEventDisableTiming));
+  }
+  h->last_slot = -1; h->last_term = nullptr; h->last_sub = nullptr;
   return TB_OK;
 }
 
 int tb_flush(TbHandle* h, void* stream) {
   if (!h) return fail(TB_E_INVAL, "tb_flush: null handle");
+  DeviceGuard g(h->device);
+  return flush_all(h, (hipStream_t)stream);
+}
+
+int tb_set_defer(TbHandle* h, int on) {
+  if (!h) return fail(TB_E_INVAL, "tb_set_defer: null handle");
+  if (on && !h->pipeline) return fail(TB_E_UNSUPPORTED, "tb_set_defer needs tb_set_pipeline(h, 1)");
+  h->defer = on ? 1 : 0;
+  return TB_OK;
+}
+
+int tb_ff_launch_pending(TbHandle* h, void* stream) {
+  if (!h) return fail(TB_E_INVAL, "tb_ff_launch_pending: null handle");
+  DeviceGuard g(h->device);
+  return launch_pending(h, (hipStream_t)stream);
+}
+
+int tb_pipeline_join(TbHandle* h, void* stream) {
+  if (!h) return fail(TB_E_INVAL, "tb_pipeline_join: null handle");
   DeviceGuard g(h->device);
   return wait_side(h, (hipStream_t)stream);
 }
@@ -996,7 +1079,7 @@ int tb_set_params(TbHandle* h, const TbParams* params, void* stream) {
   DeviceGuard g(h->device);
   hipStream_t s = (hipStream_t)stream;
   // the staging buffer may still feed an earlier async copy on another stream: settle it first
-  if (int rc = wait_side(h, s)) return rc;
+  if (int rc = flush_all(h, s)) return rc;
   HIP_TRY(hipStreamSynchronize(s));
   if ((params->flags ^ h->params.flags) & TB_F_AUTO_RESET) h->phase_valid = 0;  // episodes may stop / start restarting
   h->params = *params;
@@ -1009,7 +1092,7 @@ int tb_set_params(TbHandle* h, const TbParams* params, void* stream) {
 int tb_reset(TbHandle* h, const uint8_t* mask_dev, float* obs_dev, void* stream) {
   if (!h) return fail(TB_E_INVAL, "tb_reset: null handle");
   DeviceGuard g(h->device);
-  if (int rc = wait_side(h, (hipStream_t)stream)) return rc;
+  if (int rc = flush_all(h, (hipStream_t)stream)) return rc;
   if (mask_dev) h->phase_valid = 0;  // episodes are no longer in lockstep
   else { h->phase_valid = 1; h->phase = 0; }
   KArgs a = base_args(h);
@@ -1026,6 +1109,22 @@ int tb_step(TbHandle* h, const float* actions_dev, float* obs_dev, float* reward
   if (!h || !actions_dev || !obs_dev || !reward_dev || !done_dev) return fail(TB_E_INVAL, "tb_step: null argument");
   DeviceGuard g(h->device);
   return launch_step(h, 1, actions_dev, obs_dev, reward_dev, done_dev, terminal_obs_dev, substeps_dev, (hipStream_t)stream);
+}
+
+int tb_step_sequence(TbHandle* h, int n_steps, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev,
+                     size_t actions_stride, size_t obs_stride, size_t reward_stride, size_t done_stride, void* stream) {
+  if (!h || !actions_dev || !obs_dev || !reward_dev || !done_dev) return fail(TB_E_INVAL, "tb_step_sequence: null argument");
+  if (n_steps < 1) return fail(TB_E_INVAL, "tb_step_sequence: n_steps must be >= 1");
+  DeviceGuard g(h->device);
+  for (int t = 0; t < n_steps; ++t) {
+    const size_t k = (size_t)t;
+    if (int rc = launch_step(h, 1, reinterpret_cast<const float*>(reinterpret_cast<const char*>(actions_dev) + k * actions_stride),
+                             reinterpret_cast<float*>(reinterpret_cast<char*>(obs_dev) + k * obs_stride),
+                             reinterpret_cast<float*>(reinterpret_cast<char*>(reward_dev) + k * reward_stride), done_dev + k * done_stride, nullptr, nullptr,
+                             (hipStream_t)stream))
+      return rc;
+  }
+  return TB_OK;
 }
 
 int tb_policy_floats(int env_kind) {
@@ -1055,7 +1154,7 @@ int tb_get_state(TbHandle* h, uint32_t* words, uint8_t* done, int on_device, voi
   if (!h || !words) return fail(TB_E_INVAL, "tb_get_state: null argument");
   DeviceGuard g(h->device);
   hipStream_t s = (hipStream_t)stream;
-  if (int rc = wait_side(h, s)) return rc;
+  if (int rc = flush_all(h, s)) return rc;
   const size_t wb = sizeof(uint32_t) * (size_t)words_of(h->kind) * h->n;
   hipMemcpyKind k = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
   HIP_TRY(hipMemcpyAsync(words, h->d_words, wb, k, s));
@@ -1068,7 +1167,7 @@ int tb_set_state(TbHandle* h, const uint32_t* words, const uint8_t* done, int on
   if (!h || !words) return fail(TB_E_INVAL, "tb_set_state: null argument");
   DeviceGuard g(h->device);
   hipStream_t s = (hipStream_t)stream;
-  if (int rc = wait_side(h, s)) return rc;
+  if (int rc = flush_all(h, s)) return rc;
   h->phase_valid = 0;  // injected states need not be in lockstep
   const size_t wb = sizeof(uint32_t) * (size_t)words_of(h->kind) * h->n;
   hipMemcpyKind k = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
@@ -1082,7 +1181,7 @@ int tb_set_state(TbHandle* h, const uint32_t* words, const uint8_t* done, int on
 int tb_counters(TbHandle* h, uint64_t* out, void* stream) {
   if (!h || !out) return fail(TB_E_INVAL, "tb_counters: null argument");
   DeviceGuard g(h->device);
-  if (int rc = wait_side(h, (hipStream_t)stream)) return rc;
+  if (int rc = flush_all(h, (hipStream_t)stream)) return rc;
   static_assert(sizeof(uint64_t) == sizeof(unsigned long long), "counter width");
   uint64_t shards[TB_COUNTER_SHARDS][TB_N_COUNTERS];
   HIP_TRY(hipMemcpyAsync(shards, h->d_counters, sizeof shards, hipMemcpyDeviceToHost, (hipStream_t)stream));

@@ -70,17 +70,79 @@ class RolloutBuffer:
             return None
         return env.step(self.actions[t], out=(self.obs[t], self.rewards[t], self.dones[t]))
 
+    def step_range(self, env, t0, t1):
+        """steps t0 .. t1-1 into their slots with ONE host call (tb_step_sequence): the record
+        stride is the same for all four parts. Needs bind(env)."""
+        if getattr(self, "_bound", None) is not env:
+            raise ValueError("step_range needs bind(env) first")
+        if not 0 <= t0 < t1 <= self.T:
+            raise ValueError("step range [%d, %d) outside the buffer's %d steps" % (t0, t1, self.T))
+        a, o, r, d = self._ptrs[t0]
+        rec = self.record
+        env.step_sequence_ptrs(t1 - t0, a, o, r, d, (rec, rec, rec, rec))
+
+    def capture_chunks(self, env, n_chunks, defer_window=52):
+        """The T steps of this buffer as n_chunks hipGraphs (+ a tail graph), for exchanging the
+        rollout chunk by chunk while it is still being produced. A graph must join what it forks, so
+        a chunk that ended right after an episode end would stall on the fast-forward it just
+        started: episode ends within the last `defer_window` steps of a chunk (default 2 episodes;
+        measured best at 4096 envs: a wider window parks more fast-forwards, and three or more of
+        them starting together at the head of the next graph slow each other and the steps) are parked
+        (BatchedEnv.set_defer) and their fast-forwards launched as the first node of the NEXT graph,
+        which they then overlap with. Chunk c is therefore complete when graph c+1 is (the tail
+        graph completes the last one). Returns (graphs, tail); tail is None without a pipeline."""
+        if getattr(self, "_bound", None) is not env:
+            raise ValueError("capture_chunks needs bind(env) first")
+        if self.T % n_chunks:
+            raise ValueError("n_steps %d is not divisible into %d chunks" % (self.T, n_chunks))
+        seg, piped = self.T // n_chunks, bool(getattr(env, "pipeline", False))
+        graphs = []
+        for c in range(n_chunks):
+            def body(c=c):
+                lo, hi = c * seg, (c + 1) * seg
+                if not piped:
+                    self.step_range(env, lo, hi)
+                    return
+                env.launch_pending()
+                cut = max(lo, hi - int(defer_window))
+                if cut > lo:
+                    self.step_range(env, lo, cut)
+                if hi > cut:
+                    env.set_defer(True)
+                    try:
+                        self.step_range(env, cut, hi)
+                    finally:
+                        env.set_defer(False)
+            graphs.append(env.capture(body, join_only=piped))
+        tail = env.capture(lambda: None) if piped else None  # capture() ends with flush(): launch what is parked, join
+        return graphs, tail
+
+    def replay_chunks(self, graphs, tail, gather=False, force=False):
+        """replay capture_chunks' graphs in order; gather=True issues each chunk's all-gather
+        (begin_gather(len(graphs)) first) as soon as the graph that completes it is enqueued"""
+        lag = 1 if tail is not None else 0
+        for c, g in enumerate(graphs):
+            g.replay()
+            if gather and c >= lag:
+                self.gather_chunk(c - lag, force=force)
+        if tail is not None:
+            tail.replay()
+            if gather:
+                self.gather_chunk(len(graphs) - 1, force=force)
+
     def _world(self, group):
         dist = self.torch.distributed
         if not (dist.is_available() and dist.is_initialized()):
             return 1
         return dist.get_world_size(group)
 
-    def all_gather(self, group=None):
+    def all_gather(self, group=None, force=False):
         """ONE collective for the whole rollout: returns a list of (obs, act, rew, done) views,
-        one per rank, in rank order (= global env id order). Single process: the local shard."""
+        one per rank, in rank order (= global env id order). Single process: the local shard
+        (force=True issues the collective anyway: one-GPU rehearsal of the RCCL call)."""
         world = self._world(group)
-        if world == 1:
+        self._last_gather = "single"
+        if world == 1 and not (force and self.torch.distributed.is_initialized()):
             return [(self.obs, self.actions, self.rewards, self.dones)]
         t = self.torch
         if getattr(self, "_gathered", None) is None or self._gathered.numel() != world * self.nbytes:
@@ -88,40 +150,74 @@ class RolloutBuffer:
         t.distributed.all_gather_into_tensor(self._gathered, self.raw, group=group)
         return [self.views(self._gathered[r * self.nbytes: (r + 1) * self.nbytes], self.T) for r in range(world)]
 
-    # -- overlapped variant: the same bytes in a few step-chunks, each issued as soon as its steps
-    #    are enqueued (async on the collective's own stream), joined by finish_gather()
-    def begin_gather(self, n_chunks, group=None):
+    # -- overlapped variant: the same bytes in a few step-chunks. Each chunk's all-gather is issued
+    #    from a side stream that waits for (a) the chunk's step kernels and (b) the fast-forwards
+    #    that still owe rewards to those steps -- so the stream that steps the envs never stalls:
+    #    it neither waits for the fast-forwards nor for the collective. finish_gather() joins.
+    def begin_gather(self, n_chunks, group=None, force=False):
         if self.T % n_chunks:
             raise ValueError("n_steps %d is not divisible into %d chunks" % (self.T, n_chunks))
         world, t = self._world(group), self.torch
         self._chunks, self._chunk_steps, self._works, self._group = int(n_chunks), self.T // int(n_chunks), [], group
+        self._last_gather = "chunks"
         cb = self._chunk_steps * self.record
-        if world > 1 and (getattr(self, "_gath_chunks", None) is None or len(self._gath_chunks) != n_chunks
-                          or self._gath_chunks[0].numel() != world * cb):
+        if (world > 1 or force) and (getattr(self, "_gath_chunks", None) is None or len(self._gath_chunks) != n_chunks
+                                     or self._gath_chunks[0].numel() != world * cb):
             self._gath_chunks = [t.empty(world * cb, dtype=t.uint8, device=self.device) for _ in range(n_chunks)]
+        if self.device.type == "cuda" and getattr(self, "_gather_stream", None) is None:
+            self._gather_stream = t.cuda.Stream(device=self.device)
 
-    def gather_chunk(self, c):
-        """call after the steps [c*S, (c+1)*S) have been enqueued on the current stream"""
-        world = self._world(self._group)
-        if world == 1:
+    def gather_chunk(self, c, env=None, force=False):
+        """call after the steps [c*S, (c+1)*S) have been enqueued on the current stream. `env`: the
+        pipelined BatchedEnv whose fast-forwards write late into this buffer (its flush is put on
+        the gather stream, not on the caller's). force: issue the collective for a single rank too
+        (rehearsal of the multi-rank path on one GPU)."""
+        world, t = self._world(self._group), self.torch
+        if world == 1 and not force:
             return
         cb = self._chunk_steps * self.record
         src = self.raw[c * cb:(c + 1) * cb]
-        self._works.append(self.torch.distributed.all_gather_into_tensor(self._gath_chunks[c], src, group=self._group, async_op=True))
+        gs = getattr(self, "_gather_stream", None)
+        if gs is None:  # CPU tensors (gloo tests)
+            self._works.append(t.distributed.all_gather_into_tensor(self._gath_chunks[c], src, group=self._group, async_op=True))
+            return
+        gs.wait_stream(t.cuda.current_stream(self.device))
+        with t.cuda.stream(gs):
+            if env is not None and getattr(env, "pipeline", False):
+                env.flush()  # makes `gs` wait for the outstanding fast-forwards
+            self._works.append(t.distributed.all_gather_into_tensor(self._gath_chunks[c], src, group=self._group, async_op=True))
 
     def finish_gather(self):
-        """wait for every chunk; returns per-rank (obs, act, rew, done) over all T steps"""
+        """wait for every chunk; returns, per rank, its list of per-chunk (obs, act, rew, done) views
+        (no copy; `concatenated_chunks` builds [T, ...] tensors when a learner wants them)"""
         world, t = self._world(self._group), self.torch
-        if world == 1:
-            return [(self.obs, self.actions, self.rewards, self.dones)]
+        if not self._works:
+            return [[(self.obs, self.actions, self.rewards, self.dones)]]
         for w in self._works:
-            w.wait()
+            w.wait()  # the current stream waits for the collective
+        self._works = []
+        gs = getattr(self, "_gather_stream", None)
+        if gs is not None:
+            t.cuda.current_stream(self.device).wait_stream(gs)
         cb = self._chunk_steps * self.record
-        out = []
-        for r in range(world):
-            parts = [self.views(g[r * cb:(r + 1) * cb], self._chunk_steps) for g in self._gath_chunks]
-            out.append(tuple(t.cat([p[k] for p in parts], dim=0) for k in range(4)))
-        return out
+        return [[self.views(g[r * cb:(r + 1) * cb], self._chunk_steps) for g in self._gath_chunks] for r in range(world)]
+
+    def check_gathered(self, group=None):
+        """does the latest gather's output hold this rank's own shard, byte for byte? (a cheap
+        self-test for callers that time the exchange without consuming it)"""
+        t, dist = self.torch, self.torch.distributed
+        rank = dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
+        if getattr(self, "_last_gather", None) == "chunks" and getattr(self, "_gath_chunks", None):
+            cb = self._chunk_steps * self.record
+            return all(t.equal(g[rank * cb:(rank + 1) * cb], self.raw[c * cb:(c + 1) * cb]) for c, g in enumerate(self._gath_chunks))
+        if getattr(self, "_gathered", None) is not None:
+            return t.equal(self._gathered[rank * self.nbytes:(rank + 1) * self.nbytes], self.raw)
+        return True
+
+    def concatenated_chunks(self, shards):
+        """per-rank [T, N, ...] tensors from finish_gather()'s chunk views (this one copies)"""
+        t = self.torch
+        return [tuple(t.cat([p[k] for p in parts], dim=0) for k in range(4)) for parts in shards]
 
     def concatenated(self, shards):
         """[T, world*N, ...] tensors in global env id order (what a learner consumes)"""

@@ -63,10 +63,20 @@ def load_library():
     L.tb_flush.restype = i32
     L.tb_pipeline_sync.argtypes = [vp, i32]
     L.tb_pipeline_sync.restype = i32
+    L.tb_step_sequence.argtypes = [vp, i32, vp, vp, vp, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, vp]
+    L.tb_step_sequence.restype = i32
     L.tb_policy_floats.argtypes = [i32]
     L.tb_policy_floats.restype = i32
     L.tb_policy_step.argtypes = [vp] * 10 + [u64, i32, vp]
     L.tb_policy_step.restype = i32
+    L.tb_set_defer.argtypes = [vp, i32]
+    L.tb_set_defer.restype = i32
+    L.tb_ff_launch_pending.argtypes = [vp, vp]
+    L.tb_ff_launch_pending.restype = i32
+    L.tb_pipeline_join.argtypes = [vp, vp]
+    L.tb_pipeline_join.restype = i32
+    L.tb_pipeline_recover.argtypes = [vp]
+    L.tb_pipeline_recover.restype = i32
     L.tb_diag_stream_copy.argtypes = [vp, vp, i32, i32, i32, vp]
     L.tb_diag_stream_copy.restype = i32
     for f in ("tb_create", "tb_destroy", "tb_set_params", "tb_reset", "tb_step", "tb_rollout", "tb_get_state",
@@ -222,6 +232,15 @@ class BatchedEnv:
         if rc:
             _check(self.L, rc, "tb_step")
 
+    def step_sequence_ptrs(self, n_steps, actions_ptr, obs_ptr, reward_ptr, done_ptr, strides):
+        """n_steps consecutive steps from ONE host call (tb_step_sequence): step t uses the four
+        device addresses advanced by t * strides[k] bytes (actions, obs, reward, done). Unchecked
+        fast path, like step_ptrs; RolloutBuffer.step_range is the validated caller."""
+        rc = self.L.tb_step_sequence(self._h, int(n_steps), actions_ptr, obs_ptr, reward_ptr, done_ptr,
+                                     strides[0], strides[1], strides[2], strides[3], self.torch.cuda.current_stream(self.device).cuda_stream)
+        if rc:
+            _check(self.L, rc, "tb_step_sequence")
+
     def policy_floats(self):
         """length of the packed MlpPolicy blob tb_policy_step expects for this env kind"""
         return int(self.L.tb_policy_floats(self.kind))
@@ -261,11 +280,22 @@ class BatchedEnv:
         if rc:
             _check(self.L, rc, "tb_policy_step")
 
-    def capture(self, fn):
+    def set_defer(self, on):
+        """pipelined mode: park finished episodes without launching their fast-forward until
+        launch_pending() / flush() (tb_set_defer; for rollouts cut into several graphs)"""
+        _check(self.L, self.L.tb_set_defer(self._h, 1 if on else 0), "tb_set_defer")
+
+    def launch_pending(self):
+        """launch the deferred fast-forwards on the side streams, ordered after the current stream"""
+        _check(self.L, self.L.tb_ff_launch_pending(self._h, self._stream()), "tb_ff_launch_pending")
+
+    def capture(self, fn, join_only=False):
         """Capture `fn()` -- a fixed sequence of step()/step_ptrs()/RolloutBuffer.step_into calls on
         fixed buffers -- into a HIP graph and return it; `graph.replay()` then runs the whole
         sequence with one launch (no per-step host work). In pipelined mode the side-stream
-        fast-forwards are captured as forked branches and joined by the final flush()."""
+        fast-forwards are captured as forked branches and joined by the final flush().
+        join_only=True: the capture ends by joining the fast-forwards it launched but leaves the
+        deferred ones (set_defer) parked for the next graph."""
         t = self.torch
         t.cuda.current_stream(self.device).synchronize()
         _check(self.L, self.L.tb_pipeline_sync(self._h, 1), "tb_pipeline_sync")
@@ -275,9 +305,19 @@ class BatchedEnv:
             # issuing HIP calls while this thread captures
             with t.cuda.graph(g, capture_error_mode="thread_local"):
                 fn()
-                self.flush()
-        finally:
-            _check(self.L, self.L.tb_pipeline_sync(self._h, 0), "tb_pipeline_sync")
+                if join_only:
+                    _check(self.L, self.L.tb_pipeline_join(self._h, self._stream()), "tb_pipeline_join")
+                else:
+                    self.flush()
+        except BaseException:
+            # nothing captured ever ran; put the handle's streams and phase hint back (the env is intact)
+            try:
+                t.cuda.synchronize(self.device)
+            except Exception:  # the capture error may surface once more through torch
+                pass
+            self.L.tb_pipeline_recover(self._h)
+            raise
+        _check(self.L, self.L.tb_pipeline_sync(self._h, 0), "tb_pipeline_sync")
         return g
 
     def flush(self):

@@ -427,3 +427,146 @@ def test_racket_ground_contact_opt_in(torch):
         compare_state(env, ref, "racket-ground forced %d" % t)
     assert env.counters()["nonfinite_states"] == 0
     env.close()
+
+
+def test_step_sequence_equals_per_step_calls_and_chunked_gather_views(torch):
+    """tb_step_sequence (one host call for a run of rollout slots) against step_into per slot, with the
+    pipelined fast-forward on; and the chunked-gather bookkeeping on a single rank (no collective)"""
+    from tennisbot_rl_amd.rollout import RolloutBuffer
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    n, T = 1000, 78
+    rng = np.random.default_rng(3)
+    acts = torch.from_numpy(rng.uniform(-1, 1, (T, n, 6)).astype(np.float32)).cuda()
+    bufs = []
+    for mode in ("per_step", "sequence"):
+        env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=21, track_terminal_obs=False, pipeline=True)
+        buf = RolloutBuffer(ENV_SWING, T, n, "cuda:0").bind(env)
+        buf.actions.copy_(acts)
+        env.reset()
+        if mode == "per_step":
+            for t in range(T):
+                buf.step_into(env, t)
+        else:
+            buf.step_range(env, 0, 30)
+            buf.step_range(env, 30, T)
+        env.flush()
+        torch.cuda.synchronize()
+        bufs.append(buf)
+        with pytest.raises(ValueError):
+            buf.step_range(env, 10, T + 1)
+    assert torch.equal(bufs[0].raw, bufs[1].raw)
+    assert float(bufs[0].dones.sum()) == 3 * n  # three whole episodes went through the side streams
+    buf = bufs[1]
+    buf.begin_gather(3)
+    for c in range(3):
+        buf.gather_chunk(c)  # single rank: nothing to exchange
+    shards = buf.finish_gather()
+    assert len(shards) == 1 and torch.equal(shards[0][0][0], buf.obs)
+
+
+@pytest.mark.parametrize("n_chunks,window", [(4, 52), (8, 10), (2, 104)])
+def test_chunk_graphs_with_deferred_fast_forwards_are_bit_identical(torch, n_chunks, window):
+    """a rollout cut into several hipGraphs, episode ends near a chunk's end parked and finished by
+    the next graph (tb_set_defer / tb_ff_launch_pending / tb_pipeline_join), replayed for two
+    rounds, against the same envs stepped call by call"""
+    from tennisbot_rl_amd.rollout import RolloutBuffer
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    n, T = 1000, 208
+    rng = np.random.default_rng(12)
+    acts = torch.from_numpy(rng.uniform(-1, 1, (T, n, 6)).astype(np.float32)).cuda()
+    ref_env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=31, track_terminal_obs=False, pipeline=True)
+    ref = RolloutBuffer(ENV_SWING, T, n, "cuda:0").bind(ref_env)
+    env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=31, track_terminal_obs=False, pipeline=True)
+    buf = RolloutBuffer(ENV_SWING, T, n, "cuda:0").bind(env)
+    for b in (ref, buf):
+        b.actions.copy_(acts)
+    ref_env.reset(); env.reset()
+    for t in range(7):  # chunk boundaries off the episode grid
+        ref.step_into(ref_env, t); buf.step_into(env, t)
+    graphs, tail = buf.capture_chunks(env, n_chunks, defer_window=window)
+    assert tail is not None and len(graphs) == n_chunks
+    for rnd in range(2):
+        for t in range(T):
+            ref.step_into(ref_env, t)
+        ref_env.flush()
+        buf.replay_chunks(graphs, tail)
+        torch.cuda.synchronize()
+        assert torch.equal(ref.raw, buf.raw), "round %d" % rnd
+    c = env.counters()
+    assert c == ref_env.counters()
+    wa, da = env.get_state_words()
+    wb, db = ref_env.get_state_words()
+    assert torch.equal(wa, wb) and torch.equal(da, db)
+
+
+def test_deferred_fast_forward_is_launched_by_flush_and_by_slot_reuse(torch):
+    """tb_set_defer without anyone calling tb_ff_launch_pending: flush() must deliver, and so must a
+    fifth parked episode end that needs the first one's slot back"""
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    n = 300
+    rng = np.random.default_rng(2)
+    acts = torch.from_numpy(rng.uniform(-1, 1, (140, n, 6)).astype(np.float32)).cuda()
+    ref = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=6, track_terminal_obs=False, pipeline=True)
+    env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=6, track_terminal_obs=False, pipeline=True)
+    ref.reset(); env.reset()
+    env.set_defer(True)
+    a = [env.step(acts[t]) for t in range(140)]   # 5 episode ends, 4 slots
+    b = [ref.step(acts[t]) for t in range(140)]
+    env.flush(); ref.flush()
+    env.set_defer(False)
+    torch.cuda.synchronize()
+    for t in range(140):
+        assert all(torch.equal(x, y) for x, y in zip(a[t], b[t])), "step %d" % t
+
+
+_ABANDONED_CAPTURE_CASE = r"""
+import sys
+import numpy as np, torch
+from tennisbot_rl_amd.params import ENV_SWING
+from tennisbot_rl_amd.stepper import BatchedEnv
+n = 512
+rng = np.random.default_rng(8)
+acts = torch.from_numpy(rng.uniform(-1, 1, (60, n, 6)).astype(np.float32)).cuda()
+env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=4, track_terminal_obs=False, pipeline=True)
+twin = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=4, track_terminal_obs=False, pipeline=True)
+env.reset(); twin.reset()
+for t in range(20):
+    env.step(acts[t]); twin.step(acts[t])
+
+def bad():
+    for t in range(20, 50):  # crosses an episode end: side streams get forked into the capture
+        env.step(acts[t])
+    torch.cuda.synchronize()  # not capturable
+
+try:
+    env.capture(bad)
+    sys.exit("the capture was expected to fail")
+except Exception:
+    pass
+# HIP (ROCm 7.2) keeps refusing work on the legacy default stream of a process whose capture was
+# invalidated -- torch's own ops included -- so the survivor continues on a stream of its own
+with torch.cuda.stream(torch.cuda.Stream()):
+    for t in range(20, 60):
+        a, b = env.step(acts[t]), twin.step(acts[t])
+        env.flush(); twin.flush()
+        if not all(torch.equal(x, y) for x, y in zip(a, b)):
+            sys.exit("step %d after the abandoned capture differs" % t)
+    wa, da = env.get_state_words()
+    wb, db = twin.get_state_words()
+    if not (torch.equal(wa, wb) and torch.equal(da, db)):
+        sys.exit("state differs")
+print("survived")
+"""
+
+
+def test_abandoned_capture_leaves_the_env_usable(torch):
+    """a capture that fails half-way (here: a host synchronisation inside it) must not poison the
+    handle: tb_pipeline_recover replaces the forked side streams and restores the phase hint, and
+    the env then steps exactly like a twin that never saw the capture. Runs in a process of its own:
+    the HIP runtime stays unusable on the default stream of a process this has happened to."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _ABANDONED_CAPTURE_CASE], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "survived" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

@@ -52,7 +52,7 @@ def _worker(rank, port, kind, out_dir):
     buf.begin_gather(3)
     for c in range(3):
         buf.gather_chunk(c)
-    chunked = buf.concatenated(buf.finish_gather())
+    chunked = buf.concatenated(buf.concatenated_chunks(buf.finish_gather()))
     assert all(torch.equal(a, b) for a, b in zip(chunked, (obs, act, rew, done)))
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), obs=obs.numpy(), act=act.numpy(), rew=rew.numpy(), done=done.numpy())
     dist.barrier()
