@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work per baseline leg (1 core, all cores)")
     ap.add_argument("--sweep", action="store_true", help="also time N = 4096 .. 4M envs on one GPU (extra JSON key)")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--gather-chunks", type=int, default=0, help="N > 1: ship the rollout in this many step-chunks, each all-gather overlapped with the following chunks' steps (1 = ONE all-gather at the collect boundary; 0 = auto: 8 when N > 1 and the step count divides)")
+    ap.add_argument("--gather-chunks", type=int, default=1, help="N > 1: ship the rollout in this many step-chunks, each all-gather overlapped with later chunks' steps (one hipGraph per chunk); default 1 = ONE all-gather at the collect boundary, as BASELINE.json's north_star words it")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of replaying one captured hipGraph")
     ap.add_argument("--no-pipeline", action="store_true", help="run the SwingRacket fast-forward inside the step kernel instead of a side stream")
     return ap.parse_args()
@@ -258,9 +258,7 @@ def main():
     env.reset()
     env.counters_reset()
     use_graph = not args.no_graph
-    chunks = args.gather_chunks
-    if chunks == 0:  # auto: overlap the exchange whenever there is one
-        chunks = 8 if ((dist_on or force_collective) and args.steps == T_buf and args.steps % 8 == 0) else 1
+    chunks = max(1, args.gather_chunks)
     wall, ev_s = time_steps(env, buf, args.steps, args.warmup, torch, dist_on, graph=use_graph, gather_chunks=chunks, force_collective=force_collective)
     gather_note = ""
     if GRAPH_STATE["gather_ok"] is False:

@@ -63,5 +63,48 @@ def main():
         run(ENV_SWING, True, C, w)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and os.environ.get("TB_DIAG_GATHER") != "1":
     main()
+
+
+def gather_probe():
+    """host cost and GPU-side effect of the chunk all-gathers with ONE RCCL rank (TB_DIAG_GATHER=1)"""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0), rank=0, world_size=1)
+    for kind, pipe in ((ENV_TENNIS, False), (ENV_SWING, True)):
+        env, buf = make(kind, pipe)
+        C = 8
+        graphs, tail = buf.capture_chunks(env, C)
+        buf.begin_gather(C, force=True)
+        for c in range(C):
+            buf.gather_chunk(c, force=True)
+        buf.finish_gather()
+        for mode in ("no gather", "gather"):
+            best = None
+            for rep in range(3):
+                torch.cuda.synchronize()
+                host, t0 = [], time.perf_counter()
+                lag = 1 if tail is not None else 0
+                for c, g in enumerate(graphs):
+                    g.replay()
+                    if mode == "gather" and c >= lag:
+                        h0 = time.perf_counter(); buf.gather_chunk(c - lag, force=True); host.append((time.perf_counter() - h0) * 1e3)
+                if tail is not None:
+                    tail.replay()
+                    if mode == "gather":
+                        h0 = time.perf_counter(); buf.gather_chunk(C - 1, force=True); host.append((time.perf_counter() - h0) * 1e3)
+                t_enq = (time.perf_counter() - t0) * 1e3
+                if mode == "gather":
+                    buf.finish_gather()
+                torch.cuda.synchronize()
+                wall = (time.perf_counter() - t0) * 1e3
+                if best is None or wall < best[0]:
+                    best = (wall, t_enq, host)
+            print("%s C=8 %s: wall %.2f ms, host enqueue done at %.2f ms, gather_chunk host ms %s" % (
+                "swing" if kind == ENV_SWING else "tennis", mode, best[0], best[1], " ".join("%.2f" % x for x in best[2])))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__" and os.environ.get("TB_DIAG_GATHER") == "1":
+    gather_probe()
