@@ -108,6 +108,29 @@ def test_tennis_lockstep(torch, n):
     env.close()
 
 
+def test_baseline_full_sizes_in_lockstep_with_the_oracle(torch):
+    """BASELINE.json configs[3] and [4] at their full global sizes on one GPU (the env ids of all 8
+    shards): SwingRacket-v0 32 768 envs through a whole episode with its fast-forward, Tennisbot-v0
+    65 536 envs with the Magnus / random-spin extension -- every output and the full state bit-exact
+    against the oracle (OpenMP over envs so that the CPU side stays at seconds)."""
+    import os
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    p = default_params()
+    env = BatchedEnv(ENV_SWING, 32768, device="cuda:0", seed=3, params=p)
+    pf = p.copy(); pf.flags |= F_AUTO_RESET
+    ref = OracleBatch(pf, ENV_SWING, 32768, seed=3, precision="f32", threads=threads)
+    run_lockstep(torch, env, ref, 28, np.random.default_rng(77), "swing 32768", check_state_every=9)
+    assert env.counters()["episodes_finished"] == 32768
+    env.close()
+    p = default_params(magnus_k=2e-4, ball_spin_max=150.0)
+    env = BatchedEnv(ENV_TENNIS, 65536, device="cuda:0", seed=4, params=p)
+    pf = p.copy(); pf.flags |= F_AUTO_RESET
+    ref = OracleBatch(pf, ENV_TENNIS, 65536, seed=4, precision="f32", threads=threads)
+    run_lockstep(torch, env, ref, 120, np.random.default_rng(78), "tennis 65536", check_state_every=40)
+    env.close()
+
+
 def test_swing_without_auto_reset_sticky_done(torch):
     env, ref = make_pair(torch, ENV_SWING, 300, auto_reset=False)
     run_lockstep(torch, env, ref, 30, np.random.default_rng(5), "swing sticky")  # 4 steps past done
