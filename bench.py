@@ -170,6 +170,29 @@ def time_steps(env, buf, steps, warmup, torch, dist_on, tail_gather=True, graph=
     return wall, ev0.elapsed_time(ev1) * 1e-3
 
 
+def open_loop_rate(kind, N, flags, pipeline, dev, seed, torch):
+    """Not the metric (an RL loop needs the observation before it can choose the next action) but the
+    rate of the same kernels without the launch boundary between steps: tb_rollout, whole episodes per
+    launch with the actions known up front, replayed as one hipGraph."""
+    from tennisbot_rl_amd.params import default_params
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    env = BatchedEnv(kind, N, device=dev, seed=seed, params=default_params(flags=flags), track_terminal_obs=False, pipeline=pipeline)
+    K = 1040
+    acts = torch.empty((K, N, env.act_dim), dtype=torch.float32, device=dev).uniform_(-1.0, 1.0)
+    env.reset()
+    env.rollout(acts[:52])
+    env.flush()
+    g = env.capture(lambda: env.rollout(acts))
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    g.replay()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    env.close()
+    return {"steps_per_s": N * K / wall, "us_per_step": wall / K * 1e6, "steps": K, "envs": N,
+            "note": "tb_rollout: up to 26 agent steps per launch, actions known up front (not an RL loop; shows the cost of the per-step launch boundary)"}
+
+
 def cpu_baseline(kind_name, n_envs, seconds, seed):
     """the oracle (kind "port") on this host, same workload shape, bounded time"""
     import numpy as np
@@ -333,7 +356,8 @@ def main():
             torch.cuda.empty_cache()
         if result is not None:
             result["sweep"] = sweep
-    if rank == 0 and not args.no_cpu_baseline:
+            result["open_loop"] = open_loop_rate(kind, N, flags, pipeline, dev, args.seed, torch)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # a reported baseline, timed once, next to the 1-GPU figure
         cb = cpu_baseline(args.env, N, args.cpu_seconds, args.seed)
         best = cb["allcores"]
         result["cpu_baseline"] = {

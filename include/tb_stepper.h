@@ -199,6 +199,9 @@ int tb_step(TbHandle *h, const float *actions_dev, float *obs_dev, float *reward
  * T consecutive step() calls in ONE launch with the state kept in registers:
  * actions [T][N][A] in; obs [T][N][O], reward [T][N], done [T][N] out; substeps_total
  * [N] int32 or NULL. Requires TB_F_AUTO_RESET. Same results as T calls of tb_step.
+ * With the pipeline on (tb_set_pipeline), lockstep episodes and substeps_total_dev == NULL, the T steps
+ * are issued as launches that end where the episodes end (<= 26 steps each), each followed by its
+ * fast-forward on a side stream; the rewards of those terminal steps are then complete after tb_flush.
  */
 int tb_rollout(TbHandle *h, int n_steps, const float *actions_dev, float *obs_dev,
                float *reward_dev, uint8_t *done_dev, int32_t *substeps_total_dev, void *stream);

@@ -696,8 +696,11 @@ struct PolicyIO {  // non-null weights = fused policy step
   unsigned long long seed; int deterministic;
 };
 
+// lean_multi (T > 1): the caller guarantees lockstep episodes (phase_valid) and that an episode can only
+// end at the LAST of the T steps (phase + T <= 26), so the launch parks at most once per env and the
+// pipelined kernel (no in-kernel fast-forward) can run several steps per launch too.
 int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* reward, uint8_t* done, float* term, int32_t* substeps, hipStream_t s,
-                const PolicyIO* pol = nullptr) {
+                const PolicyIO* pol = nullptr, bool lean_multi = false) {
   KArgs a = base_args(h);
   if (pol) {
     a.pol_weights = pol->weights; a.pol_obs = pol->obs_in; a.pol_actions = pol->actions; a.pol_raw = pol->raw; a.pol_logp = pol->logp;
@@ -711,8 +714,8 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
   // envs were reset together; episodes are exactly 26 steps) only the 26th call can park anything, so
   // only that call is followed by tb_ff_kernel; when it does not (masked reset, injected state), every
   // call gets a slot and a (then mostly idle) tb_ff_kernel.
-  const bool piped = T == 1 && h->pipeline && h->kind == TB_ENV_SWING && (h->kp.flags & TB_F_AUTO_RESET);
-  const bool may_park = piped && (!h->phase_valid || h->phase == 25);
+  const bool piped = (T == 1 || lean_multi) && h->pipeline && h->kind == TB_ENV_SWING && (h->kp.flags & TB_F_AUTO_RESET);
+  const bool may_park = piped && (T == 1 ? (!h->phase_valid || h->phase == 25) : h->phase + T - 1 == 25);
   int slot = -1;
   if (may_park) {
     slot = h->next_slot;
@@ -732,7 +735,10 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
   } while (0)
   if (T > 1) {
     if (h->kind == TB_ENV_TENNIS) TB_LAUNCH_STEP(TB_ENV_TENNIS, false, true);
-    else TB_LAUNCH_STEP(TB_ENV_SWING, false, true);
+    else if (piped) {
+      if (!may_park) { a.ff_words = nullptr; a.ff_flag = nullptr; }
+      TB_LAUNCH_STEP(TB_ENV_SWING, true, true);
+    } else TB_LAUNCH_STEP(TB_ENV_SWING, false, true);
   } else if (h->kind == TB_ENV_TENNIS) TB_LAUNCH_STEP(TB_ENV_TENNIS, false, false);
   else if (may_park) TB_LAUNCH_STEP(TB_ENV_SWING, true, false);
   else if (piped) {
@@ -746,6 +752,7 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
 #undef TB_LAUNCH_STEP
   HIP_TRY(hipGetLastError());
   if (may_park) {
+    if (T > 1) a.reward = reward + (size_t)(T - 1) * h->n;  // the fast-forward owes its reward to the step that parked: the last one
     if (h->defer) {  // tb_set_defer: park now, finish when the caller says so (tb_ff_launch_pending / tb_flush)
       TbHandle::Pending& p = h->pending[h->n_pending++];  // (a slot is never parked into twice: n_pending <= TB_FF_SLOTS)
       p.a = a; p.slot = slot; p.term = term; p.sub = substeps;
@@ -983,7 +990,21 @@ int tb_rollout(TbHandle* h, int n_steps, const float* actions_dev, float* obs_de
   if (n_steps < 1) return fail(TB_E_INVAL, "tb_rollout: n_steps must be >= 1");
   if (!(h->kp.flags & TB_F_AUTO_RESET)) return fail(TB_E_UNSUPPORTED, "tb_rollout needs TB_F_AUTO_RESET (episodes must restart inside the launch)");
   DeviceGuard g(h->device);
-  return launch_step(h, n_steps, actions_dev, obs_dev, reward_dev, done_dev, nullptr, substeps_total_dev, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  if (h->pipeline && h->kind == TB_ENV_SWING && h->phase_valid && !substeps_total_dev) {
+    // pipelined: launches that end where the episodes end (<= 26 steps each), every one followed by its
+    // fast-forward on a side stream instead of stalling its waves on it
+    const size_t n = (size_t)h->n;
+    for (int t = 0; t < n_steps;) {
+      const int room = 26 - h->phase, chunk = n_steps - t < room ? n_steps - t : room;
+      if (int rc = launch_step(h, chunk, actions_dev + (size_t)t * n * TB_SWING_ACT_DIM, obs_dev + (size_t)t * n * TB_SWING_OBS_DIM, reward_dev + (size_t)t * n,
+                               done_dev + (size_t)t * n, nullptr, nullptr, s, nullptr, chunk > 1))
+        return rc;
+      t += chunk;
+    }
+    return TB_OK;
+  }
+  return launch_step(h, n_steps, actions_dev, obs_dev, reward_dev, done_dev, nullptr, substeps_total_dev, s);
 }
 
 int tb_get_state(TbHandle* h, uint32_t* words, uint8_t* done, int on_device, void* stream) {

@@ -335,7 +335,9 @@ class BatchedEnv:
         a = self._check_tensor(actions, (T, self.num_envs, self.act_dim), t.float32, "actions")
         obs, rew, done = self._out(T)
         _check(self.L, self.L.tb_rollout(self._h, T, a.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(),
-                                         self._substeps.data_ptr(), self._stream()), "tb_rollout")
+                                         None if self.pipeline else self._substeps.data_ptr(), self._stream()), "tb_rollout")
+        if self.pipeline:
+            self._inflight.append(rew)  # terminal rewards are written late, from the side streams: flush() before reading
         return obs, rew, done
 
     def terminal_obs(self):

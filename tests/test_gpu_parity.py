@@ -236,6 +236,44 @@ def test_rollout_equals_repeated_steps(torch):
         e1.close(); e2.close()
 
 
+def test_pipelined_rollout_equals_repeated_steps(torch):
+    """tb_rollout with the pipeline on: launches that end where the episodes end (<= 26 steps each),
+    fast-forwards on the side streams -- from any starting phase, also captured in a hipGraph"""
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    n, T = 1000, 75
+    rng = np.random.default_rng(13)
+    acts = torch.from_numpy(rng.uniform(-1, 1, (T + 9, n, 6)).astype(np.float32)).cuda()
+    e1 = BatchedEnv(ENV_SWING, n, seed=4, pipeline=True, track_terminal_obs=False)
+    e2 = BatchedEnv(ENV_SWING, n, seed=4)
+    e1.reset(); e2.reset()
+    for t in range(9):  # start the rollout in the middle of an episode
+        e1.step(acts[T + t]); e2.step(acts[T + t])
+    obs, rew, done = e1.rollout(acts[:T])
+    e1.flush()
+    for t in range(T):
+        o, r, d = e2.step(acts[t])
+        assert torch.equal(o, obs[t]) and torch.equal(d, done[t]), "step %d" % t
+        assert torch.equal(r, rew[t]), "reward, step %d" % t
+    assert int(done.sum()) == 3 * n  # the episode ends at rollout steps 16, 42, 68
+    # and as a graph: same buffers, replayed twice
+    a_static = acts[:52].clone()
+    out = {}
+
+    def body():
+        out["r"] = e1.rollout(a_static)
+    g = e1.capture(body)
+    for rnd in range(2):
+        g.replay()
+        torch.cuda.synchronize()
+        for t in range(52):
+            o, r, d = e2.step(a_static[t])
+            assert torch.equal(o, out["r"][0][t]) and torch.equal(r, out["r"][1][t]) and torch.equal(d, out["r"][2][t]), "graph round %d step %d" % (rnd, t)
+    w1, d1 = e1.get_state_words(); w2, d2 = e2.get_state_words()
+    assert torch.equal(w1, w2) and torch.equal(d1, d2)
+    assert e1.counters() == e2.counters()
+    e1.close(); e2.close()
+
+
 def test_sharding_independence(torch):
     """RNG keyed by the GLOBAL env id: two half batches == one whole batch"""
     from tennisbot_rl_amd.stepper import BatchedEnv
