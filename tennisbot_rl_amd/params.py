@@ -97,15 +97,41 @@ def hull_edge_table(hull_yz_link, com_yz, scale):
     return rec.astype(np.float32)
 
 
+def bullet_shape_inertia(scene=None, hull_margin=0.001):
+    """Inertia as Bullet derives it from the collision shapes -- what loadURDF uses unless
+    URDF_USE_INERTIA_FROM_FILE is passed, and the reference passes no flags (racket.py:35-36,
+    objects.py:25-27): a sphere gets 0.4 m r^2; the racket's hull sits behind a non-identity inertial
+    frame, i.e. in a btCompoundShape, whose calculateLocalInertia is the box formula
+    m/12 (ly^2+lz^2, lx^2+lz^2, lx^2+ly^2) over its AABB (the hull's, margin included).
+    [3P-recalled] like every engine constant -- but this one is PINNED by the reference's own record:
+    with these values the shipped ppo_swing policy reaches the goal in 23 % of the episodes against
+    27 +- 4.4 % in the 100 PyBullet episodes stored in backup_models/ppo_swing.zip; with the URDF's
+    diag(.04, .08, .12) / 1.0 it is 12 % (tools/compare_reference_policy.py)."""
+    sc = scene or load_scene()
+    rk, bl = sc["racket"], sc["ball"]
+    ext = [(hi - lo) + 2.0 * hull_margin for lo, hi in zip(rk["bbox_min"], rk["bbox_max"])]
+    m = rk["mass"] / 12.0
+    return dict(racket_inertia=(m * (ext[1] ** 2 + ext[2] ** 2), m * (ext[0] ** 2 + ext[2] ** 2), m * (ext[0] ** 2 + ext[1] ** 2)),
+                ball_inertia=0.4 * bl["mass"] * bl["radius"] ** 2)
+
+
+def urdf_file_inertia(scene=None):
+    """the <inertia> values of racket.urdf / ball.urdf (what URDF_USE_INERTIA_FROM_FILE would select)"""
+    sc = scene or load_scene()
+    return dict(racket_inertia=tuple(sc["racket"]["inertia_diag"]), ball_inertia=sc["ball"]["inertia_diag"][0])
+
+
 def default_params(racket_scale=1.0, flags=F_DEFAULT, scene=None, **overrides):
     """Reference scene + the Bullet defaults of SURVEY.md Appendix B.2.
 
     Any TbParams field can be overridden by keyword (calibration on a host with pybullet).
     Derived fields (inverses, hull table, bound radius) are recomputed from the primary ones.
+    Inertia defaults to bullet_shape_inertia(); `**urdf_file_inertia()` selects the URDF values.
     """
     sc = scene or load_scene()
     rk, bl = sc["racket"], sc["ball"]
     s = float(racket_scale)
+    shape_inertia = bullet_shape_inertia(sc)
     prim = dict(
         dt=1.0 / 240.0,                 # racket.py:24; PyBullet default fixed time step
         gravity=9.81,                   # swingracket_env.py:154
@@ -114,9 +140,9 @@ def default_params(racket_scale=1.0, flags=F_DEFAULT, scene=None, **overrides):
         rest_vel_threshold=0.2, erp=0.2,
         contact_threshold=0.02 * bl["radius"],
         solver_iters=50, solver_tol=4e-6,
-        racket_mass=rk["mass"], racket_inertia=tuple(rk["inertia_diag"]),
+        racket_mass=rk["mass"], racket_inertia=shape_inertia["racket_inertia"],
         hull_margin=0.001,
-        ball_mass=bl["mass"], ball_inertia=bl["inertia_diag"][0], ball_radius=bl["radius"],
+        ball_mass=bl["mass"], ball_inertia=shape_inertia["ball_inertia"], ball_radius=bl["radius"],
         magnus_k=0.0, ball_spin_max=0.0,
         # restitution .9 / lateralFriction .2 on racket, ball, court (racket.py:43-45,
         # objects.py:29-31,48-50); the goal keeps Bullet's defaults (0 / 0.5); pair = product

@@ -156,3 +156,27 @@ def test_policy_step_rejects_bad_arguments(torch):
     rg = BatchedEnv(ENV_SWING, 64, device="cuda:0", params=default_params(flags=F_DEFAULT | F_RACKET_GROUND))
     with pytest.raises(StepperError):
         rg.policy_step(packed, rg.reset())
+
+
+def test_reference_policy_reward_statistics_match_the_pybullet_record(torch):
+    """The one PyBullet-derived pin there is: the reference's shipped policy, rolled out with its
+    training noise on the HIP envs, against the 100 PyBullet episodes recorded inside
+    backup_models/ppo_swing.zip (tests/golden/ppo_swing_reference_episodes.json). Statistical, not
+    trajectory-level: goal-hit rate within 2.7 standard errors of the 100-episode sample, the two
+    reward clusters where PyBullet has them. With the URDF-file inertia instead of Bullet's
+    shape-derived one the goal rate halves (the evidence for params.bullet_shape_inertia)."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import compare_reference_policy as crp
+    from tennisbot_rl_amd.params import urdf_file_inertia
+    ref = crp.summarize(json.load(open(os.path.join(root, "tests", "golden", "ppo_swing_reference_episodes.json")))["episode_rewards"])
+    got = crp.summarize(crp.rollout_rewards(num_envs=4096, episodes=4))
+    se = (ref["goal_rate"] * (1 - ref["goal_rate"]) / ref["episodes"]) ** 0.5
+    assert abs(got["goal_rate"] - ref["goal_rate"]) < 2.7 * se, (got, ref)
+    assert abs(got["goal_cluster_mean"] - ref["goal_cluster_mean"]) < 1.5, (got, ref)
+    assert abs(got["other_median"] - ref["other_median"]) < 1.0, (got, ref)
+    urdf = crp.summarize(crp.rollout_rewards(num_envs=4096, episodes=4, **urdf_file_inertia()))
+    assert urdf["goal_rate"] < got["goal_rate"] - 0.05, (urdf, got)

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""A statistical cross-check against PyBullet through the reference's own artifacts: the shipped PPO
+policy (tests/golden/ppo_swing_policy.npz, exported from backup_models/ppo_swing.zip) is rolled out,
+with the exploration noise it was trained with, on the batched HIP envs, and its episode rewards are
+compared with the 100 PyBullet episodes stable-baselines3 recorded when that file was saved
+(tests/golden/ppo_swing_reference_episodes.json). Not a trajectory-level parity proof -- the policy
+is stochastic and the start states are random -- but an engine whose contact, restitution or timing
+were off would move the goal-hit rate and the reward clusters."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+
+def bullet_recomputed_inertia():
+    from tennisbot_rl_amd.params import bullet_shape_inertia
+    return bullet_shape_inertia()
+
+
+def rollout_rewards(num_envs=4096, episodes=4, seed=0, **overrides):
+    import torch
+    from tennisbot_rl_amd.params import ENV_SWING, default_params
+    from tennisbot_rl_amd.ppo import build_actor_critic, pack_policy
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    policy = build_actor_critic(6, 6, (32, 64, 32)).to("cuda:0")
+    policy.load_sb3_arrays(dict(np.load(os.path.join(ROOT, "tests", "golden", "ppo_swing_policy.npz"))))
+    blob = pack_policy(policy)
+    env = BatchedEnv(ENV_SWING, num_envs, device="cuda:0", seed=seed, pipeline=True, track_terminal_obs=False, params=default_params(**overrides))
+    obs = env.reset()
+    total = torch.zeros(num_envs, device="cuda:0")
+    out = []
+    for ep in range(episodes):
+        steps = []
+        for t in range(26):
+            (obs, rew, done), _ = env.policy_step(blob, obs, seed=seed + 17)
+            steps.append((rew, done))
+        env.flush()  # terminal rewards arrive from the side streams
+        ret = torch.stack([r for r, _ in steps]).sum(0)
+        assert bool(steps[-1][1].all()) and not bool(torch.stack([d for _, d in steps[:-1]]).any())
+        out.append(ret.cpu().numpy())
+    return np.concatenate(out)
+
+
+def summarize(r):
+    r = np.asarray(r, dtype=np.float64)
+    goal = r >= 50.0  # only the goal bonus (+50) lifts an episode that high
+    rest = r[~goal]
+    return {"episodes": int(r.size), "mean": float(r.mean()), "goal_rate": float(goal.mean()),
+            "goal_cluster_mean": float(r[goal].mean()) if goal.any() else None,
+            "other_median": float(np.median(rest)), "other_p10": float(np.percentile(rest, 10)), "other_p90": float(np.percentile(rest, 90))}
+
+
+def main():
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "ppo_swing_reference_episodes.json")))
+    a = summarize(ref["episode_rewards"])
+    print("PyBullet (reference's record, 100 episodes):", json.dumps(a))
+    se = (a["goal_rate"] * (1 - a["goal_rate"]) / a["episodes"]) ** 0.5
+    variants = {"default parameters": {}, "inertia as in the URDF files": dict(racket_inertia=(0.04, 0.08, 0.12), ball_inertia=1.0),
+                "inertia recomputed from the collision shapes": bullet_recomputed_inertia(),
+                "racket recomputed, ball as in the URDF": dict(racket_inertia=bullet_recomputed_inertia()["racket_inertia"], ball_inertia=1.0),
+                "ball recomputed, racket as in the URDF": dict(racket_inertia=(0.04, 0.08, 0.12), ball_inertia=bullet_recomputed_inertia()["ball_inertia"])}
+    if len(sys.argv) > 1 and sys.argv[1] == "--default-only":
+        variants = {"default parameters": {}}
+    for name, over in variants.items():
+        b = summarize(rollout_rewards(**over))
+        print("HIP envs, %s %s:\n    %s" % (name, {k: (tuple(round(x, 5) for x in v) if isinstance(v, tuple) else v) for k, v in over.items()}, json.dumps(b)))
+        print("    goal-rate difference %+.3f = %+.1f standard errors of the 100-episode sample" % (b["goal_rate"] - a["goal_rate"], (b["goal_rate"] - a["goal_rate"]) / se))
+
+
+if __name__ == "__main__":
+    main()
