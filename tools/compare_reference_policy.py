@@ -64,10 +64,20 @@ def main():
                 "ball recomputed, racket as in the URDF": dict(racket_inertia=(0.04, 0.08, 0.12), ball_inertia=bullet_recomputed_inertia()["ball_inertia"])}
     if len(sys.argv) > 1 and sys.argv[1] == "--default-only":
         variants = {"default parameters": {}}
+    if len(sys.argv) > 1 and sys.argv[1] == "--sensitivity":
+        # not a fit (100 episodes cannot carry one): which recalled constants does the record constrain at all?
+        variants = {"default parameters": {}, "no damping": dict(lin_damp=0.0, ang_damp=0.0), "damping 0.02": dict(lin_damp=0.02, ang_damp=0.02),
+                    "damping 0.08": dict(lin_damp=0.08, ang_damp=0.08),
+                    "racket restitution 0.9 (not the product 0.81)": dict(rest_racket=0.9), "racket restitution 0.5": dict(rest_racket=0.5),
+                    "racket friction 0.2 (not the product 0.04)": dict(fric_racket=0.2), "restitution threshold 1.0": dict(rest_vel_threshold=1.0),
+                    "racket mass 2": dict(racket_mass=2.0), "ball mass 0.058": dict(ball_mass=0.058), "10 solver iterations": dict(solver_iters=10)}
     for name, over in variants.items():
         b = summarize(rollout_rewards(**over))
         print("HIP envs, %s %s:\n    %s" % (name, {k: (tuple(round(x, 5) for x in v) if isinstance(v, tuple) else v) for k, v in over.items()}, json.dumps(b)))
-        print("    goal-rate difference %+.3f = %+.1f standard errors of the 100-episode sample" % (b["goal_rate"] - a["goal_rate"], (b["goal_rate"] - a["goal_rate"]) / se))
+        rest = np.array([x for x in ref["episode_rewards"] if x < 50.0])
+        se_med = 1.2533 * rest.std(ddof=1) / len(rest) ** 0.5
+        print("    goal rate %+.3f = %+.1f s.e.;  median of the other episodes %+.2f = %+.1f s.e. (of the 100-episode sample)" % (
+            b["goal_rate"] - a["goal_rate"], (b["goal_rate"] - a["goal_rate"]) / se, b["other_median"] - a["other_median"], (b["other_median"] - a["other_median"]) / se_med))
 
 
 if __name__ == "__main__":
