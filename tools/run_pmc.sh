@@ -13,5 +13,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $OUT -o calib_$C -- python3 $R/tools/pmc_calibrate.py > $OUT/calib_$C.log 2>&1 || exit 1
   rocprofv3 --pmc $C --output-format csv -d $OUT -o swing4096_$C -- python3 $R/bench.py --steps 104 --warmup 26 --no-cpu-baseline > $OUT/swing4096_$C.log 2>&1 || exit 1
   rocprofv3 --pmc $C --output-format csv -d $OUT -o swing1m_$C -- python3 $R/bench.py --envs-per-gpu 1048576 --steps 52 --warmup 26 --no-cpu-baseline > $OUT/swing1m_$C.log 2>&1 || exit 1
+  rocprofv3 --pmc $C --output-format csv -d $OUT -o tennis4096_$C -- python3 $R/bench.py --env tennis --steps 104 --warmup 26 --no-cpu-baseline > $OUT/tennis4096_$C.log 2>&1 || exit 1
+  rocprofv3 --pmc $C --output-format csv -d $OUT -o tennis1m_$C -- python3 $R/bench.py --env tennis --envs-per-gpu 1048576 --steps 52 --warmup 26 --no-cpu-baseline > $OUT/tennis1m_$C.log 2>&1 || exit 1
 done
 ls -la $OUT

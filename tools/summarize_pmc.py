@@ -32,22 +32,25 @@ def main(d, out):
     write_ratio = cal_w[big] / truth_kib
     res = {"source": os.path.basename(d.rstrip("/")), "fetch_calibration": fetch_ratio, "write_calibration": write_ratio,
            "fetch_correction": 1.0 / fetch_ratio, "workloads": {}}
-    for tag in ("swing4096", "swing1m"):
+    for tag in ("swing4096", "swing1m", "tennis4096", "tennis1m"):
+        env = "swing" if tag.startswith("swing") else "tennis"
+        if not os.path.exists(os.path.join(d, "%s_FETCH_SIZE_counter_collection.csv" % tag)):
+            continue
         f, nf = per_kernel(os.path.join(d, "%s_FETCH_SIZE_counter_collection.csv" % tag), "FETCH_SIZE", "tb_step_kernel")
         w, _ = per_kernel(os.path.join(d, "%s_WRITE_SIZE_counter_collection.csv" % tag), "WRITE_SIZE", "tb_step_kernel")
         for n in f:
             fb = f[n] * 1024.0 / fetch_ratio
             wb = w[n] * 1024.0 / write_ratio
-            res["workloads"]["swing_%d" % n] = {
+            res["workloads"]["%s_%d" % (env, n)] = {
                 "launches": nf[n], "FETCH_SIZE_KiB_raw": f[n], "WRITE_SIZE_KiB_raw": w[n],
                 "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "traffic_bytes_per_launch": fb + wb,
-                "traffic_bytes_per_env_step": (fb + wb) / n, "algorithmic_bytes_per_env_step": 267}
+                "traffic_bytes_per_env_step": (fb + wb) / n, "algorithmic_bytes_per_env_step": 267 if env == "swing" else 263}
         # pipelined runs: the fast-forward is its own kernel (one launch per 26 agent steps)
         ff, nff = per_kernel(os.path.join(d, "%s_FETCH_SIZE_counter_collection.csv" % tag), "FETCH_SIZE", "tb_ff_kernel")
         fw, _ = per_kernel(os.path.join(d, "%s_WRITE_SIZE_counter_collection.csv" % tag), "WRITE_SIZE", "tb_ff_kernel")
         for n in ff:
             fb, wb = ff[n] * 1024.0 / fetch_ratio, fw[n] * 1024.0 / write_ratio
-            res["workloads"]["swing_%d" % n]["ff_kernel"] = {
+            res["workloads"]["%s_%d" % (env, n)]["ff_kernel"] = {
                 "launches": nff[n], "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
                 "traffic_bytes_per_env_per_launch": (fb + wb) / n,
                 "note": "one tb_ff_kernel launch per 26 tb_step_kernel launches; reads the parked state (121 B/env), writes reward (4 B/env)"}
