@@ -336,7 +336,7 @@ def main():
                          "kernel": "tb_step_kernel<%d>" % kind, "launch_us": launch_s * 1e6,
                          "algorithmic_bytes_per_env_step": ab["read"] + ab["write"],
                          "note": "latency-bound at this batch size, not bandwidth-bound (see sweep / DESIGN.md)"},
-            "parity": "vs CPU restatement (PyBullet parity unpinned: reference ships no tests or golden vectors, PyBullet not available offline)",
+            "parity": "bit-exact vs the CPU restatement; PyBullet parity unpinned at trajectory level (the reference ships no tests or golden vectors, PyBullet is not available offline), pinned statistically by the 100 PyBullet episodes recorded in the reference's ppo_swing.zip (DESIGN.md section 2)",
         }
     if args.sweep and not dist_on:
         sweep = []
