@@ -15,7 +15,11 @@
  *       (semi-implicit Euler, k1+k2|v| damping, sequential-impulse
  *       contacts with product-rule restitution/friction, Baumgarte ERP, exponential-map
  *       orientation update) with every recalled constant a TbParams field -- this part
- *       is pinned only by closed-form known-answer tests (tests/test_oracle_kat.py).
+ *       is pinned by closed-form known-answer tests (tests/test_oracle_kat.py) and,
+ *       statistically, by the one PyBullet record the reference holds: the rewards of the
+ *       last 100 PyBullet training episodes stored inside backup_models/ppo_swing.zip
+ *       (tests/golden/ppo_swing_reference_episodes.json). No
+ *       trajectory-level PyBullet vector exists, hence "unpinned" stays in this header.
  *
  * One source, two builds:  -DTBO_F64 -> libtb_oracle_f64.so  (the numerical "truth")
  *                          (default) -> libtb_oracle_f32.so  (same operation order as the
