@@ -562,21 +562,22 @@ def test_chunk_graphs_with_deferred_fast_forwards_are_bit_identical(torch, n_chu
 
 def test_deferred_fast_forward_is_launched_by_flush_and_by_slot_reuse(torch):
     """tb_set_defer without anyone calling tb_ff_launch_pending: flush() must deliver, and so must a
-    fifth parked episode end that needs the first one's slot back"""
+    ninth parked episode end that needs the first one's slot back (the handle has 8 slots)"""
     from tennisbot_rl_amd.stepper import BatchedEnv
     n = 300
     rng = np.random.default_rng(2)
-    acts = torch.from_numpy(rng.uniform(-1, 1, (140, n, 6)).astype(np.float32)).cuda()
+    T = 26 * 10 + 5
+    acts = torch.from_numpy(rng.uniform(-1, 1, (T, n, 6)).astype(np.float32)).cuda()
     ref = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=6, track_terminal_obs=False, pipeline=True)
     env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=6, track_terminal_obs=False, pipeline=True)
     ref.reset(); env.reset()
     env.set_defer(True)
-    a = [env.step(acts[t]) for t in range(140)]   # 5 episode ends, 4 slots
-    b = [ref.step(acts[t]) for t in range(140)]
+    a = [env.step(acts[t]) for t in range(T)]   # 10 episode ends, 8 slots
+    b = [ref.step(acts[t]) for t in range(T)]
     env.flush(); ref.flush()
     env.set_defer(False)
     torch.cuda.synchronize()
-    for t in range(140):
+    for t in range(T):
         assert all(torch.equal(x, y) for x, y in zip(a[t], b[t])), "step %d" % t
 
 
