@@ -429,8 +429,16 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
   if (blockIdx.x == 0 && threadIdx.x == 0)  // the first substep of every env in every agent step of this launch
     atomicAdd(&A.counters[6], (unsigned long long)A.n * (unsigned long long)(MULTI ? A.T : 1));
 #ifdef TB_DIAG_STAMPS
-  if ((threadIdx.x & 63) == 0) {  // per-wave sums (lane 0 carries the wave's scalar clock reads)
+  // a lane stops accumulating when its own env leaves the substep loop: the lane that stayed longest has
+  // the wave's complete account (every stamp adds the same scalar delta to all lanes still in the loop)
+  unsigned int mine = 0u;
+  for (int k = 0; k < 6; ++k) mine += st.acc[k];
+  unsigned int best = mine;
+  for (int off = 32; off > 0; off >>= 1) { unsigned int o = __shfl_xor(best, off, 64); best = o > best ? o : best; }
+  const unsigned long long holders = __ballot(mine == best);
+  if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)holders) - 1u)
     for (int k = 0; k < 6; ++k) atomicAdd(&g_diag_cycles[k], (unsigned long long)st.acc[k]);
+  if ((threadIdx.x & 63) == 0) {  // per-wave scalars
     atomicAdd(&g_diag_cycles[8], stamp_now() - t_kernel0);
     atomicAdd(&g_diag_cycles[9], 1ull);
     atomicAdd(&g_diag_cycles[14], __builtin_amdgcn_s_memrealtime() - rt_kernel0);  // 100 MHz ticks
