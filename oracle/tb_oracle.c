@@ -374,11 +374,16 @@ typedef struct {
   int kind;
   v3 n, rr, t1, t2; /* n: toward the pushed body; rr: contact point relative to the racket COM */
   real mu, target, kn, kt1, kt2, jn, jt1, jt2;
+  real inv_s2;      /* 1 / scale^2: the racket's inverse inertia at this env's globalScaling (see racket_invI) */
 } Row;
 
-static inline v3 racket_invI(const Prm *P, q4 q, v3 x) {
+/* I_w^-1 x for a racket built with globalScaling s (tennisbot_env.py:234). Bullet derives the inertia
+ * from the collision shape (params.bullet_shape_inertia), so scaling the shape by s scales the box
+ * formula's extents and the inertia by s^2 (the unscaled 1 mm margin changes that by < 0.3 %); the
+ * mass is not scaled. P holds the scale-1 inverse inertia; inv_s2 = 1 / (s * s). */
+static inline v3 racket_invI(const Prm *P, q4 q, v3 x, real inv_s2) {
   v3 b = qrot_inv(q, x);
-  b = V3(b.x * P->racket_inv_inertia[0], b.y * P->racket_inv_inertia[1], b.z * P->racket_inv_inertia[2]);
+  b = V3((b.x * P->racket_inv_inertia[0]) * inv_s2, (b.y * P->racket_inv_inertia[1]) * inv_s2, (b.z * P->racket_inv_inertia[2]) * inv_s2);
   return qrot(q, b);
 }
 static inline v3 rel_vel(const Row *c, const Racket *rk, const Ball *b, v3 rb) {
@@ -403,20 +408,21 @@ static inline void plane_space(v3 n, v3 *p, v3 *q) {
 static inline void apply_impulse(const Prm *P, const Row *c, Racket *rk, Ball *b, v3 rb, v3 dir, real j, int angular_ball) {
   if (c->kind == ROW_RACKET_COURT) {
     rk->v = axpy3(j * P->racket_inv_mass, dir, rk->v);
-    rk->w = axpy3(j, racket_invI(P, rk->q, cross3(c->rr, dir)), rk->w);
+    rk->w = axpy3(j, racket_invI(P, rk->q, cross3(c->rr, dir), c->inv_s2), rk->w);
     return;
   }
   b->v = axpy3(j * P->ball_inv_mass, dir, b->v);
   if (angular_ball) b->w = axpy3(j * P->ball_inv_inertia, cross3(rb, dir), b->w);
   if (c->kind == ROW_BALL_RACKET) {
     rk->v = axpy3(-(j * P->racket_inv_mass), dir, rk->v);
-    rk->w = axpy3(-j, racket_invI(P, rk->q, cross3(c->rr, dir)), rk->w);
+    rk->w = axpy3(-j, racket_invI(P, rk->q, cross3(c->rr, dir), c->inv_s2), rk->w);
   }
 }
-static void setup_row(const Prm *P, Row *c, const Hit *h, int kind, real e, real mu, const Racket *rk, const Ball *b) {
+static void setup_row(const Prm *P, Row *c, const Hit *h, int kind, real e, real mu, const Racket *rk, const Ball *b, real scale) {
   const real r = P->ball_radius;
   memset(c, 0, sizeof *c);
   c->kind = kind; c->n = h->n; c->rr = h->rr; c->mu = mu;
+  c->inv_s2 = R(1) / (scale * scale);
   plane_space(c->n, &c->t1, &c->t2);
   v3 rb = mul3(-r, c->n);
   real kn, kt1, kt2;
@@ -425,9 +431,9 @@ static void setup_row(const Prm *P, Row *c, const Hit *h, int kind, real e, real
   if (kind == ROW_BALL_RACKET) { kn = kn + P->racket_inv_mass; kt1 = kt1 + P->racket_inv_mass; kt2 = kt2 + P->racket_inv_mass; }
   if (kind != ROW_BALL_STATIC) {
     v3 a;
-    a = cross3(c->rr, c->n);  kn = kn + dot3(a, racket_invI(P, rk->q, a));
-    a = cross3(c->rr, c->t1); kt1 = kt1 + dot3(a, racket_invI(P, rk->q, a));
-    a = cross3(c->rr, c->t2); kt2 = kt2 + dot3(a, racket_invI(P, rk->q, a));
+    a = cross3(c->rr, c->n);  kn = kn + dot3(a, racket_invI(P, rk->q, a, c->inv_s2));
+    a = cross3(c->rr, c->t1); kt1 = kt1 + dot3(a, racket_invI(P, rk->q, a, c->inv_s2));
+    a = cross3(c->rr, c->t2); kt2 = kt2 + dot3(a, racket_invI(P, rk->q, a, c->inv_s2));
   }
   c->kn = R(1) / kn; c->kt1 = R(1) / kt1; c->kt2 = R(1) / kt2;
   real vn = dot3(c->n, rel_vel(c, rk, b, rb));
@@ -644,11 +650,11 @@ static int substep(const Prm *P, int kind, Racket *rk, Ball *b, v3 Fr, v3 Tr, v3
   integrate_velocities(P, rk, b, Fr, Tr, Fb);
 
   if (bits) {
-    if (bits & CT_RACKET) setup_row(P, &rows[nrows++], &h, ROW_BALL_RACKET, P->rest_racket, P->fric_racket, rk, b);
-    if (bits & CT_GROUND) setup_row(P, &rows[nrows++], &hg, ROW_BALL_STATIC, P->rest_court, P->fric_court, rk, b);
-    if (bits & CT_NET) setup_row(P, &rows[nrows++], &hn, ROW_BALL_STATIC, P->rest_court, P->fric_court, rk, b);
-    if (bits & CT_GOAL) setup_row(P, &rows[nrows++], &hc, ROW_BALL_STATIC, P->rest_goal, P->fric_goal, rk, b);
-    for (int j = 0; j < nrg; ++j) setup_row(P, &rows[nrows++], &hrg[j], ROW_RACKET_COURT, P->rest_racket_court, P->fric_racket_court, rk, b);
+    if (bits & CT_RACKET) setup_row(P, &rows[nrows++], &h, ROW_BALL_RACKET, P->rest_racket, P->fric_racket, rk, b, scale);
+    if (bits & CT_GROUND) setup_row(P, &rows[nrows++], &hg, ROW_BALL_STATIC, P->rest_court, P->fric_court, rk, b, scale);
+    if (bits & CT_NET) setup_row(P, &rows[nrows++], &hn, ROW_BALL_STATIC, P->rest_court, P->fric_court, rk, b, scale);
+    if (bits & CT_GOAL) setup_row(P, &rows[nrows++], &hc, ROW_BALL_STATIC, P->rest_goal, P->fric_goal, rk, b, scale);
+    for (int j = 0; j < nrg; ++j) setup_row(P, &rows[nrows++], &hrg[j], ROW_RACKET_COURT, P->rest_racket_court, P->fric_racket_court, rk, b, scale);
     solve_contacts(P, rows, nrows, rk, b);
   }
   integrate_pose(P, rk, b);

@@ -310,9 +310,15 @@ struct RowR {  // ball vs racket
   float mu, target, kn, kt1, kt2, jn, jt1, jt2;
 };
 
-TB_DEV vec3 racket_invI(const KParams& P, quat q, vec3 x) {
+// I_w^-1 x for a racket built with globalScaling s: Bullet derives the inertia from the collision shape
+// (params.bullet_shape_inertia), so a shape scaled by s has s^2 the inertia (mass is not scaled); P holds
+// the scale-1 inverse inertia, inv_s2 = 1 / (s * s). SCALED = false (SwingRacket, s == 1) drops the
+// multiplications by 1.
+template <bool SCALED>
+TB_DEV vec3 racket_invI(const KParams& P, quat q, vec3 x, float inv_s2) {
   vec3 b = rotate_inv(q, x);
   b = mk(b.x * P.racket_inv_inertia[0], b.y * P.racket_inv_inertia[1], b.z * P.racket_inv_inertia[2]);
+  if (SCALED) b = mk(b.x * inv_s2, b.y * inv_s2, b.z * inv_s2);
   return rotate(q, b);
 }
 TB_DEV void plane_space(vec3 n, vec3& p, vec3& q) {
@@ -346,15 +352,17 @@ TB_DEV void setup_static(const KParams& P, RowS& c, const Hit& h, float e, float
   vec3 rb = (-P.ball_radius) * c.n;
   c.target = contact_target(P, dot(c.n, ball_point_vel(b, rb)), h.dist, e);
 }
-TB_DEV void setup_racket(const KParams& P, RowR& c, const Hit& h, const Racket& rk, const Ball& b) {
+template <bool SCALED>
+TB_DEV void setup_racket(const KParams& P, RowR& c, const Hit& h, const Racket& rk, const Ball& b, float scale) {
   const float r = P.ball_radius;
+  const float inv_s2 = SCALED ? 1.0f / (scale * scale) : 1.0f;
   c.n = h.n; c.rr = h.rr; c.mu = P.fric_racket; c.jn = 0.0f; c.jt1 = 0.0f; c.jt2 = 0.0f;
   plane_space(c.n, c.t1, c.t2);
   float kt = FMA(P.ball_inv_inertia, r * r, P.ball_inv_mass);
   vec3 a;
-  a = cross(c.rr, c.n);  c.an = racket_invI(P, rk.q, a);  c.kn = 1.0f / ((P.ball_inv_mass + P.racket_inv_mass) + dot(a, c.an));
-  a = cross(c.rr, c.t1); c.at1 = racket_invI(P, rk.q, a); c.kt1 = 1.0f / ((kt + P.racket_inv_mass) + dot(a, c.at1));
-  a = cross(c.rr, c.t2); c.at2 = racket_invI(P, rk.q, a); c.kt2 = 1.0f / ((kt + P.racket_inv_mass) + dot(a, c.at2));
+  a = cross(c.rr, c.n);  c.an = racket_invI<SCALED>(P, rk.q, a, inv_s2);  c.kn = 1.0f / ((P.ball_inv_mass + P.racket_inv_mass) + dot(a, c.an));
+  a = cross(c.rr, c.t1); c.at1 = racket_invI<SCALED>(P, rk.q, a, inv_s2); c.kt1 = 1.0f / ((kt + P.racket_inv_mass) + dot(a, c.at1));
+  a = cross(c.rr, c.t2); c.at2 = racket_invI<SCALED>(P, rk.q, a, inv_s2); c.kt2 = 1.0f / ((kt + P.racket_inv_mass) + dot(a, c.at2));
   vec3 rb = (-r) * c.n;
   c.target = contact_target(P, dot(c.n, rel_vel_racket(c, rk, b, rb)), h.dist, P.rest_racket);
 }
@@ -522,8 +530,10 @@ TB_DEV int racket_vs_ground(const KParams& P, const float4* hull, const Racket& 
   }
   return (picks[1] >= 0) + (picks[2] >= 0) + (picks[3] >= 0) + 1;
 }
+template <bool SCALED>
 TB_DEV void setup_ground_row(const KParams& P, const float4* hull, RowG& c, int k, float s, vec3 zr, const Racket& rk) {
   const vec3 n = mk(0.0f, 0.0f, 1.0f);
+  const float inv_s2 = SCALED ? 1.0f / (s * s) : 1.0f;
   vec3 t1, t2;
   plane_space(n, t1, t2);
   vec3 v = hull_vertex(P, hull, k, s);
@@ -532,9 +542,9 @@ TB_DEV void setup_ground_row(const KParams& P, const float4* hull, RowG& c, int 
   c.rr.z = c.rr.z - P.hull_margin;  // the point on the inflated hull
   c.jn = 0.0f; c.jt1 = 0.0f; c.jt2 = 0.0f;
   vec3 a;
-  a = cross(c.rr, n);  c.an = racket_invI(P, rk.q, a);  c.kn = 1.0f / (P.racket_inv_mass + dot(a, c.an));
-  a = cross(c.rr, t1); c.at1 = racket_invI(P, rk.q, a); c.kt1 = 1.0f / (P.racket_inv_mass + dot(a, c.at1));
-  a = cross(c.rr, t2); c.at2 = racket_invI(P, rk.q, a); c.kt2 = 1.0f / (P.racket_inv_mass + dot(a, c.at2));
+  a = cross(c.rr, n);  c.an = racket_invI<SCALED>(P, rk.q, a, inv_s2);  c.kn = 1.0f / (P.racket_inv_mass + dot(a, c.an));
+  a = cross(c.rr, t1); c.at1 = racket_invI<SCALED>(P, rk.q, a, inv_s2); c.kt1 = 1.0f / (P.racket_inv_mass + dot(a, c.at1));
+  a = cross(c.rr, t2); c.at2 = racket_invI<SCALED>(P, rk.q, a, inv_s2); c.kt2 = 1.0f / (P.racket_inv_mass + dot(a, c.at2));
   c.target = contact_target(P, dot(n, rk.v + cross(rk.w, c.rr)), dist, P.rest_racket_court);
 }
 TB_DEV bool normal_ground(const KParams& P, RowG& c, Racket& rk, float& jref) {
@@ -732,10 +742,10 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, ve
         // picks are found in order 0..3 and a later one exists only if the earlier ones do: compact already
 #pragma unroll
         for (int j = 0; j < TB_MAX_RG; ++j)
-          if (rg_picks[j] >= 0) setup_ground_row(P, hull, R.rg[j], rg_picks[j], scale, rg_zr, rk);
+          if (rg_picks[j] >= 0) setup_ground_row<KIND == TB_ENV_TENNIS>(P, hull, R.rg[j], rg_picks[j], scale, rg_zr, rk);
       }
       R.on[0] = bits & CT_RACKET; R.on[1] = bits & CT_GROUND; R.on[2] = bits & CT_NET; R.on[3] = bits & CT_GOAL;
-      if (R.on[0]) setup_racket(P, R.rk, hr, rk, b);
+      if (R.on[0]) setup_racket<KIND == TB_ENV_TENNIS>(P, R.rk, hr, rk, b, scale);
       if (R.on[1]) setup_static(P, R.st[0], hg, P.rest_court, P.fric_court, b);
       if (R.on[2]) setup_static(P, R.st[1], hn, P.rest_court, P.fric_court, b);
       if (R.on[3]) setup_static(P, R.st[2], hc, P.rest_goal, P.fric_goal, b);

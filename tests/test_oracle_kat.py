@@ -648,3 +648,29 @@ def test_racket_ground_contact_dynamics():
             assert np.isfinite(s["racket_quat"]).all() and abs(np.linalg.norm(s["racket_quat"][0]) - 1) < 1e-6
         else:
             assert zmin < -1.0
+
+
+@pytest.mark.parametrize("scale", [1.0, 2.0, 3.0])
+def test_scaled_racket_has_s2_inertia_in_contact_response(scale):
+    """globalScaling s (curriculum, tennisbot_env.py:234): the shape-derived inertia grows with s^2,
+    the mass does not. An off-centre hit: the racket's angular momentum about its COM, (s^2 I) dw,
+    equals the arm crossed with the impulse it received, and its linear momentum the impulse itself."""
+    p = default_params(racket_scale=scale, lin_damp=0.0, ang_damp=0.0, gravity=0.0)
+    b = OracleBatch(p, ENV_TENNIS, 1, precision="f64")
+    r, ht = 0.0335, float(p.racket_half_thick) * scale
+    rpos = np.array((10.0, 0.0, 3.0))
+    ball = rpos + np.array((-(ht + 0.001 + r) - 0.0002, 0.04 * scale, 0.08 * scale))  # in front of the face, off the COM
+    v0 = np.array((6.0, 0.5, -0.3))
+    w, d = make_words(ENV_TENNIS, 1, racket_pos=rpos, ball_pos=ball, ball_vel=v0, step_count=50, racket_scale=scale)
+    b.set_state_words(w, d)
+    s0 = b.get_state()
+    hit, dist, n, rr = query_racket(p, s0["racket_pos"][0], s0["racket_quat"][0], s0["ball_pos"][0])
+    assert hit and n[0] == pytest.approx(-1.0)
+    b.step(np.zeros((1, 2), np.float32))  # Tennisbot's own force on the racket: 4 * 9.81 upward, gravity is off here
+    s1 = b.get_state()
+    J = 0.05 * (s1["ball_vel"][0] - np.float32(v0).astype(np.float64))       # impulse on the ball
+    dv = s1["racket_vel"][0] - np.array((0.0, 0.0, 4 * 9.81 / 4.0 * DT))
+    assert np.allclose(4.0 * dv, -J, rtol=1e-9, atol=1e-12)                    # mass is NOT scaled
+    inertia = np.array([float(np.format_float_positional(np.float32(x), unique=True)) for x in p.racket_inertia]) * scale * scale
+    assert np.allclose(inertia * s1["racket_angvel"][0], np.cross(rr, -J), rtol=1e-6, atol=1e-12)
+    assert np.abs(s1["racket_angvel"][0]).max() > 1e-3                          # the hit really was off-centre
