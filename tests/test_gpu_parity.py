@@ -214,6 +214,65 @@ def test_forced_contacts_exercise_the_solver(torch):
     env.close()
 
 
+@pytest.mark.parametrize("kind,rg", [(ENV_TENNIS, False), (ENV_SWING, False), (ENV_TENNIS, True), (ENV_SWING, True)])
+def test_fuzzed_states_around_the_racket_stay_bit_exact(torch, kind, rg):
+    """16 384 random states with the ball anywhere in a thin shell around a randomly oriented (Tennisbot:
+    randomly scaled) racket that itself hovers close to the court -- faces, rim, handle, corners, grazing
+    and deep overlaps, ball on racket AND ground at once -- stepped 8 times: every output and the whole
+    state bit-exact against the oracle. The outline sweep's inside / edge / corner cases and the
+    multi-row solver only occur by accident in the policy-driven tests. rg: with the opt-in
+    racket<->court contact as well (racket, ball and court in one solve)."""
+    n = 2048 if rg else 16384
+    rng = np.random.default_rng(97 + kind + 10 * rg)
+    p = default_params()
+    env, ref = make_pair(torch, kind, n, auto_reset=False, flags=F_DEFAULT | (F_RACKET_GROUND if rg else 0))
+    ref.L.tbo_set_threads(ref.h, 8)
+    scale = rng.uniform(1.0, 3.0, n) if kind == ENV_TENNIS else np.ones(n)
+    q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    rp = np.stack([rng.uniform(8, 12, n), rng.uniform(-4, 4, n), rng.uniform(0.05, 1.2, n) * scale], 1)
+    if rg:  # keep every hull vertex above the court (the stateless manifold ignores vertices below it): COM at least its reach up
+        rp[:, 2] = rng.uniform(0.52, 0.75, n) * scale
+    ht, r = float(p.racket_half_thick), float(p.ball_radius)
+    pad = r + 0.004
+    loc = np.stack([rng.uniform(-(ht * scale + pad), ht * scale + pad), rng.uniform(-0.16 * scale - pad, 0.16 * scale + pad),
+                    rng.uniform(-0.51 * scale - pad, 0.21 * scale + pad)], 1)
+    # push two thirds of the samples onto the shell (the rest stay inside: deep overlaps)
+    k = rng.integers(0, 3, n); sgn = np.where(rng.random(n) < 0.5, -1.0, 1.0); shell = rng.random(n) < 0.67
+    ext = np.stack([ht * scale, 0.15 * scale, np.where(sgn > 0, 0.197, 0.5) * scale], 1)
+    idx = np.arange(n)
+    loc[idx[shell], k[shell]] = (sgn * (ext[idx, k] + r + rng.uniform(-0.004, 0.001, n)))[shell]
+
+    def rot(q, v):
+        u, w = q[:, :3], q[:, 3:4]
+        t = 2 * np.cross(u, v)
+        return v + w * t + np.cross(u, t)
+    bp = rp + rot(q, loc)
+    bp[:, 2] = np.maximum(bp[:, 2], 0.005 + r - 0.003)  # never (much) under the court
+    fields = dict(racket_pos=rp, racket_quat=q, racket_vel=rng.uniform(-4, 4, (n, 3)), racket_angvel=rng.uniform(-6, 6, (n, 3)),
+                  ball_pos=bp, ball_vel=rng.uniform(-15, 15, (n, 3)), ball_angvel=rng.uniform(-60, 60, (n, 3)))
+    if kind == ENV_TENNIS:
+        fields.update(shoot_force=(30, 0, 20), step_count=50, racket_scale=scale)
+        A = 2
+    else:
+        fields.update(goal=np.stack([rng.uniform(-11, -4, n), rng.uniform(-4, 4, n)], 1), spawn_pos=(9, 0, 0.6), init_dist=rng.uniform(8, 20, n),
+                      step_count=rng.integers(0, 24, n))
+        A = 6
+    w, d = make_words(kind, n, **fields)
+    env.set_state_words(w.view(np.int32), d); ref.set_state_words(w, d)
+    for t in range(4 if rg else 8):
+        a = rng.uniform(-1, 1, (n, A)).astype(np.float32)
+        obs, rew, done = env.step(torch.from_numpy(a).cuda())
+        o2, r2, d2, s2 = ref.step(a)
+        same(done.cpu().numpy(), d2, "fuzz done %d" % t)
+        same(env.last_substeps().cpu().numpy(), s2, "fuzz substeps %d" % t)
+        same(obs.cpu().numpy(), o2, "fuzz obs %d" % t)
+        same(rew.cpu().numpy(), r2, "fuzz reward %d" % t)
+        compare_state(env, ref, "fuzz %d" % t)
+    c = env.counters()
+    assert c["racket_ball_contact_substeps"] > n // 8 and c["nonfinite_states"] == 0
+    env.close()
+
+
 def test_rollout_equals_repeated_steps(torch):
     from tennisbot_rl_amd.stepper import BatchedEnv
     n, T = 1000, 60
