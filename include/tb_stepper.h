@@ -244,6 +244,22 @@ int tb_policy_step(TbHandle *h, const float *weights_dev, const float *obs_in_de
                    float *reward_dev, uint8_t *done_dev, uint64_t noise_seed, int deterministic, void *stream);
 
 /*
+ * n_steps of tb_policy_step without a launch boundary between them: whole episodes per launch, the
+ * policy's weights resident in registers, the envs' state too; the observation a step produces is the
+ * one the next step acts on (obs_in_dev is only read for the first). Output arrays are [n_steps][N][..];
+ * step_strides_bytes (or NULL = contiguous) gives the distance in bytes between consecutive steps of
+ * {actions, raw_actions, logp, value, obs, reward, done} -- e.g. the record size of a packed rollout
+ * buffer; a 0 entry means contiguous for that array. Per env the arithmetic and the noise (keyed by
+ * env, episode, step) are those of tb_policy_step: identical results. Requires TB_F_AUTO_RESET; on
+ * SwingRacket-v0 also tb_set_pipeline(h, 1) and lockstep episodes (the launches end where the episodes
+ * end, each followed by its fast-forward on a side stream; terminal rewards complete after tb_flush).
+ */
+int tb_policy_rollout(TbHandle *h, int n_steps, const float *weights_dev, const float *obs_in_dev,
+                      float *actions_dev, float *raw_actions_dev, float *logp_dev, float *value_dev,
+                      float *obs_dev, float *reward_dev, uint8_t *done_dev, const size_t *step_strides_bytes,
+                      uint64_t noise_seed, int deterministic, void *stream);
+
+/*
  * Pipelined fast-forward (SwingRacket-v0 with TB_F_AUTO_RESET; HIP streams, no reference
  * counterpart). The <= 775-substep fast-forward of swingracket_env.py:105-141 takes no
  * agent input, and the next episode does not depend on its outcome. With the pipeline

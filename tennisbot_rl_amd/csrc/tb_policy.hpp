@@ -77,45 +77,63 @@ struct LayerRegs {
 };
 
 // one tower for 32 envs: lane l works on env (l & 31); out[0..3] = head rows 0-3 (lanes 0-31) or 4-7
-// (lanes 32-63) of that env. `obs_row`: this lane's env's observation (clamped to a valid env).
-template <int KIND>
-TB_DEV void policy_tower(const float* g, const float* obs_row, int lane, float (&out)[4]) {
-  using N = PolicyNet<KIND>;
-  constexpr int O = Dims<KIND>::O, NP0 = O / 2, NT0 = N::H0 / 32, NT1 = N::H1 / 32, NT2 = N::H2 / 32;
-  LayerRegs<NT0, NP0> l0;
-  LayerRegs<NT1, NT0 * 16> l1;
-  // every operand of the tower is requested up front (one VGPR per fragment): the loads of the later
-  // layers land while the earlier ones compute; the barrier keeps the scheduler from sinking each load
-  // down to its MFMA
-  float x0[NP0];
-#pragma unroll
-  for (int pr = 0; pr < NP0; ++pr) x0[pr] = obs_row[2 * pr + (lane >> 5)];
-  l0.load(g, lane);
-  g += layer_floats(O, N::H0);
-  l1.load(g, lane);
-  g += layer_floats(N::H0, N::H1);
-  float h0[NT0 * 16], h1[NT1 * 16], y[16];
-  if constexpr (N::NH == 3) {
-    LayerRegs<NT2, NT1 * 16> l2;
-    LayerRegs<1, NT2 * 16> lh;
-    l2.load(g, lane);
-    g += layer_floats(N::H1, N::H2);
+// (lanes 32-63) of that env. Every operand of the tower is requested by load() up front (one VGPR per
+// fragment): the loads of the later layers land while the earlier ones compute (policy_tower), or stay
+// resident across the steps of a rollout launch (tb_policy_rollout_kernel).
+template <int KIND> struct TowerRegs;
+template <> struct TowerRegs<TB_ENV_SWING> {  // 6 -> 32 -> 64 -> 32 -> head
+  using N = PolicyNet<TB_ENV_SWING>;
+  static constexpr int O = Dims<TB_ENV_SWING>::O, NP0 = O / 2;
+  LayerRegs<1, NP0> l0;
+  LayerRegs<2, 16> l1;
+  LayerRegs<1, 32> l2;
+  LayerRegs<1, 16> lh;
+  TB_DEV void load(const float* g, int lane) {
+    l0.load(g, lane); g += layer_floats(O, N::H0);
+    l1.load(g, lane); g += layer_floats(N::H0, N::H1);
+    l2.load(g, lane); g += layer_floats(N::H1, N::H2);
     lh.load(g, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    float h2[NT2 * 16];
+  }
+  TB_DEV void apply(const float (&x0)[NP0], float (&out)[4]) const {
+    float h0[16], h1[32], h2[16], y[16];
     l0.template apply<true>(x0, h0);
     l1.template apply<true>(h0, h1);
     l2.template apply<true>(h1, h2);
     lh.template apply<false>(h2, y);
-  } else {
-    LayerRegs<1, NT1 * 16> lh;
+    out[0] = y[0]; out[1] = y[1]; out[2] = y[2]; out[3] = y[3];
+  }
+};
+template <> struct TowerRegs<TB_ENV_TENNIS> {  // 12 -> 64 -> 64 -> head
+  using N = PolicyNet<TB_ENV_TENNIS>;
+  static constexpr int O = Dims<TB_ENV_TENNIS>::O, NP0 = O / 2;
+  LayerRegs<2, NP0> l0;
+  LayerRegs<2, 32> l1;
+  LayerRegs<1, 32> lh;
+  TB_DEV void load(const float* g, int lane) {
+    l0.load(g, lane); g += layer_floats(O, N::H0);
+    l1.load(g, lane); g += layer_floats(N::H0, N::H1);
     lh.load(g, lane);
-    __builtin_amdgcn_sched_barrier(0);
+  }
+  TB_DEV void apply(const float (&x0)[NP0], float (&out)[4]) const {
+    float h0[32], h1[32], y[16];
     l0.template apply<true>(x0, h0);
     l1.template apply<true>(h0, h1);
     lh.template apply<false>(h1, y);
+    out[0] = y[0]; out[1] = y[1]; out[2] = y[2]; out[3] = y[3];
   }
-  out[0] = y[0]; out[1] = y[1]; out[2] = y[2]; out[3] = y[3];
+};
+
+// `obs_row`: this lane's env's observation (clamped to a valid env)
+template <int KIND>
+TB_DEV void policy_tower(const float* g, const float* obs_row, int lane, float (&out)[4]) {
+  constexpr int NP0 = TowerRegs<KIND>::NP0;
+  float x0[NP0];
+#pragma unroll
+  for (int pr = 0; pr < NP0; ++pr) x0[pr] = obs_row[2 * pr + (lane >> 5)];
+  TowerRegs<KIND> regs;
+  regs.load(g, lane);
+  __builtin_amdgcn_sched_barrier(0);  // keeps the scheduler from sinking each load down to its MFMA
+  regs.apply(x0, out);
 }
 
 // standard normals from Philox bits (Box-Muller); keyed by (seed, global env id, episode, step):
@@ -154,9 +172,12 @@ TB_DEV void policy_towers(const KArgs& A, float* s_mean) {
   }
 }
 // wave 0, after the workgroup barrier: sample, report, and hand the clipped actions to the env step
+// `t`: the step of a rollout launch (tb_policy_rollout_kernel) whose output rows are written; 0 otherwise
 template <int KIND>
-TB_DEV void policy_sample(const KArgs& A, const float* s_mean, int i, const EnvRegs& e, float* a) {
+TB_DEV void policy_sample(const KArgs& A, const float* s_mean, int i, const EnvRegs& e, float* a, size_t t = 0) {
   constexpr int NA = Dims<KIND>::A;
+  float* out_act = A.pol_actions + t * A.st_act;
+  float* out_raw = A.pol_raw + t * A.st_raw;
   const float* log_std = A.pol_weights + 2 * tower_floats<KIND>();
   const float* mean = s_mean + (threadIdx.x & 63) * 8;
   float eps[NA], logp = 0.0f;
@@ -166,11 +187,11 @@ TB_DEV void policy_sample(const KArgs& A, const float* s_mean, int i, const EnvR
     float ek = A.pol_deterministic ? 0.0f : eps[k];
     float raw = FMA(expf(log_std[k]), ek, mean[k]);
     logp += FMA(-0.5f * ek, ek, -log_std[k]) - 0.9189385332046727f;  // -(eps^2)/2 - log_std - ln(2 pi)/2
-    A.pol_raw[(size_t)i * NA + k] = raw;
+    out_raw[(size_t)i * NA + k] = raw;
     a[k] = fminf(fmaxf(raw, -1.0f), 1.0f);  // SB3 clips Box actions before env.step
-    A.pol_actions[(size_t)i * NA + k] = a[k];
+    out_act[(size_t)i * NA + k] = a[k];
   }
-  A.pol_logp[i] = logp;
+  A.pol_logp[t * A.st_logp + i] = logp;
 }
 
 }  // namespace

@@ -58,6 +58,8 @@ struct KArgs {
   float* pol_value;          // [n]
   unsigned long long pol_seed;
   int pol_deterministic;
+  // per-step strides (in elements) of the output arrays of a policy rollout launch (tb_policy_rollout)
+  size_t st_obs, st_rew, st_done, st_act, st_raw, st_logp, st_val;
 };
 
 struct EnvRegs {
@@ -446,6 +448,109 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
 #endif
 }
 
+// T agent steps with the policy inside, ONE launch: no launch boundary, no state round trip between the
+// steps of an episode. Five waves per 64 envs: waves 0-3 are the towers of tb_policy.hpp, their weight
+// fragments loaded once and resident in registers for the whole launch; wave 4 holds the 64 envs' state
+// in registers and steps them. Per step: towers (obs from LDS) -> barrier -> wave 4 samples, steps,
+// writes the step's outputs and the new observations to LDS -> barrier. The two role branches execute
+// the same number of barriers. SwingRacket episodes end at most once per launch, at its last step (the
+// host cuts rollouts at episode ends): those lanes are parked for tb_ff_kernel exactly as in the
+// pipelined step kernel. Same arithmetic per env as tb_policy_step, step after step: identical results.
+template <int KIND>
+__global__ void __launch_bounds__(320) tb_policy_rollout_kernel(KArgs A) {
+  constexpr int NA = Dims<KIND>::A, NO = Dims<KIND>::O;
+  __shared__ float4 s_hull[TB_MAX_HULL * 2];
+  __shared__ __attribute__((aligned(16))) float s_mean[64 * 8];
+  __shared__ __attribute__((aligned(16))) float s_obs[64 * NO];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int k = threadIdx.x; k < 2 * A.P.n_hull; k += blockDim.x) s_hull[k] = A.hull[k];
+  if (wave < 4) {
+    constexpr int NP0 = TowerRegs<KIND>::NP0;
+    const int tower = wave >> 1, half = wave & 1, h = lane >> 5;
+    const int slot = half * 32 + (lane & 31), env = blockIdx.x * 64 + slot;
+    const int env_c = env < A.n ? env : A.n - 1;
+    TowerRegs<KIND> regs;
+    regs.load(A.pol_weights + tower * tower_floats<KIND>(), lane);
+    __syncthreads();
+    for (int t = 0; t < A.T; ++t) {
+      float x0[NP0], out[4];
+      if (t == 0) {
+#pragma unroll
+        for (int pr = 0; pr < NP0; ++pr) x0[pr] = A.pol_obs[(size_t)env_c * NO + 2 * pr + h];
+      } else {
+#pragma unroll
+        for (int pr = 0; pr < NP0; ++pr) x0[pr] = s_obs[slot * NO + 2 * pr + h];
+      }
+      regs.apply(x0, out);
+      if (tower == 0) *reinterpret_cast<float4*>(s_mean + slot * 8 + h * 4) = make_float4(out[0], out[1], out[2], out[3]);
+      else if (lane < 32 && env < A.n) A.pol_value[(size_t)t * A.st_val + env] = out[0];
+      __syncthreads();  // the action means of step t are in LDS
+      __syncthreads();  // the observations after step t are in LDS
+    }
+    return;
+  }
+  const int i = blockIdx.x * 64 + lane;
+  const bool live = i < A.n;
+  EnvRegs e;
+  if (live) load_env<KIND>(A.words, A.done_state, A.n, i, e);
+  uint32_t cnt[TB_N_COUNTERS];
+#pragma unroll
+  for (int k = 0; k < TB_N_COUNTERS; ++k) cnt[k] = 0u;
+  bool any_reset = false;
+#ifdef TB_DIAG_STAMPS
+  Stamps st;
+  for (int k = 0; k < 8; ++k) st.acc[k] = 0u;
+  st.t = stamp_now();
+#endif
+  __syncthreads();
+  for (int t = 0; t < A.T; ++t) {
+    __syncthreads();  // the action means of step t are in LDS
+    if (live) {
+      float a[NA], o[NO];
+      policy_sample<KIND>(A, s_mean, i, e, a, (size_t)t);
+      int ns = 1;
+      bool d, parked = false;
+      float rew;
+      if (KIND == TB_ENV_SWING) {
+        rew = swing_step<false>(A.P, s_hull, e, a, ns, cnt, true, parked TB_STAMP_PASS);  // never loops in here: see tb_step_kernel<LEAN>
+        make_obs<TB_ENV_SWING>(e, o);
+        d = e.done != TB_DONE_NO;
+        if (parked) {
+          if (A.ff_words) {
+            store_env<TB_ENV_SWING>(A.ff_words, A.ff_flag, A.n, i, e, true);
+            A.ff_flag[i] = 1;
+          } else {
+            cnt[7]++;  // lockstep invariant broken (see launch_policy_rollout): reported, never silent
+          }
+          d = true;
+        }
+      } else {
+        rew = tennis_step<false>(A.P, s_hull, e, a, o, d, cnt TB_STAMP_PASS);
+      }
+      cnt[6] += (uint32_t)(ns - 1);
+      if (!(finite3(e.r.p) && finite3(e.r.v) && finite3(e.r.w) && finite3(e.b.p) && finite3(e.b.v) && finite3(e.b.w) &&
+            isfinite(e.r.q.x) && isfinite(e.r.q.y) && isfinite(e.r.q.z) && isfinite(e.r.q.w)))
+        cnt[7]++;
+      if (d) {  // (rollouts require TB_F_AUTO_RESET)
+        cnt[5]++;
+        e.episode += 1u;
+        reset_env<KIND>(A, i, e);
+        make_obs<KIND>(e, o);
+        any_reset = true;
+      }
+      write_obs<KIND>(A.obs + (size_t)t * A.st_obs, (size_t)i, o);
+      A.reward[(size_t)t * A.st_rew + i] = rew;
+      A.done_out[(size_t)t * A.st_done + i] = d ? 1 : 0;
+#pragma unroll
+      for (int k = 0; k < NO; ++k) s_obs[lane * NO + k] = o[k];
+    }
+    __syncthreads();  // the observations after step t are in LDS
+  }
+  if (live) store_env<KIND>(A.words, A.done_state, A.n, i, e, any_reset);
+  flush_counters(A.counters, cnt);
+  if (blockIdx.x == 0 && lane == 0) atomicAdd(&A.counters[6], (unsigned long long)A.n * (unsigned long long)A.T);
+}
+
 // finishes parked SwingRacket fast-forwards (side stream): same device code as the in-step loop
 template <bool RG>
 __global__ void __launch_bounds__(256) tb_ff_kernel(KArgs A) {
@@ -772,6 +877,43 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
   return TB_OK;
 }
 
+// one launch of tb_policy_rollout_kernel over T steps; SwingRacket: T ends where the episode does
+int launch_policy_rollout(TbHandle* h, int T, const PolicyIO& pol, float* obs, float* reward, uint8_t* done, const size_t* st /*element strides*/,
+                          hipStream_t s) {
+  KArgs a = base_args(h);
+  a.pol_weights = pol.weights; a.pol_obs = pol.obs_in; a.pol_actions = pol.actions; a.pol_raw = pol.raw; a.pol_logp = pol.logp;
+  a.pol_value = pol.value; a.pol_seed = pol.seed; a.pol_deterministic = pol.deterministic;
+  a.obs = obs; a.reward = reward; a.done_out = done; a.T = T;
+  a.st_act = st[0]; a.st_raw = st[1]; a.st_logp = st[2]; a.st_val = st[3]; a.st_obs = st[4]; a.st_rew = st[5]; a.st_done = st[6];
+  const bool swing = h->kind == TB_ENV_SWING;
+  const bool may_park = swing && h->phase + T - 1 == 25;  // (the caller checked pipeline, lockstep phase and phase + T <= 26)
+  int slot = -1;
+  if (may_park) {
+    slot = h->next_slot;
+    h->next_slot = (slot + 1) % TB_FF_SLOTS;
+    for (int i = 0; i < h->n_pending; ++i)
+      if (h->pending[i].slot == slot) { if (int rc = launch_pending(h, s)) return rc; break; }
+    if (h->ff_busy[slot]) HIP_TRY(hipStreamWaitEvent(s, h->ev_ff[slot], 0));
+    a.defer = 1; a.ff_words = h->d_ff_words[slot]; a.ff_flag = h->d_ff_flag[slot];
+  }
+  dim3 grid((unsigned)((h->n + 63) / 64)), block(320);
+  (void)hipGetLastError();
+  if (swing) hipLaunchKernelGGL(tb_policy_rollout_kernel<TB_ENV_SWING>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(tb_policy_rollout_kernel<TB_ENV_TENNIS>, grid, block, 0, s, a);
+  HIP_TRY(hipGetLastError());
+  if (may_park) {
+    a.reward = reward + (size_t)(T - 1) * st[5];  // the fast-forward owes its reward to the step that parked: the last one
+    if (h->defer) {
+      TbHandle::Pending& p = h->pending[h->n_pending++];
+      p.a = a; p.slot = slot; p.term = nullptr; p.sub = nullptr;
+    } else if (int rc = launch_ff(h, slot, a, nullptr, nullptr, s)) {
+      return rc;
+    }
+  }
+  if (h->phase_valid) h->phase = (h->phase + T) % 26;
+  return TB_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -990,6 +1132,42 @@ int tb_policy_step(TbHandle* h, const float* weights_dev, const float* obs_in_de
   DeviceGuard g(h->device);
   PolicyIO pol = {weights_dev, obs_in_dev, actions_dev, raw_actions_dev, logp_dev, value_dev, noise_seed, deterministic};
   return launch_step(h, 1, nullptr, obs_dev, reward_dev, done_dev, nullptr, nullptr, (hipStream_t)stream, &pol);
+}
+
+int tb_policy_rollout(TbHandle* h, int n_steps, const float* weights_dev, const float* obs_in_dev, float* actions_dev, float* raw_actions_dev,
+                      float* logp_dev, float* value_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, const size_t* step_strides_bytes,
+                      uint64_t noise_seed, int deterministic, void* stream) {
+  if (!h || !weights_dev || !obs_in_dev || !actions_dev || !raw_actions_dev || !logp_dev || !value_dev || !obs_dev || !reward_dev || !done_dev)
+    return fail(TB_E_INVAL, "tb_policy_rollout: null argument");
+  if (n_steps < 1) return fail(TB_E_INVAL, "tb_policy_rollout: n_steps must be >= 1");
+  if (!(h->kp.flags & TB_F_AUTO_RESET)) return fail(TB_E_UNSUPPORTED, "tb_policy_rollout needs TB_F_AUTO_RESET (episodes must restart inside the launch)");
+  if (h->kp.flags & TB_F_RACKET_GROUND) return fail(TB_E_UNSUPPORTED, "tb_policy_rollout is not instantiated with TB_F_RACKET_GROUND");
+  const bool swing = h->kind == TB_ENV_SWING;
+  if (swing && !(h->pipeline && h->phase_valid))
+    return fail(TB_E_UNSUPPORTED, "tb_policy_rollout on SwingRacket-v0 needs tb_set_pipeline(h, 1) and episodes in lockstep (every env reset together): "
+                                  "the fast-forward that ends an episode cannot run inside a multi-step launch");
+  const size_t n = (size_t)h->n, A = swing ? TB_SWING_ACT_DIM : TB_TENNIS_ACT_DIM, O = swing ? TB_SWING_OBS_DIM : TB_TENNIS_OBS_DIM;
+  size_t st[7] = {n * A, n * A, n, n, n * O, n, n};  // elements per step: actions, raw, logp, value, obs, reward, done
+  if (step_strides_bytes) {
+    for (int k = 0; k < 7; ++k) {
+      const size_t el = k == 6 ? 1 : sizeof(float);
+      if (step_strides_bytes[k] % el) return fail(TB_E_INVAL, "tb_policy_rollout: a step stride is not a multiple of its element size");
+      if (step_strides_bytes[k]) st[k] = step_strides_bytes[k] / el;
+    }
+  }
+  DeviceGuard g(h->device);
+  hipStream_t s = (hipStream_t)stream;
+  const float* obs_in = obs_in_dev;
+  for (int t = 0; t < n_steps;) {
+    int chunk = n_steps - t;
+    if (swing) { const int room = 26 - h->phase; chunk = chunk < room ? chunk : room; }
+    PolicyIO pol = {weights_dev, obs_in, actions_dev + (size_t)t * st[0], raw_actions_dev + (size_t)t * st[1], logp_dev + (size_t)t * st[2],
+                    value_dev + (size_t)t * st[3], noise_seed, deterministic};
+    if (int rc = launch_policy_rollout(h, chunk, pol, obs_dev + (size_t)t * st[4], reward_dev + (size_t)t * st[5], done_dev + (size_t)t * st[6], st, s)) return rc;
+    t += chunk;
+    obs_in = obs_dev + (size_t)(t - 1) * st[4];  // the next launch acts on what this one observed last
+  }
+  return TB_OK;
 }
 
 int tb_rollout(TbHandle* h, int n_steps, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev,

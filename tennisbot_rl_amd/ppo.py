@@ -147,7 +147,7 @@ class PPOTrainer:
     """clipped-surrogate PPO over a BatchedEnv; one process per GPU when distributed"""
 
     def __init__(self, env_id="SwingRacket-v0", num_envs=4096, n_steps=104, device=None, seed=0, batch_size=None,
-                 pipeline=True, graph=True, fused=True, **hp):
+                 pipeline=True, graph=True, fused=True, rollout_launch=True, **hp):
         import torch
         self.torch = torch
         kind = ENV_IDS[env_id]
@@ -180,6 +180,8 @@ class PPOTrainer:
         # then only the learner's view of the same weights, repacked once per rollout
         self.fused = bool(fused) and tuple(d["net_arch"]) == tuple((SWING_DEFAULTS if kind == ENV_SWING else TENNIS_DEFAULTS)["net_arch"])
         self.noise_seed = (seed * 1000003 + 7919 * (self.rank + 1)) & 0xFFFFFFFF
+        # whole episodes per launch need the pipelined fast-forward on SwingRacket (always on for Tennisbot)
+        self.rollout_launch = bool(rollout_launch) and self.fused and (kind != ENV_SWING or self.env.pipeline)
         self._rollouts = 0
         if self.fused:
             self.packed = pack_policy(self.policy)
@@ -187,13 +189,20 @@ class PPOTrainer:
 
     # ------------------------------------------------------------------ collect
     def _collect_fused(self):
-        """the rollout as n_steps launches of the fused policy+step kernel (plus the side-stream
-        fast-forwards): no library GEMM, no sampling kernels, nothing between two env steps"""
+        """the rollout through the fused policy+step kernels (plus the side-stream fast-forwards): no
+        library GEMM, no sampling kernels, nothing between two env steps. rollout_launch=True: whole
+        episodes per launch (tb_policy_rollout: weights and env state resident in registers, no launch
+        boundary between steps); otherwise one launch per step (tb_policy_step). Same results."""
         buf, env = self.buf, self.env
         n, O, A = self.num_envs, env.obs_dim, env.act_dim
         wp, cur = self.packed.data_ptr(), self.obs_in.data_ptr()
         self.obs_seq[0].copy_(self.obs_in)
-        for k in range(self.n_steps):
+        if self.rollout_launch:
+            rec = buf.record
+            env.policy_rollout_ptrs(self.n_steps, wp, cur, buf.actions[0].data_ptr(), self._raw_actions.data_ptr(), self.logps.data_ptr(),
+                                    self.values.data_ptr(), buf.obs[0].data_ptr(), buf.rewards[0].data_ptr(), buf.dones[0].data_ptr(),
+                                    (rec, 0, 0, 0, rec, rec, rec), self.noise_seed)
+        for k in range(0 if self.rollout_launch else self.n_steps):
             obs_k = buf.obs[k]
             # exploration noise is keyed by (seed, env, episode, step) inside the kernel: replaying
             # the captured graph draws fresh noise because episodes / steps advance

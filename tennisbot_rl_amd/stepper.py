@@ -63,6 +63,8 @@ def load_library():
     L.tb_flush.restype = i32
     L.tb_pipeline_sync.argtypes = [vp, i32]
     L.tb_pipeline_sync.restype = i32
+    L.tb_policy_rollout.argtypes = [vp, i32] + [vp] * 9 + [ctypes.POINTER(ctypes.c_size_t), u64, i32, vp]
+    L.tb_policy_rollout.restype = i32
     L.tb_step_sequence.argtypes = [vp, i32, vp, vp, vp, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, vp]
     L.tb_step_sequence.restype = i32
     L.tb_policy_floats.argtypes = [i32]
@@ -288,6 +290,33 @@ class BatchedEnv:
     def launch_pending(self):
         """launch the deferred fast-forwards on the side streams, ordered after the current stream"""
         _check(self.L, self.L.tb_ff_launch_pending(self._h, self._stream()), "tb_ff_launch_pending")
+
+    def policy_rollout_ptrs(self, n_steps, weights_ptr, obs_in_ptr, act_ptr, raw_ptr, logp_ptr, value_ptr, obs_ptr, reward_ptr, done_ptr,
+                            strides_bytes, seed, deterministic=False):
+        """n_steps of policy_step_ptrs in as few launches as the episodes allow (tb_policy_rollout): the
+        towers' weights and the envs' state stay in registers from step to step. strides_bytes: distance
+        between consecutive steps of (actions, raw, logp, value, obs, reward, done), 0 = contiguous.
+        Unchecked fast path; terminal SwingRacket rewards are complete after flush()."""
+        st = (ctypes.c_size_t * 7)(*[int(x) for x in strides_bytes])
+        rc = self.L.tb_policy_rollout(self._h, int(n_steps), weights_ptr, obs_in_ptr, act_ptr, raw_ptr, logp_ptr, value_ptr, obs_ptr, reward_ptr, done_ptr,
+                                      st, int(seed) & 0xFFFFFFFFFFFFFFFF, 1 if deterministic else 0, self.torch.cuda.current_stream(self.device).cuda_stream)
+        if rc:
+            _check(self.L, rc, "tb_policy_rollout")
+
+    def policy_rollout(self, weights, obs_in, n_steps, seed=0, deterministic=False):
+        """T = n_steps agent steps with the MlpPolicy inside the kernel, whole episodes per launch.
+        Returns ((obs [T,N,O], reward [T,N], done [T,N]), (actions [T,N,A], raw [T,N,A], logp [T,N], value [T,N]))."""
+        t, n, T = self.torch, self.num_envs, int(n_steps)
+        w = self._check_tensor(weights, (self.policy_floats(),), t.float32, "weights")
+        oi = self._check_tensor(obs_in, (n, self.obs_dim), t.float32, "obs_in")
+        f = dict(dtype=t.float32, device=self.device)
+        obs, rew, done = t.empty((T, n, self.obs_dim), **f), t.empty((T, n), **f), t.empty((T, n), dtype=t.uint8, device=self.device)
+        act, raw, logp, value = t.empty((T, n, self.act_dim), **f), t.empty((T, n, self.act_dim), **f), t.empty((T, n), **f), t.empty((T, n), **f)
+        self.policy_rollout_ptrs(T, w.data_ptr(), oi.data_ptr(), act.data_ptr(), raw.data_ptr(), logp.data_ptr(), value.data_ptr(),
+                                 obs.data_ptr(), rew.data_ptr(), done.data_ptr(), (0,) * 7, seed, deterministic)
+        if self.pipeline:
+            self._inflight.append(rew)
+        return (obs, rew, done), (act, raw, logp, value)
 
     def capture(self, fn, join_only=False):
         """Capture `fn()` -- a fixed sequence of step()/step_ptrs()/RolloutBuffer.step_into calls on

@@ -180,3 +180,62 @@ def test_reference_policy_reward_statistics_match_the_pybullet_record(torch):
     assert abs(got["other_median"] - ref["other_median"]) < 1.0, (got, ref)
     urdf = crp.summarize(crp.rollout_rewards(num_envs=4096, episodes=4, **urdf_file_inertia()))
     assert urdf["goal_rate"] < got["goal_rate"] - 0.05, (urdf, got)
+
+
+@pytest.mark.parametrize("kind,n,T,lead", [(ENV_SWING, 1000, 70, 9), (ENV_SWING, 4096, 52, 0), (ENV_TENNIS, 777, 150, 3)])
+def test_policy_rollout_equals_repeated_policy_steps(torch, kind, n, T, lead):
+    """tb_policy_rollout (whole episodes per launch, weights and env state resident in registers)
+    against tb_policy_step called T times: every output of every step bit-identical, from a start in
+    the middle of an episode, with the SwingRacket fast-forwards on the side streams"""
+    from tennisbot_rl_amd.ppo import SWING_DEFAULTS, TENNIS_DEFAULTS, build_actor_critic, pack_policy
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    torch.manual_seed(11)
+    arch = (SWING_DEFAULTS if kind == ENV_SWING else TENNIS_DEFAULTS)["net_arch"]
+    policy = build_actor_critic(OBS_DIM[kind], ACT_DIM[kind], tuple(arch)).to("cuda:0")
+    with torch.no_grad():
+        policy.action_net.weight.mul_(20.0)
+        policy.log_std.fill_(-0.5)
+    blob = pack_policy(policy)
+    pipe = kind == ENV_SWING
+    a = BatchedEnv(kind, n, device="cuda:0", seed=8, pipeline=pipe, track_terminal_obs=False)
+    b = BatchedEnv(kind, n, device="cuda:0", seed=8, pipeline=pipe, track_terminal_obs=False)
+    oa, ob = a.reset(), b.reset()
+    for t in range(lead):
+        (oa, _, _), _ = a.policy_step(blob, oa, seed=5)
+        (ob, _, _), _ = b.policy_step(blob, ob, seed=5)
+    (obs, rew, done), (act, raw, logp, value) = a.policy_rollout(blob, oa, T, seed=5)
+    a.flush()
+    steps = []
+    for t in range(T):
+        (ob_next, r, d), (ac, rw, lp, v) = b.policy_step(blob, ob, seed=5)
+        steps.append((ob_next, r, d, ac, rw, lp, v))
+        ob = ob_next
+    b.flush()
+    torch.cuda.synchronize()
+    for t, (o, r, d, ac, rw, lp, v) in enumerate(steps):
+        for name, x, y in (("obs", obs[t], o), ("done", done[t], d), ("actions", act[t], ac), ("raw", raw[t], rw), ("logp", logp[t], lp),
+                           ("value", value[t], v), ("reward", rew[t], r)):
+            assert torch.equal(x, y), "%s differs at step %d" % (name, t)
+    if kind == ENV_SWING:
+        assert int(done.sum()) == n * ((lead + T) // 26)
+    wa, da = a.get_state_words(); wb, db = b.get_state_words()
+    assert torch.equal(wa, wb) and torch.equal(da, db) and a.counters() == b.counters()
+    # without the pipeline a SwingRacket rollout launch is refused, loudly
+    if kind == ENV_SWING:
+        from tennisbot_rl_amd.stepper import StepperError
+        c = BatchedEnv(kind, 64, device="cuda:0", seed=8)
+        with pytest.raises(StepperError):
+            c.policy_rollout(blob, c.reset(), 4)
+
+
+def test_trainer_collect_by_rollout_launch_equals_per_step_launches(torch):
+    from tennisbot_rl_amd.ppo import PPOTrainer
+    a = PPOTrainer("SwingRacket-v0", num_envs=1024, n_steps=52, device="cuda:0", seed=3, rollout_launch=True)
+    b = PPOTrainer("SwingRacket-v0", num_envs=1024, n_steps=52, device="cuda:0", seed=3, rollout_launch=False)
+    assert a.rollout_launch and not b.rollout_launch
+    for it in range(3):  # eager, capture, replay
+        a.collect(); b.collect()
+        torch.cuda.synchronize()
+        assert torch.equal(a.buf.raw, b.buf.raw), "rollout buffers differ in round %d" % it
+        assert torch.equal(a.values, b.values) and torch.equal(a.logps, b.logps) and torch.equal(a._raw_actions, b._raw_actions)
+        assert torch.equal(a.obs_seq, b.obs_seq) and torch.equal(a.last_value, b.last_value)
