@@ -209,11 +209,13 @@ class PPOTrainer:
             env.policy_step_ptrs(wp, cur, buf.actions[k].data_ptr(), self._raw_actions[k].data_ptr(), self.logps[k].data_ptr(),
                                  self.values[k].data_ptr(), obs_k.data_ptr(), buf.rewards[k].data_ptr(), buf.dones[k].data_ptr(), self.noise_seed)
             cur = obs_k.data_ptr()
-        env.flush()
+        # observations are final when the step kernels are; only terminal rewards still trickle in from
+        # the side streams -- so the bookkeeping below overlaps with the last fast-forward
         self.obs_seq[1:].copy_(buf.obs[:-1])
         last = buf.obs[self.n_steps - 1]
         self.last_value.copy_(self.policy(last)[1])
         self.obs_in.copy_(last)
+        env.flush()
 
     def _collect_body(self):
         t = self.torch
