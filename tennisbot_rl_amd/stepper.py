@@ -17,7 +17,8 @@ import numpy as np
 from .params import (ACT_DIM, COUNTER_NAMES, ENV_SWING, ENV_TENNIS, F_AUTO_RESET, F_DEFAULT, N_COUNTERS, OBS_DIM,
                      STATE_ROWS, STATE_WORDS, TbParams, default_params)
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtb_stepper.so")
+# TB_STEPPER_LIB: another build of the same ABI (diagnostic builds, A/B timing); never a different implementation
+_LIB_PATH = os.environ.get("TB_STEPPER_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtb_stepper.so")
 _LIB = None
 
 ENV_IDS = {"SwingRacket-v0": ENV_SWING, "Tennisbot-v0": ENV_TENNIS}  # tennisbot/__init__.py:3-11
