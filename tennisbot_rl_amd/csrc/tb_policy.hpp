@@ -173,18 +173,36 @@ TB_DEV void policy_towers(const KArgs& A, float* s_mean) {
 }
 // wave 0, after the workgroup barrier: sample, report, and hand the clipped actions to the env step
 // `t`: the step of a rollout launch (tb_policy_rollout_kernel) whose output rows are written; 0 otherwise
+// The noise of a step depends on the env's (episode, step) only, not on the policy's output: a caller
+// with idle time before the means arrive (the env wave of tb_policy_rollout_kernel, while the towers
+// run) draws it early with policy_draw and passes it in; `eps` = nullptr draws it here.
 template <int KIND>
-TB_DEV void policy_sample(const KArgs& A, const float* s_mean, int i, const EnvRegs& e, float* a, size_t t = 0) {
+TB_DEV void policy_draw(const KArgs& A, int i, const EnvRegs& e, float* eps) {
+  constexpr int NA = Dims<KIND>::A;
+  if (!A.pol_deterministic) {
+    policy_noise<NA>(A.pol_seed, A.env_id_base + (unsigned long long)i, e.episode, e.step_count, eps);
+  } else {
+#pragma unroll
+    for (int k = 0; k < NA; ++k) eps[k] = 0.0f;
+  }
+}
+template <int KIND>
+TB_DEV void policy_sample(const KArgs& A, const float* s_mean, int i, const EnvRegs& e, float* a, size_t t = 0, const float* drawn = nullptr) {
   constexpr int NA = Dims<KIND>::A;
   float* out_act = A.pol_actions + t * A.st_act;
   float* out_raw = A.pol_raw + t * A.st_raw;
   const float* log_std = A.pol_weights + 2 * tower_floats<KIND>();
   const float* mean = s_mean + (threadIdx.x & 63) * 8;
   float eps[NA], logp = 0.0f;
-  if (!A.pol_deterministic) policy_noise<NA>(A.pol_seed, A.env_id_base + (unsigned long long)i, e.episode, e.step_count, eps);
+  if (drawn) {
+#pragma unroll
+    for (int k = 0; k < NA; ++k) eps[k] = drawn[k];
+  } else {
+    policy_draw<KIND>(A, i, e, eps);
+  }
 #pragma unroll
   for (int k = 0; k < NA; ++k) {
-    float ek = A.pol_deterministic ? 0.0f : eps[k];
+    float ek = eps[k];
     float raw = FMA(expf(log_std[k]), ek, mean[k]);
     logp += FMA(-0.5f * ek, ek, -log_std[k]) - 0.9189385332046727f;  // -(eps^2)/2 - log_std - ln(2 pi)/2
     out_raw[(size_t)i * NA + k] = raw;

@@ -504,10 +504,12 @@ __global__ void __launch_bounds__(320) tb_policy_rollout_kernel(KArgs A) {
 #endif
   __syncthreads();
   for (int t = 0; t < A.T; ++t) {
+    float eps[NA];
+    if (live) policy_draw<KIND>(A, i, e, eps);  // while the towers run
     __syncthreads();  // the action means of step t are in LDS
     if (live) {
       float a[NA], o[NO];
-      policy_sample<KIND>(A, s_mean, i, e, a, (size_t)t);
+      policy_sample<KIND>(A, s_mean, i, e, a, (size_t)t, eps);
       int ns = 1;
       bool d, parked = false;
       float rew;
