@@ -187,7 +187,8 @@ TB_DEV void policy_draw(const KArgs& A, int i, const EnvRegs& e, float* eps) {
   }
 }
 template <int KIND>
-TB_DEV void policy_sample(const KArgs& A, const float* s_mean, int i, const EnvRegs& e, float* a, size_t t = 0, const float* drawn = nullptr) {
+TB_DEV void policy_sample(const KArgs& A, const float* s_mean, int i, const EnvRegs& e, float* a, size_t t = 0, const float* drawn = nullptr,
+                          const float* stdv = nullptr /* exp(log_std), when the caller keeps it across steps */) {
   constexpr int NA = Dims<KIND>::A;
   float* out_act = A.pol_actions + t * A.st_act;
   float* out_raw = A.pol_raw + t * A.st_raw;
@@ -203,7 +204,7 @@ TB_DEV void policy_sample(const KArgs& A, const float* s_mean, int i, const EnvR
 #pragma unroll
   for (int k = 0; k < NA; ++k) {
     float ek = eps[k];
-    float raw = FMA(expf(log_std[k]), ek, mean[k]);
+    float raw = FMA(stdv ? stdv[k] : expf(log_std[k]), ek, mean[k]);
     logp += FMA(-0.5f * ek, ek, -log_std[k]) - 0.9189385332046727f;  // -(eps^2)/2 - log_std - ln(2 pi)/2
     out_raw[(size_t)i * NA + k] = raw;
     a[k] = fminf(fmaxf(raw, -1.0f), 1.0f);  // SB3 clips Box actions before env.step

@@ -503,13 +503,16 @@ __global__ void __launch_bounds__(320) tb_policy_rollout_kernel(KArgs A) {
   st.t = stamp_now();
 #endif
   __syncthreads();
+  float stdv[NA];
+#pragma unroll
+  for (int k = 0; k < NA; ++k) stdv[k] = expf(A.pol_weights[2 * tower_floats<KIND>() + k]);
   for (int t = 0; t < A.T; ++t) {
     float eps[NA];
     if (live) policy_draw<KIND>(A, i, e, eps);  // while the towers run
     __syncthreads();  // the action means of step t are in LDS
     if (live) {
       float a[NA], o[NO];
-      policy_sample<KIND>(A, s_mean, i, e, a, (size_t)t, eps);
+      policy_sample<KIND>(A, s_mean, i, e, a, (size_t)t, eps, stdv);
       int ns = 1;
       bool d, parked = false;
       float rew;
