@@ -16,7 +16,7 @@ import warnings
 
 import numpy as np
 
-from .params import ENV_SWING, ENV_TENNIS, default_params
+from .params import ENV_SWING, ENV_TENNIS
 from .stepper import BatchedEnv
 
 try:  # optional

@@ -9,8 +9,9 @@ in train.py:164 -- the ranks exchange their shards with ONE all-gather (RCCL ove
 
 Packed layout per rank: T per-step records, each `obs f32 [N][O] | act f32 [N][A] | rew f32 [N] |
 done u8 [N]` (every part padded to 16 B), so any range of steps is one contiguous byte range:
-the whole buffer goes out in ONE all-gather, and `all_gather_chunked` can instead ship it in a
-few step-chunks on RCCL's stream while later steps are still being computed. n_steps defaults
+the whole buffer goes out in ONE all-gather, and begin_gather / gather_chunk / finish_gather can
+instead ship it in a few step-chunks from a side stream while later steps are still being computed
+(capture_chunks cuts the rollout into one hipGraph per chunk for that). n_steps defaults
 to the reference's 1100 (train_swing.py:49-50).
 """
 import numpy as np

@@ -14,7 +14,7 @@ import os
 
 import numpy as np
 
-from .params import (ACT_DIM, COUNTER_NAMES, ENV_SWING, ENV_TENNIS, F_AUTO_RESET, F_DEFAULT, N_COUNTERS, OBS_DIM,
+from .params import (ACT_DIM, COUNTER_NAMES, ENV_SWING, ENV_TENNIS, F_AUTO_RESET, N_COUNTERS, OBS_DIM,
                      STATE_ROWS, STATE_WORDS, TbParams, default_params)
 
 # TB_STEPPER_LIB: another build of the same ABI (diagnostic builds, A/B timing); never a different implementation

@@ -5,11 +5,9 @@ Builds variants of libtb_stepper.so with TB_DIAG_* macros into /tmp, puts every 
 state that runs the full 776-substep fast-forward without contacts (ball far off the court)
 and reports microseconds per substep of a full wave. Variant results are WRONG by
 construction; only the times matter. Usage: python tools/diag_substep.py [n_envs]"""
-import ctypes
 import os
 import subprocess
 import sys
-import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
