@@ -178,6 +178,9 @@ def test_reference_policy_reward_statistics_match_the_pybullet_record(torch):
     assert abs(got["goal_rate"] - ref["goal_rate"]) < 2.7 * se, (got, ref)
     assert abs(got["goal_cluster_mean"] - ref["goal_cluster_mean"]) < 1.5, (got, ref)
     assert abs(got["other_median"] - ref["other_median"]) < 1.0, (got, ref)
+    # 5 of the 100 PyBullet episodes keep the racket contact for a second agent step after a good strike;
+    # with Bullet's library ERP (0.2) instead of the 0.08 PyBullet builds its world with, none would here
+    assert ref["two_bonus_good_shots"] == pytest.approx(0.05) and 0.01 < got["two_bonus_good_shots"] < 0.10, (got, ref)
     urdf = crp.summarize(crp.rollout_rewards(num_envs=4096, episodes=4, **urdf_file_inertia()))
     assert urdf["goal_rate"] < got["goal_rate"] - 0.05, (urdf, got)
 

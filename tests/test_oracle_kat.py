@@ -291,7 +291,7 @@ def test_tennis_shoot_pulse():
     assert v[2] == pytest.approx((400 - 9.81) * 5 / 240 - 2 * 9.81 / 240, rel=1e-6)
 
 
-def _impact_expected(vn, dist, e, mb=0.05, mr=4.0, thr=0.2, erp=0.2):
+def _impact_expected(vn, dist, e, mb=0.05, mr=4.0, thr=0.2, erp=float(np.float32(0.08))):
     """normal-row closed form for a contact through both COMs (no angular coupling);
     vn = relative velocity along the normal that points from the racket to the ball"""
     rest = 0.0 if abs(vn) < thr else max(e * -vn, 0.0)
@@ -348,7 +348,7 @@ def test_ground_bounce_restitution_and_threshold():
     b.step(np.zeros((1, 2), np.float32))
     vz = b.get_state()["ball_vel"][0, 2]
     pen = np.float32(0.005 + 0.0335 - 0.001).astype(np.float64) - (0.005 + 0.0335)
-    assert vz == pytest.approx(-pen * 0.2 * 240.0, rel=1e-5)  # Baumgarte push-out only
+    assert vz == pytest.approx(-pen * 0.08 * 240.0, rel=1e-5)  # Baumgarte push-out only (contact ERP 0.08)
 
 
 def test_friction_is_bounded_by_mu_times_normal_impulse():

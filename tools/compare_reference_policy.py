@@ -48,7 +48,10 @@ def summarize(r):
     r = np.asarray(r, dtype=np.float64)
     goal = r >= 50.0  # only the goal bonus (+50) lifts an episode that high
     rest = r[~goal]
-    return {"episodes": int(r.size), "mean": float(r.mean()), "goal_rate": float(goal.mean()),
+    # one contact bonus (+2) per agent step with racket contact before step 25; a good shot scores at most
+    # 18.6 (+2), a goal 50 + ~19 (+2): anything in (21, 24) or (72, 76) carries TWO bonuses on a good shot
+    two = ((r > 21.0) & (r < 24.0)) | ((r > 72.0) & (r < 76.0))
+    return {"episodes": int(r.size), "mean": float(r.mean()), "goal_rate": float(goal.mean()), "two_bonus_good_shots": float(two.mean()),
             "goal_cluster_mean": float(r[goal].mean()) if goal.any() else None,
             "other_median": float(np.median(rest)), "other_p10": float(np.percentile(rest, 10)), "other_p90": float(np.percentile(rest, 90))}
 

@@ -76,7 +76,7 @@ def main():
     g = run(ENV_SWING, n, 26, 101, acts)
     np.savez_compressed(os.path.join(OUT, "swing_trajectories.npz"), seed=101, actions=acts, **g)
     print("swing: rewards", g["reward"][-1], "substeps", g["substeps"][-1], "racket contacts", g["counters"][0])
-    tseed = 223  # (a seed whose 8 runs contain racket<->ball interceptions with the tracking controller below)
+    tseed = 207  # (a seed whose 8 runs contain racket<->ball interceptions with the tracking controller below)
     acts = tennis_closed_loop(n, 800, tseed, np.random.default_rng(20261004 + tseed))
     g = run(ENV_TENNIS, n, 800, tseed, acts)
     np.savez_compressed(os.path.join(OUT, "tennis_trajectories.npz"), seed=tseed, actions=acts, **g)
