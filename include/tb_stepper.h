@@ -107,7 +107,7 @@ typedef struct TbParams {
   float ang_damp;           /* 0.04 */
   float max_ang_step;       /* pi/4 per substep rotation clamp */
   float rest_vel_threshold; /* 0.2 m/s: below it restitution is 0 */
-  float erp;                /* 0.2 Baumgarte */
+  float erp;                /* contact ERP (Baumgarte): 0.08 = PyBullet's world default (Bullet's library default is 0.2) */
   float contact_threshold;  /* 0.02 * ball radius: manifold keeps points closer than this */
   int32_t solver_iters;     /* sequential-impulse iteration cap (Bullet default 50) */
   float solver_tol;         /* stop early once every impulse update of a sweep is <= tol * |impulse|
@@ -115,7 +115,7 @@ typedef struct TbParams {
   uint32_t flags;           /* TB_F_* */
   /* racket: racket.urdf:17-21, racket.py:43-45 */
   float racket_mass, racket_inv_mass;
-  float racket_inertia[3], racket_inv_inertia[3]; /* body-frame diagonal */
+  float racket_inertia[3], racket_inv_inertia[3]; /* body-frame diagonal at scale 1; default: derived from the collision shape as Bullet does */
   float racket_com[3];       /* inertial origin in the link frame, at scale 1 */
   float racket_half_thick;   /* at scale 1 */
   float hull_margin;         /* URDF convex-hull collision margin, 0.001 (not scaled) */
