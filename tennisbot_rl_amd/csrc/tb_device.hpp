@@ -583,24 +583,40 @@ template <bool RG> struct Rows;
 template <> struct Rows<false> { RowR rk; RowS st[3]; bool on[4]; };
 template <> struct Rows<true> { RowR rk; RowS st[3]; bool on[4]; RowG rg[TB_MAX_RG]; int nrg; };
 
-template <bool RG>
+// REGROWS: the three static rows statically indexed too, i.e. in registers (~40 VGPRs more): the right
+// trade where balls bounce on the court all the time and occupancy matters little -- Tennisbot up to
+// 131072 envs (+12 % on whole episodes; tb_create decides); for SwingRacket the registers cost more
+// than they give at every size (-2 % at 4096 envs, -17 % at 1 M). Same arithmetic either way.
+template <bool RG, bool REGROWS>
 TB_DEV void solve_contacts(const KParams& P, Rows<RG>& R, Racket& rk, Ball& b) {
   float jref = 0.0f;
   for (int it = 0; it < P.solver_iters; ++it) {
     bool moved = false;
     if (R.on[0]) moved |= normal_racket(P, R.rk, rk, b, jref);
+    if constexpr (REGROWS) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        if (R.on[i + 1]) moved |= normal_static(P, R.st[i], b, jref);
+    } else {
 #pragma unroll 1
-    for (int i = 0; i < 3; ++i)
-      if (R.on[i + 1]) moved |= normal_static(P, R.st[i], b, jref);
+      for (int i = 0; i < 3; ++i)
+        if (R.on[i + 1]) moved |= normal_static(P, R.st[i], b, jref);
+    }
     if constexpr (RG) {
 #pragma unroll
       for (int j = 0; j < TB_MAX_RG; ++j)
         if (j < R.nrg) moved |= normal_ground(P, R.rg[j], rk, jref);
     }
     if (R.on[0]) moved |= friction_racket(P, R.rk, rk, b, jref);
+    if constexpr (REGROWS) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        if (R.on[i + 1]) moved |= friction_static(P, R.st[i], b, jref);
+    } else {
 #pragma unroll 1
-    for (int i = 0; i < 3; ++i)
-      if (R.on[i + 1]) moved |= friction_static(P, R.st[i], b, jref);
+      for (int i = 0; i < 3; ++i)
+        if (R.on[i + 1]) moved |= friction_static(P, R.st[i], b, jref);
+    }
     if constexpr (RG) {
 #pragma unroll
       for (int j = 0; j < TB_MAX_RG; ++j)
@@ -684,7 +700,7 @@ TB_DEV void integrate_pose(const KParams& P, Racket& rk, Ball& b) {
 // the narrowphase is arranged as cheap per-lane culls + wave votes: a wave runs the outline
 // sweep / the static tests / the impulse solver only if __any lane needs them, and those
 // branches are wave-uniform (s_cbranch on the ballot), never if-converted into the hot path.
-template <int KIND, bool RG>
+template <int KIND, bool RG, bool REGROWS = false>
 TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, vec3 Fr, vec3 Tr, vec3 Fb, float goal_x, float goal_y, float scale TB_STAMP_ARG) {
   int bits = 0;
   TB_STAMP(st, 0);  // everything between two substeps (loop control, env logic)
@@ -749,7 +765,7 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, ve
       if (R.on[1]) setup_static(P, R.st[0], hg, P.rest_court, P.fric_court, b);
       if (R.on[2]) setup_static(P, R.st[1], hn, P.rest_court, P.fric_court, b);
       if (R.on[3]) setup_static(P, R.st[2], hc, P.rest_goal, P.fric_goal, b);
-      solve_contacts(P, R, rk, b);
+      solve_contacts<RG, REGROWS>(P, R, rk, b);
     }
   }
   TB_STAMP(st, 4);  // contact solve

@@ -98,8 +98,10 @@ def test_swing_lockstep_ragged_sizes(torch, n):
     env.close()
 
 
-@pytest.mark.parametrize("n", [1, 65, 4096])
-def test_tennis_lockstep(torch, n):
+@pytest.mark.parametrize("n,reg_rows", [(1, "1"), (65, "1"), (4096, "1"), (65, "0"), (4096, "0")])
+def test_tennis_lockstep(torch, n, reg_rows, monkeypatch):
+    # both builds of the Tennisbot step kernel: static contact rows in registers (small batches) / in scratch
+    monkeypatch.setenv("TB_TENNIS_REG_ROWS", reg_rows)
     env, ref = make_pair(torch, ENV_TENNIS, n)
     # 1010 steps: past the 1000-step timeout (tennisbot_env.py:201-203), so every env finishes at least once
     run_lockstep(torch, env, ref, 1010, np.random.default_rng(100 + n), "tennis n=%d" % n, check_state_every=50)
