@@ -214,13 +214,13 @@ TB_DEV vec3 restoring_force(const EnvRegs& e) {  // swingracket_env.py:135-141
 //                    later ones with the restoring force of :135-141.
 // `in_ff` = start inside the fast-forward (tb_ff_kernel resuming a parked env).
 // `defer`  = leave the fast-forward to tb_ff_kernel: sets `parked` instead of looping.
-template <bool RG>
+template <bool RG, bool REGROWS = false>
 TB_DEV float swing_loop(const KParams& P, const float4* hull, EnvRegs& e, vec3 F, vec3 T, bool in_ff, bool defer, bool& parked,
                         int& ns, uint32_t* cnt TB_STAMP_ARG) {
   const vec3 zero = mk(0.0f, 0.0f, 0.0f);
   float reward = 0.0f;
   for (;;) {
-    int bits = substep<TB_ENV_SWING, RG>(P, hull, e.r, e.b, F, T, zero, e.aux[0], e.aux[1], 1.0f TB_STAMP_PASS);  // :82 / :107
+    int bits = substep<TB_ENV_SWING, RG, REGROWS>(P, hull, e.r, e.b, F, T, zero, e.aux[0], e.aux[1], 1.0f TB_STAMP_PASS);  // :82 / :107
     e.step_count += 1; ns++;                                                                                   // :83 / :108
     if (bits & CT_RACKET) cnt[0]++;
     if (!in_ff) {
@@ -239,7 +239,7 @@ TB_DEV float swing_loop(const KParams& P, const float4* hull, EnvRegs& e, vec3 F
   return reward;
 }
 
-template <bool RG>
+template <bool RG, bool REGROWS = false>
 TB_DEV float swing_step(const KParams& P, const float4* hull, EnvRegs& e, const float* a, int& ns, uint32_t* cnt, bool defer, bool& parked TB_STAMP_ARG) {
   vec3 F = mk(a[0] * 400.0f, a[1] * 400.0f, FMA(a[2], 400.0f, 4.0f * 9.81f));  // :76-77
   vec3 T = mk(a[3] * 5.0f, a[4] * 5.0f, a[5] * 5.0f);                          // :78
@@ -248,7 +248,7 @@ TB_DEV float swing_step(const KParams& P, const float4* hull, EnvRegs& e, const 
     e.done = TB_DONE_YES;
   }
   ns = 0;
-  return swing_loop<RG>(P, hull, e, F, T, false, defer, parked, ns, cnt TB_STAMP_PASS);
+  return swing_loop<RG, REGROWS>(P, hull, e, F, T, false, defer, parked, ns, cnt TB_STAMP_PASS);
 }
 
 // tennisbot_env.py:90-102
@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
       bool d, parked = false;
       float rew;
       if (KIND == TB_ENV_SWING) {
-        rew = swing_step<RG>(A.P, s_hull, e, a, ns, cnt, LEAN || A.defer != 0, parked TB_STAMP_PASS);
+        rew = swing_step<RG, REGROWS>(A.P, s_hull, e, a, ns, cnt, LEAN || A.defer != 0, parked TB_STAMP_PASS);
         make_obs<TB_ENV_SWING>(e, o);
         d = e.done != TB_DONE_NO;  // swingracket_env.py:145 returns self.done
         if (parked) {
@@ -722,6 +722,7 @@ void to_kparams(const TbParams* p, KParams* k) {
 struct TbHandle {
   int device, kind, n, block;
   int reg_rows;  // Tennisbot step kernel with the static contact rows in registers (small batches)
+  int swing_reg_rows;  // the same for the pipelined SwingRacket step kernel (+1.7 % at 4096 envs; NOT for tb_ff_kernel)
   uint64_t seed, env_id_base;
   TbParams params;
   KParams kp;
@@ -954,6 +955,8 @@ int tb_create(const TbParams* params, int env_kind, int n_envs, int device, uint
      // the contact-free phase, where the kernel runs at 70 % of HBM peak and occupancy counts
     const char* rr = getenv("TB_TENNIS_REG_ROWS");
     h->reg_rows = env_kind == TB_ENV_TENNIS && (rr ? atoi(rr) != 0 : n_envs <= 131072);
+    const char* sr = getenv("TB_SWING_REG_ROWS");
+    h->swing_reg_rows = env_kind == TB_ENV_SWING && (sr ? atoi(sr) != 0 : n_envs <= 131072);
   }
   const int nw = words_of(env_kind);
   hipError_t err;

@@ -414,12 +414,15 @@ def test_float32_drift_vs_float64_truth(torch):
     assert np.array_equal(g["step_count"], c["step_count"])
 
 
-@pytest.mark.parametrize("n", [4096, 1000])
-def test_pipelined_fast_forward_is_bit_identical(torch, n):
+@pytest.mark.parametrize("n,reg_rows", [(4096, "1"), (1000, "1"), (1000, "0")])
+def test_pipelined_fast_forward_is_bit_identical(torch, n, reg_rows, monkeypatch):
     """tb_set_pipeline: the fast-forward runs on a side stream and writes the terminal step's
-    reward late; after flush() every output equals the unpipelined path bit for bit"""
+    reward late; after flush() every output equals the unpipelined path bit for bit (both builds
+    of the pipelined step kernel: static contact rows in registers, as small batches run it, and in
+    scratch)"""
     from tennisbot_rl_amd.rollout import RolloutBuffer
     from tennisbot_rl_amd.stepper import BatchedEnv
+    monkeypatch.setenv("TB_SWING_REG_ROWS", reg_rows)
     T = 26 * 4 + 7
     rng = np.random.default_rng(41)
     acts = torch.from_numpy(rng.uniform(-1, 1, (T, n, 6)).astype(np.float32)).cuda()
