@@ -855,13 +855,16 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
     else hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, MULTI, false>), grid, block, 0, s, a);                  \
   } while (0)
   if (T > 1) {
-    if (h->kind == TB_ENV_TENNIS) TB_LAUNCH_STEP(TB_ENV_TENNIS, false, true);
-    else if (piped) {
+    if (h->kind == TB_ENV_TENNIS) {
+      if (h->reg_rows && !pol && !rg) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, true, false, false, true>), grid, block, 0, s, a);
+      else TB_LAUNCH_STEP(TB_ENV_TENNIS, false, true);
+    } else if (piped) {
       if (!may_park) { a.ff_words = nullptr; a.ff_flag = nullptr; }
       TB_LAUNCH_STEP(TB_ENV_SWING, true, true);
     } else TB_LAUNCH_STEP(TB_ENV_SWING, false, true);
   } else if (h->kind == TB_ENV_TENNIS) {
-    if (h->reg_rows && !pol && !rg) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, false, false, false, true>), grid, block, 0, s, a);
+    if (h->reg_rows && !rg && pol) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, false, false, true, true>), grid, block, 0, s, a);
+    else if (h->reg_rows && !rg) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, false, false, false, true>), grid, block, 0, s, a);
     else TB_LAUNCH_STEP(TB_ENV_TENNIS, false, false);
   } else if (may_park) TB_LAUNCH_STEP(TB_ENV_SWING, true, false);
   else if (piped) {
