@@ -722,7 +722,7 @@ void to_kparams(const TbParams* p, KParams* k) {
 struct TbHandle {
   int device, kind, n, block;
   int reg_rows;  // Tennisbot step kernel with the static contact rows in registers (small batches)
-  int swing_reg_rows;  // the same for the pipelined SwingRacket step kernel (+1.7 % at 4096 envs; NOT for tb_ff_kernel)
+  int swing_reg_rows;  // the same for the pipelined SwingRacket step kernel (+2.7 % at 4096 envs; NOT for tb_ff_kernel)
   uint64_t seed, env_id_base;
   TbParams params;
   KParams kp;
@@ -866,6 +866,9 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
     if (h->reg_rows && !rg && pol) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, false, false, true, true>), grid, block, 0, s, a);
     else if (h->reg_rows && !rg) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, false, false, false, true>), grid, block, 0, s, a);
     else TB_LAUNCH_STEP(TB_ENV_TENNIS, false, false);
+  } else if (piped && h->swing_reg_rows && !pol && !rg) {
+    if (!may_park) { a.ff_words = nullptr; a.ff_flag = nullptr; }  // (see the comment of the next branch but one)
+    hipLaunchKernelGGL((tb_step_kernel<TB_ENV_SWING, true, false, false, false, true>), grid, block, 0, s, a);
   } else if (may_park) TB_LAUNCH_STEP(TB_ENV_SWING, true, false);
   else if (piped) {
     // phase known and not the 26th step: every env has step_count = phase < 25 (all were reset
