@@ -531,7 +531,7 @@ __global__ void __launch_bounds__(320) tb_policy_rollout_kernel(KArgs A) {
           d = true;
         }
       } else {
-        rew = tennis_step<false>(A.P, s_hull, e, a, o, d, cnt TB_STAMP_PASS);
+        rew = tennis_step<false, true>(A.P, s_hull, e, a, o, d, cnt TB_STAMP_PASS);
       }
       cnt[6] += (uint32_t)(ns - 1);
       if (!(finite3(e.r.p) && finite3(e.r.v) && finite3(e.r.w) && finite3(e.b.p) && finite3(e.b.v) && finite3(e.b.w) &&
