@@ -323,13 +323,26 @@ namespace {
 // POLICY: the actions are not read from memory but inferred in-kernel (tb_policy_step).
 // REGROWS (Tennisbot, small batches): the static contact rows in registers, see solve_contacts.
 template <int KIND, bool LEAN, bool MULTI, bool RG, bool POLICY = false, bool REGROWS = false>
-__global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
+__global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict__ k_words, const uint8_t* __restrict__ k_done, const float* __restrict__ k_actions,
+                                                      const float4* __restrict__ k_hull, int k_n, int k_nhull, KArgs A) {
+  // The leading arguments repeat A.words / done_state / actions / hull / n / P.n_hull as separate,
+  // restrict-qualified kernel arguments: the compiler then knows that the state loads every launch starts
+  // with cannot alias the stores it ends with. (Preloading them into SGPRs at wave launch,
+  // -amdgpu-kernarg-preload-count, was measured too: no further gain for Tennisbot, -5 % for SwingRacket.)
   constexpr int NA = Dims<KIND>::A, NO = Dims<KIND>::O;
   __shared__ float4 s_hull[TB_MAX_HULL * 2];
   __shared__ __attribute__((aligned(16))) float s_mean[POLICY ? 64 * 8 : 4];
   // POLICY: 256-thread workgroups, four waves per 64 envs (see policy_towers); wave 0 steps the envs
   const int i = POLICY ? blockIdx.x * 64 + (threadIdx.x & 63) : blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < A.n;
+  // measured at 4096 envs: Tennisbot +5.6 % (687 -> 726 M env steps/s); SwingRacket -6 % if it uses them too
+  // (its kernels sit at the SGPR limit), so SwingRacket keeps reading the struct
+  constexpr bool SEP = KIND == TB_ENV_TENNIS;
+  const uint32_t* __restrict__ w_words = SEP ? k_words : A.words;
+  const uint8_t* __restrict__ w_done = SEP ? k_done : A.done_state;
+  const float* __restrict__ w_actions = SEP ? k_actions : A.actions;
+  const float4* __restrict__ w_hull = SEP ? k_hull : A.hull;
+  const int w_n = SEP ? k_n : A.n, w_nhull = SEP ? k_nhull : A.P.n_hull;
+  const bool live = i < w_n;
   EnvRegs e;
 #ifdef TB_DIAG_STAMPS
   const unsigned long long t_entry = stamp_now();
@@ -338,23 +351,24 @@ __global__ void __launch_bounds__(256) tb_step_kernel(KArgs A) {
   // the outline table -- so that their latencies overlap instead of queueing behind the barrier
   float a[NA];
   if (live && !(POLICY && threadIdx.x >= 64)) {
-    load_env<KIND>(A.words, A.done_state, A.n, i, e);
-    if (!POLICY) load_actions<KIND>(A.actions, (size_t)i, a);
+    load_env<KIND>(w_words, w_done, w_n, i, e);
+    if (!POLICY) load_actions<KIND>(w_actions, (size_t)i, a);
   }
   if (POLICY) {
     // one barrier for both hand-offs (outline table, action means); the outline rows are requested
     // before the towers' operands and parked in a register meanwhile
     static_assert(2 * TB_MAX_HULL <= 256, "one outline row per thread");
-    const bool has_row = (int)threadIdx.x < 2 * A.P.n_hull;
+    const bool has_row = (int)threadIdx.x < 2 * w_nhull;
     float4 row = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (has_row) row = A.hull[threadIdx.x];
+    if (has_row) row = w_hull[threadIdx.x];
     policy_towers<KIND>(A, s_mean);
     if (has_row) s_hull[threadIdx.x] = row;
     __syncthreads();
     if (threadIdx.x >= 64) return;  // no barrier below this point
     if (live) policy_sample<KIND>(A, s_mean, i, e, a);
   } else {
-    stage_hull(s_hull, A);
+    for (int k = threadIdx.x; k < 2 * w_nhull; k += blockDim.x) s_hull[k] = w_hull[k];
+    __syncthreads();
   }
 #ifdef TB_DIAG_STAMPS
   if (live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -850,25 +864,25 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
   (void)hipGetLastError();  // the check below is about THIS launch, not about whatever another library left behind
 #define TB_LAUNCH_STEP(KIND, LEAN, MULTI)                                                                      \
   do {                                                                                                         \
-    if (pol) hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, false, false, true>), grid, block, 0, s, a);        \
-    else if (rg) hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, MULTI, true>), grid, block, 0, s, a);           \
-    else hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, MULTI, false>), grid, block, 0, s, a);                  \
+    if (pol) hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, false, false, true>), grid, block, 0, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);        \
+    else if (rg) hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, MULTI, true>), grid, block, 0, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);           \
+    else hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, MULTI, false>), grid, block, 0, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);                  \
   } while (0)
   if (T > 1) {
     if (h->kind == TB_ENV_TENNIS) {
-      if (h->reg_rows && !pol && !rg) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, true, false, false, true>), grid, block, 0, s, a);
+      if (h->reg_rows && !pol && !rg) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, true, false, false, true>), grid, block, 0, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);
       else TB_LAUNCH_STEP(TB_ENV_TENNIS, false, true);
     } else if (piped) {
       if (!may_park) { a.ff_words = nullptr; a.ff_flag = nullptr; }
       TB_LAUNCH_STEP(TB_ENV_SWING, true, true);
     } else TB_LAUNCH_STEP(TB_ENV_SWING, false, true);
   } else if (h->kind == TB_ENV_TENNIS) {
-    if (h->reg_rows && !rg && pol) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, false, false, true, true>), grid, block, 0, s, a);
-    else if (h->reg_rows && !rg) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, false, false, false, true>), grid, block, 0, s, a);
+    if (h->reg_rows && !rg && pol) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, false, false, true, true>), grid, block, 0, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);
+    else if (h->reg_rows && !rg) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, false, false, false, true>), grid, block, 0, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);
     else TB_LAUNCH_STEP(TB_ENV_TENNIS, false, false);
   } else if (piped && h->swing_reg_rows && !pol && !rg) {
     if (!may_park) { a.ff_words = nullptr; a.ff_flag = nullptr; }  // (see the comment of the next branch but one)
-    hipLaunchKernelGGL((tb_step_kernel<TB_ENV_SWING, true, false, false, false, true>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((tb_step_kernel<TB_ENV_SWING, true, false, false, false, true>), grid, block, 0, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);
   } else if (may_park) TB_LAUNCH_STEP(TB_ENV_SWING, true, false);
   else if (piped) {
     // phase known and not the 26th step: every env has step_count = phase < 25 (all were reset
