@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--contact-off", action="store_true", help="BASELINE configs[1] bench mode: racket<->ball pair disabled")
     ap.add_argument("--racket-ground", action="store_true", help="also simulate racket<->court contact (TB_F_RACKET_GROUND, row f3; opt-in)")
+    ap.add_argument("--rolling-friction", action="store_true", help="also solve the rolling-friction rows of every ball contact (TbParams.roll_*, row f3; opt-in)")
     ap.add_argument("--magnus", type=float, default=0.0, help="BASELINE configs[4] extension: Magnus coefficient k_M in F = k_M w x v (0 = the reference)")
     ap.add_argument("--spin-max", type=float, default=0.0, help="BASELINE configs[4] extension: initial ball spin ~ U(-w, w)^3 rad/s at reset (0 = the reference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -275,6 +276,9 @@ def main():
     N = args.envs_per_gpu
     pipeline = kind == ENV_SWING and not args.no_pipeline
     ext = dict(magnus_k=args.magnus, ball_spin_max=args.spin_max) if (args.magnus or args.spin_max) else {}
+    if args.rolling_friction:
+        from tennisbot_rl_amd.params import reference_rolling_friction
+        ext.update(reference_rolling_friction())
     env = BatchedEnv(kind, N, device=dev, seed=args.seed, env_id_base=rank * N, params=default_params(flags=flags, **ext),
                      track_terminal_obs=False, pipeline=pipeline)
     T_buf = min(args.steps, 1100)  # rollout length of the reference: n_steps = 1100 (train_swing.py:49-50)
@@ -323,7 +327,8 @@ def main():
             "config": {"workload": "%s, %d envs/GPU, %s, auto-reset, U(-1,1) actions, rollout buffer %d steps%s%s%s" % (
                 "SwingRacket-v0" if args.env == "swing" else "Tennisbot-v0", N,
                 ("racket<->ball contact off (configs[1] bench mode)" if args.contact_off else "full contact semantics") + (" + racket<->court contact" if args.racket_ground else "")
-                + (" + Magnus k=%g, spin<=%g rad/s (extension, not in the reference)" % (args.magnus, args.spin_max) if ext else ""),
+                + (" + rolling-friction rows" if args.rolling_friction else "")
+                + (" + Magnus k=%g, spin<=%g rad/s (extension, not in the reference)" % (args.magnus, args.spin_max) if (args.magnus or args.spin_max) else ""),
                 T_buf, ", fast-forward pipelined on side streams" if pipeline else "", ", K steps replayed as one hipGraph" if (use_graph and GRAPH_STATE["used"]) else "",
                 gather_note),
                 "envs_per_gpu": N, "global_envs": world * N, "parallelism": "env-sharded x%d" % world},

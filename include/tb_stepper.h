@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TB_ABI_VERSION 1
+#define TB_ABI_VERSION 2
 
 /* library error codes (negative); positive return values are hipError_t */
 #define TB_OK 0
@@ -130,6 +130,13 @@ typedef struct TbParams {
   /* pair coefficients: product rule, objects.py:16-18,29-31,48-50; goal keeps defaults */
   float rest_racket, rest_court, rest_goal;
   float fric_racket, fric_court, fric_goal;
+  /* rolling friction of a ball contact (racket.py:43-45, objects.py:29-31,48-50 set rollingFriction .001):
+   * combined coefficient of the pair, Bullet's rule rolling_a * friction_b + rolling_b * friction_a
+   * (4e-4 with the racket and the court, 5e-4 with the goal: params.reference_rolling_friction()).
+   * > 0 adds two angular rows per ball contact, along the friction directions, each boxed by
+   * roll * j_n, solved between the normal and the sliding-friction rows. 0 (default) = no such rows:
+   * whether Bullet's multibody solver visits them in PyBullet's default solver mode is not known here */
+  float roll_racket, roll_court, roll_goal;
   /* racket <-> court (TB_F_RACKET_GROUND): product rule again (0.81, 0.04); manifold threshold
    * 0.02 * the racket's bounding radius at scale 1 (Bullet: 0.02 * angular motion disc) */
   float rest_racket_court, fric_racket_court, racket_ground_threshold;

@@ -147,6 +147,7 @@ typedef struct {
   real ball_inv_mass, ball_inv_inertia, ball_radius, magnus_k, ball_spin_max;
   real rest_racket, rest_court, rest_goal, fric_racket, fric_court, fric_goal;
   real rest_racket_court, fric_racket_court, racket_ground_threshold;
+  real roll_racket, roll_court, roll_goal;
   real ground_half[3], net_half[3], goal_radius, goal_half_len;
   real racket_scale;
   int n_hull; real hull_edges[TB_MAX_HULL][6];
@@ -187,6 +188,7 @@ static void prm_from(Prm *Q, const TbParams *P) {
   Q->rest_racket = W(P->rest_racket); Q->rest_court = W(P->rest_court); Q->rest_goal = W(P->rest_goal);
   Q->fric_racket = W(P->fric_racket); Q->fric_court = W(P->fric_court); Q->fric_goal = W(P->fric_goal);
   Q->rest_racket_court = W(P->rest_racket_court); Q->fric_racket_court = W(P->fric_racket_court);
+  Q->roll_racket = W(P->roll_racket); Q->roll_court = W(P->roll_court); Q->roll_goal = W(P->roll_goal);
   Q->racket_ground_threshold = P->racket_ground_threshold; /* derived from mesh data: exact as stored */
   Q->goal_radius = W(P->goal_radius); Q->goal_half_len = W(P->goal_half_len);
   Q->n_hull = P->n_hull;
@@ -375,6 +377,8 @@ typedef struct {
   v3 n, rr, t1, t2; /* n: toward the pushed body; rr: contact point relative to the racket COM */
   real mu, target, kn, kt1, kt2, jn, jt1, jt2;
   real inv_s2;      /* 1 / scale^2: the racket's inverse inertia at this env's globalScaling (see racket_invI) */
+  /* rolling friction (TbParams.roll_*; ball rows only): two angular rows along t1 / t2, boxed by roll * jn */
+  real roll, kr1, kr2, jr1, jr2;
 } Row;
 
 /* I_w^-1 x for a racket built with globalScaling s (tennisbot_env.py:234). Bullet derives the inertia
@@ -418,7 +422,7 @@ static inline void apply_impulse(const Prm *P, const Row *c, Racket *rk, Ball *b
     rk->w = axpy3(-j, racket_invI(P, rk->q, cross3(c->rr, dir), c->inv_s2), rk->w);
   }
 }
-static void setup_row(const Prm *P, Row *c, const Hit *h, int kind, real e, real mu, const Racket *rk, const Ball *b, real scale) {
+static void setup_row(const Prm *P, Row *c, const Hit *h, int kind, real e, real mu, real roll, const Racket *rk, const Ball *b, real scale) {
   const real r = P->ball_radius;
   memset(c, 0, sizeof *c);
   c->kind = kind; c->n = h->n; c->rr = h->rr; c->mu = mu;
@@ -441,6 +445,17 @@ static void setup_row(const Prm *P, Row *c, const Hit *h, int kind, real e, real
   if (rest < R(0)) rest = R(0);
   real pos = h->dist > R(0) ? -(h->dist * P->inv_dt) : -(h->dist * P->erp) * P->inv_dt;
   c->target = rest + pos; /* the normal row drives vn toward this value */
+  /* [3P-recalled] Bullet's torsional rows for rolling friction: angular-only Jacobians along the two
+   * friction directions, target relative spin 0, effective mass 1 / (t.I_b^-1 t + t.I_r^-1 t) */
+  c->roll = kind == ROW_RACKET_COURT ? R(0) : roll;
+  if (c->roll > R(0)) {
+    real k1 = P->ball_inv_inertia, k2 = P->ball_inv_inertia;
+    if (kind == ROW_BALL_RACKET) {
+      k1 = k1 + dot3(c->t1, racket_invI(P, rk->q, c->t1, c->inv_s2));
+      k2 = k2 + dot3(c->t2, racket_invI(P, rk->q, c->t2, c->inv_s2));
+    }
+    c->kr1 = R(1) / k1; c->kr2 = R(1) / k2;
+  }
 }
 
 /* racket vs the court's ground box (court.urdf:19-24), SURVEY.md A.3 / 8f.3. Bullet would build a
@@ -536,6 +551,27 @@ static void solve_contacts(const Prm *P, Row *rows, int nrows, Racket *rk, Ball 
       c->jn = jn;
       if (jn > jref) jref = jn;
       if (d != R(0)) { apply_impulse(P, c, rk, b, rb, c->n, d, 0); if (FABS(d) > P->solver_tol * jref) moved = 1; }
+    }
+    for (int i = 0; i < nrows; ++i) { /* rolling rows: after the normals, before sliding friction */
+      Row *c = &rows[i];
+      real lim = c->roll * c->jn;
+      if (!(lim > R(0))) continue;
+      for (int k = 0; k < 2; ++k) {
+        v3 t = k ? c->t2 : c->t1;
+        real *acc = k ? &c->jr2 : &c->jr1;
+        real kr = k ? c->kr2 : c->kr1;
+        real wt = dot3(t, c->kind == ROW_BALL_RACKET ? sub3(b->w, rk->w) : b->w);
+        real jr = FMA(-wt, kr, *acc);
+        jr = jr < -lim ? -lim : (jr > lim ? lim : jr);
+        real d = jr - *acc;
+        *acc = jr;
+        if (d != R(0)) {
+          b->w = axpy3(d * P->ball_inv_inertia, t, b->w);
+          if (c->kind == ROW_BALL_RACKET) rk->w = axpy3(-d, racket_invI(P, rk->q, t, c->inv_s2), rk->w);
+          /* an angular impulse: judged against jref through the ball radius (a length) */
+          if (FABS(d) > P->solver_tol * (FABS(jr) > jref * r ? FABS(jr) : jref * r)) moved = 1;
+        }
+      }
     }
     for (int i = 0; i < nrows; ++i) {
       Row *c = &rows[i];
@@ -650,11 +686,11 @@ static int substep(const Prm *P, int kind, Racket *rk, Ball *b, v3 Fr, v3 Tr, v3
   integrate_velocities(P, rk, b, Fr, Tr, Fb);
 
   if (bits) {
-    if (bits & CT_RACKET) setup_row(P, &rows[nrows++], &h, ROW_BALL_RACKET, P->rest_racket, P->fric_racket, rk, b, scale);
-    if (bits & CT_GROUND) setup_row(P, &rows[nrows++], &hg, ROW_BALL_STATIC, P->rest_court, P->fric_court, rk, b, scale);
-    if (bits & CT_NET) setup_row(P, &rows[nrows++], &hn, ROW_BALL_STATIC, P->rest_court, P->fric_court, rk, b, scale);
-    if (bits & CT_GOAL) setup_row(P, &rows[nrows++], &hc, ROW_BALL_STATIC, P->rest_goal, P->fric_goal, rk, b, scale);
-    for (int j = 0; j < nrg; ++j) setup_row(P, &rows[nrows++], &hrg[j], ROW_RACKET_COURT, P->rest_racket_court, P->fric_racket_court, rk, b, scale);
+    if (bits & CT_RACKET) setup_row(P, &rows[nrows++], &h, ROW_BALL_RACKET, P->rest_racket, P->fric_racket, P->roll_racket, rk, b, scale);
+    if (bits & CT_GROUND) setup_row(P, &rows[nrows++], &hg, ROW_BALL_STATIC, P->rest_court, P->fric_court, P->roll_court, rk, b, scale);
+    if (bits & CT_NET) setup_row(P, &rows[nrows++], &hn, ROW_BALL_STATIC, P->rest_court, P->fric_court, P->roll_court, rk, b, scale);
+    if (bits & CT_GOAL) setup_row(P, &rows[nrows++], &hc, ROW_BALL_STATIC, P->rest_goal, P->fric_goal, P->roll_goal, rk, b, scale);
+    for (int j = 0; j < nrg; ++j) setup_row(P, &rows[nrows++], &hrg[j], ROW_RACKET_COURT, P->rest_racket_court, P->fric_racket_court, R(0), rk, b, scale);
     solve_contacts(P, rows, nrows, rk, b);
   }
   integrate_pose(P, rk, b);

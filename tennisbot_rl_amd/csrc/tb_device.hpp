@@ -100,6 +100,7 @@ struct KParams {
   float ball_inv_mass, ball_inv_inertia, ball_radius, magnus_k, ball_spin_max;
   float rest_racket, rest_court, rest_goal, fric_racket, fric_court, fric_goal;
   float rest_racket_court, fric_racket_court, racket_ground_threshold;
+  float roll_racket, roll_court, roll_goal;
   float ground_half[3], net_half[3], goal_radius, goal_half_len;
   float static_top;  // highest point of any enabled static shape (host-derived)
   // conservative convex superset of the outline (host-derived): half-planes n.p <= h in the COM
@@ -437,6 +438,50 @@ TB_DEV bool friction_racket(const KParams& P, RowR& c, Racket& rk, Ball& b, floa
   return moved;
 }
 
+// Rolling friction (TbParams.roll_*; opt-in, part of the RG instantiations only so that the
+// default kernels carry none of it): two angular rows per ball contact along the friction directions, target
+// relative spin 0, boxed by roll * j_n; the angular impulse is judged against jref through the ball radius.
+struct RollS { float roll, kr, jr1, jr2; };
+struct RollR { vec3 ar1, ar2; float roll, kr1, kr2, jr1, jr2; };
+TB_DEV void setup_roll_static(const KParams& P, RollS& q, float roll) {
+  q.roll = roll; q.jr1 = 0.0f; q.jr2 = 0.0f; q.kr = 0.0f;
+  if (roll > 0.0f) q.kr = 1.0f / P.ball_inv_inertia;
+}
+template <bool SCALED>
+TB_DEV void setup_roll_racket(const KParams& P, RollR& q, const RowR& c, const Racket& rk, float scale) {
+  q.roll = P.roll_racket; q.jr1 = 0.0f; q.jr2 = 0.0f; q.kr1 = 0.0f; q.kr2 = 0.0f;
+  q.ar1 = mk(0.0f, 0.0f, 0.0f); q.ar2 = mk(0.0f, 0.0f, 0.0f);
+  if (q.roll > 0.0f) {
+    const float inv_s2 = SCALED ? 1.0f / (scale * scale) : 1.0f;
+    q.ar1 = racket_invI<SCALED>(P, rk.q, c.t1, inv_s2); q.kr1 = 1.0f / (P.ball_inv_inertia + dot(c.t1, q.ar1));
+    q.ar2 = racket_invI<SCALED>(P, rk.q, c.t2, inv_s2); q.kr2 = 1.0f / (P.ball_inv_inertia + dot(c.t2, q.ar2));
+  }
+}
+TB_DEV bool rolling_static(const KParams& P, const RowS& c, RollS& q, Ball& b, float jref) {
+  float lim = q.roll * c.jn;
+  if (!(lim > 0.0f)) return false;
+  bool moved = false;
+  const float ref = jref * P.ball_radius;
+  float d;
+  bool m = clamp_friction(dot(c.t1, b.w), q.kr, lim, P.solver_tol, ref, q.jr1, d);
+  if (d != 0.0f) { moved |= m; b.w = fma3(d * P.ball_inv_inertia, c.t1, b.w); }
+  m = clamp_friction(dot(c.t2, b.w), q.kr, lim, P.solver_tol, ref, q.jr2, d);
+  if (d != 0.0f) { moved |= m; b.w = fma3(d * P.ball_inv_inertia, c.t2, b.w); }
+  return moved;
+}
+TB_DEV bool rolling_racket(const KParams& P, const RowR& c, RollR& q, Racket& rk, Ball& b, float jref) {
+  float lim = q.roll * c.jn;
+  if (!(lim > 0.0f)) return false;
+  bool moved = false;
+  const float ref = jref * P.ball_radius;
+  float d;
+  bool m = clamp_friction(dot(c.t1, b.w - rk.w), q.kr1, lim, P.solver_tol, ref, q.jr1, d);
+  if (d != 0.0f) { moved |= m; b.w = fma3(d * P.ball_inv_inertia, c.t1, b.w); rk.w = fma3(-d, q.ar1, rk.w); }
+  m = clamp_friction(dot(c.t2, b.w - rk.w), q.kr2, lim, P.solver_tol, ref, q.jr2, d);
+  if (d != 0.0f) { moved |= m; b.w = fma3(d * P.ball_inv_inertia, c.t2, b.w); rk.w = fma3(-d, q.ar2, rk.w); }
+  return moved;
+}
+
 // racket vs the court's ground box (TB_F_RACKET_GROUND; opt-in). Bullet would
 // grow a persistent manifold of up to 4 points over several frames; here the manifold is rebuilt
 // every substep from the hull's 2 x n_hull vertices that are closer to the ground's top face than
@@ -581,7 +626,7 @@ TB_DEV bool friction_ground(const KParams& P, RowG& c, Racket& rk, float jref) {
 // TB_F_RACKET_GROUND is set; the default kernels do not contain any of this.
 template <bool RG> struct Rows;
 template <> struct Rows<false> { RowR rk; RowS st[3]; bool on[4]; };
-template <> struct Rows<true> { RowR rk; RowS st[3]; bool on[4]; RowG rg[TB_MAX_RG]; int nrg; };
+template <> struct Rows<true> { RowR rk; RowS st[3]; bool on[4]; RowG rg[TB_MAX_RG]; int nrg; RollR qrk; RollS qst[3]; };
 
 // REGROWS: the three static rows statically indexed too, i.e. in registers (~40 VGPRs more): the right
 // trade where balls bounce on the court all the time and occupancy matters little -- Tennisbot up to
@@ -606,6 +651,12 @@ TB_DEV void solve_contacts(const KParams& P, Rows<RG>& R, Racket& rk, Ball& b) {
 #pragma unroll
       for (int j = 0; j < TB_MAX_RG; ++j)
         if (j < R.nrg) moved |= normal_ground(P, R.rg[j], rk, jref);
+    }
+    if constexpr (RG) {  // rolling rows: after the normals, before sliding friction
+      if (R.on[0]) moved |= rolling_racket(P, R.rk, R.qrk, rk, b, jref);
+#pragma unroll 1
+      for (int i = 0; i < 3; ++i)
+        if (R.on[i + 1]) moved |= rolling_static(P, R.st[i], R.qst[i], b, jref);
     }
     if (R.on[0]) moved |= friction_racket(P, R.rk, rk, b, jref);
     if constexpr (REGROWS) {
@@ -746,8 +797,9 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, ve
   if (hc.hit) bits |= CT_GOAL;
   int rg_picks[TB_MAX_RG] = {-1, -1, -1, -1};
   vec3 rg_zr = mk(0.0f, 0.0f, 0.0f);
-  if constexpr (RG) {
-    if (racket_vs_ground(P, hull, rk, scale, rg_picks, rg_zr) > 0) bits |= CT_RACKET_COURT;
+  if constexpr (RG) {  // the RG instantiations also serve rolling friction alone: the flag decides at run time
+    if (P.flags & TB_F_RACKET_GROUND)
+      if (racket_vs_ground(P, hull, rk, scale, rg_picks, rg_zr) > 0) bits |= CT_RACKET_COURT;
   }
 
   if (__any(bits != 0)) {
@@ -765,6 +817,12 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, ve
       if (R.on[1]) setup_static(P, R.st[0], hg, P.rest_court, P.fric_court, b);
       if (R.on[2]) setup_static(P, R.st[1], hn, P.rest_court, P.fric_court, b);
       if (R.on[3]) setup_static(P, R.st[2], hc, P.rest_goal, P.fric_goal, b);
+      if constexpr (RG) {
+        if (R.on[0]) setup_roll_racket<KIND == TB_ENV_TENNIS>(P, R.qrk, R.rk, rk, scale);
+        if (R.on[1]) setup_roll_static(P, R.qst[0], P.roll_court);
+        if (R.on[2]) setup_roll_static(P, R.qst[1], P.roll_court);
+        if (R.on[3]) setup_roll_static(P, R.qst[2], P.roll_goal);
+      }
       solve_contacts<RG, REGROWS>(P, R, rk, b);
     }
   }

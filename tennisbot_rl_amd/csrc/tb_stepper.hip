@@ -698,6 +698,7 @@ void to_kparams(const TbParams* p, KParams* k) {
   k->rest_racket = p->rest_racket; k->rest_court = p->rest_court; k->rest_goal = p->rest_goal;
   k->fric_racket = p->fric_racket; k->fric_court = p->fric_court; k->fric_goal = p->fric_goal;
   k->rest_racket_court = p->rest_racket_court; k->fric_racket_court = p->fric_racket_court; k->racket_ground_threshold = p->racket_ground_threshold;
+  k->roll_racket = p->roll_racket; k->roll_court = p->roll_court; k->roll_goal = p->roll_goal;
   k->goal_radius = p->goal_radius; k->goal_half_len = p->goal_half_len;
   k->n_hull = p->n_hull;
   float top = p->ground_half[2] > p->goal_half_len ? p->ground_half[2] : p->goal_half_len;
@@ -794,6 +795,11 @@ int wait_side(TbHandle* h, hipStream_t s) {
   return TB_OK;
 }
 
+// the RG template instantiations hold what the default kernels leave out: racket <-> court contact and rolling friction
+bool extended_contacts(const KParams& kp) {
+  return (kp.flags & TB_F_RACKET_GROUND) || kp.roll_racket > 0.0f || kp.roll_court > 0.0f || kp.roll_goal > 0.0f;
+}
+
 // finish the lanes parked in `slot` on that slot's side stream, ordered after everything issued to `s` so far
 int launch_ff(TbHandle* h, int slot, const KArgs& a, const void* term, const void* substeps, hipStream_t s) {
   dim3 grid((unsigned)((h->n + h->block - 1) / h->block)), block((unsigned)h->block);
@@ -802,7 +808,7 @@ int launch_ff(TbHandle* h, int slot, const KArgs& a, const void* term, const voi
   // two fast-forwards that write the same terminal-obs / substeps buffer must finish in order
   if (h->last_slot >= 0 && h->last_slot != slot && ((term && term == h->last_term) || (substeps && substeps == h->last_sub)))
     HIP_TRY(hipStreamWaitEvent(h->side[slot], h->ev_ff[h->last_slot], 0));
-  if (h->kp.flags & TB_F_RACKET_GROUND) hipLaunchKernelGGL(tb_ff_kernel<true>, grid, block, 0, h->side[slot], a);
+  if (extended_contacts(h->kp)) hipLaunchKernelGGL(tb_ff_kernel<true>, grid, block, 0, h->side[slot], a);
   else hipLaunchKernelGGL(tb_ff_kernel<false>, grid, block, 0, h->side[slot], a);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(h->ev_ff[slot], h->side[slot]));
@@ -860,7 +866,7 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
     if (h->ff_busy[slot]) HIP_TRY(hipStreamWaitEvent(s, h->ev_ff[slot], 0));  // slot still in use by an older fast-forward
     a.defer = 1; a.ff_words = h->d_ff_words[slot]; a.ff_flag = h->d_ff_flag[slot];
   }
-  const bool rg = (h->kp.flags & TB_F_RACKET_GROUND) != 0;  // selects the instantiation that contains racket<->court contact
+  const bool rg = extended_contacts(h->kp);  // selects the instantiation that contains racket<->court contact and rolling friction
   (void)hipGetLastError();  // the check below is about THIS launch, not about whatever another library left behind
 #define TB_LAUNCH_STEP(KIND, LEAN, MULTI)                                                                      \
   do {                                                                                                         \
@@ -1165,7 +1171,7 @@ int tb_policy_step(TbHandle* h, const float* weights_dev, const float* obs_in_de
                    float* value_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, uint64_t noise_seed, int deterministic, void* stream) {
   if (!h || !weights_dev || !obs_in_dev || !actions_dev || !raw_actions_dev || !logp_dev || !value_dev || !obs_dev || !reward_dev || !done_dev)
     return fail(TB_E_INVAL, "tb_policy_step: null argument");
-  if (h->kp.flags & TB_F_RACKET_GROUND) return fail(TB_E_UNSUPPORTED, "tb_policy_step is not instantiated with TB_F_RACKET_GROUND");
+  if (extended_contacts(h->kp)) return fail(TB_E_UNSUPPORTED, "tb_policy_step is not instantiated with TB_F_RACKET_GROUND / rolling friction");
   DeviceGuard g(h->device);
   PolicyIO pol = {weights_dev, obs_in_dev, actions_dev, raw_actions_dev, logp_dev, value_dev, noise_seed, deterministic};
   return launch_step(h, 1, nullptr, obs_dev, reward_dev, done_dev, nullptr, nullptr, (hipStream_t)stream, &pol);
@@ -1178,7 +1184,7 @@ int tb_policy_rollout(TbHandle* h, int n_steps, const float* weights_dev, const 
     return fail(TB_E_INVAL, "tb_policy_rollout: null argument");
   if (n_steps < 1) return fail(TB_E_INVAL, "tb_policy_rollout: n_steps must be >= 1");
   if (!(h->kp.flags & TB_F_AUTO_RESET)) return fail(TB_E_UNSUPPORTED, "tb_policy_rollout needs TB_F_AUTO_RESET (episodes must restart inside the launch)");
-  if (h->kp.flags & TB_F_RACKET_GROUND) return fail(TB_E_UNSUPPORTED, "tb_policy_rollout is not instantiated with TB_F_RACKET_GROUND");
+  if (extended_contacts(h->kp)) return fail(TB_E_UNSUPPORTED, "tb_policy_rollout is not instantiated with TB_F_RACKET_GROUND / rolling friction");
   const bool swing = h->kind == TB_ENV_SWING;
   if (swing && !(h->pipeline && h->phase_valid))
     return fail(TB_E_UNSUPPORTED, "tb_policy_rollout on SwingRacket-v0 needs tb_set_pipeline(h, 1) and episodes in lockstep (every env reset together): "

@@ -59,6 +59,7 @@ class TbParams(ctypes.Structure):
         ("ball_radius", ctypes.c_float), ("magnus_k", ctypes.c_float), ("ball_spin_max", ctypes.c_float),
         ("rest_racket", ctypes.c_float), ("rest_court", ctypes.c_float), ("rest_goal", ctypes.c_float),
         ("fric_racket", ctypes.c_float), ("fric_court", ctypes.c_float), ("fric_goal", ctypes.c_float),
+        ("roll_racket", ctypes.c_float), ("roll_court", ctypes.c_float), ("roll_goal", ctypes.c_float),
         ("rest_racket_court", ctypes.c_float), ("fric_racket_court", ctypes.c_float), ("racket_ground_threshold", ctypes.c_float),
         ("ground_half", ctypes.c_float * 3), ("net_half", ctypes.c_float * 3),
         ("goal_radius", ctypes.c_float), ("goal_half_len", ctypes.c_float),
@@ -121,6 +122,14 @@ def urdf_file_inertia(scene=None):
     return dict(racket_inertia=tuple(sc["racket"]["inertia_diag"]), ball_inertia=sc["ball"]["inertia_diag"][0])
 
 
+def reference_rolling_friction():
+    """The pairs' combined rolling-friction coefficients of the reference scene: rollingFriction .001 and
+    lateralFriction .2 on racket, ball and court (racket.py:43-45, objects.py:29-31,48-50), Bullet's
+    defaults 0 / 0.5 on the goal; [3P-recalled] pair rule rolling_a * friction_b + rolling_b * friction_a.
+    `default_params(**reference_rolling_friction())` turns the rolling rows on (TbParams.roll_*)."""
+    return dict(roll_racket=0.001 * 0.2 + 0.001 * 0.2, roll_court=0.001 * 0.2 + 0.001 * 0.2, roll_goal=0.001 * 0.5 + 0.0 * 0.2)
+
+
 def default_params(racket_scale=1.0, flags=F_DEFAULT, scene=None, **overrides):
     """Reference scene + the Bullet defaults of SURVEY.md Appendix B.2.
 
@@ -155,6 +164,7 @@ def default_params(racket_scale=1.0, flags=F_DEFAULT, scene=None, **overrides):
         # objects.py:29-31,48-50); the goal keeps Bullet's defaults (0 / 0.5); pair = product
         rest_racket=0.9 * 0.9, rest_court=0.9 * 0.9, rest_goal=0.9 * 0.0,
         fric_racket=0.2 * 0.2, fric_court=0.2 * 0.2, fric_goal=0.2 * 0.5,
+        roll_racket=0.0, roll_court=0.0, roll_goal=0.0,  # rolling-friction rows: opt-in, reference_rolling_friction()
         rest_racket_court=0.9 * 0.9, fric_racket_court=0.2 * 0.2,
         ground_half=tuple(0.5 * x for x in sc["court"]["ground_box_size"]),
         net_half=tuple(0.5 * x for x in sc["court"]["net_box_size"]),
@@ -169,7 +179,8 @@ def default_params(racket_scale=1.0, flags=F_DEFAULT, scene=None, **overrides):
     for k in ("dt", "gravity", "lin_damp", "ang_damp", "max_ang_step", "rest_vel_threshold", "erp",
               "contact_threshold", "solver_tol", "racket_mass", "hull_margin", "ball_mass", "ball_radius", "magnus_k",
               "ball_spin_max", "rest_racket", "rest_court", "rest_goal", "fric_racket", "fric_court",
-              "fric_goal", "rest_racket_court", "fric_racket_court", "goal_radius", "goal_half_len"):
+              "fric_goal", "roll_racket", "roll_court", "roll_goal", "rest_racket_court", "fric_racket_court", "goal_radius",
+              "goal_half_len"):
         setattr(p, k, float(prim[k]))
     p.inv_dt = 1.0 / float(prim["dt"])
     p.solver_iters = int(prim["solver_iters"])

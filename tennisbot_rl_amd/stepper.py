@@ -85,8 +85,8 @@ def load_library():
     for f in ("tb_create", "tb_destroy", "tb_set_params", "tb_reset", "tb_step", "tb_rollout", "tb_get_state",
               "tb_set_state", "tb_counters", "tb_counters_reset", "tb_obs_dim", "tb_act_dim", "tb_state_words"):
         getattr(L, f).restype = i32
-    if L.tb_abi_version() != 1:
-        raise StepperError("libtb_stepper.so ABI version %d, expected 1" % L.tb_abi_version())
+    if L.tb_abi_version() != 2:
+        raise StepperError("libtb_stepper.so ABI version %d, expected 2" % L.tb_abi_version())
     for kind in (ENV_SWING, ENV_TENNIS):
         assert L.tb_obs_dim(kind) == OBS_DIM[kind] and L.tb_act_dim(kind) == ACT_DIM[kind]
         assert L.tb_state_words(kind) == STATE_WORDS[kind]

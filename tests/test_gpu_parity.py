@@ -11,7 +11,8 @@ import pytest
 
 from helpers import make_words
 from oracle import OracleBatch
-from tennisbot_rl_amd.params import (ENV_SWING, ENV_TENNIS, F_AUTO_RESET, F_DEFAULT, F_NET, F_RACKET_GROUND, STATE_WORDS, default_params)
+from tennisbot_rl_amd.params import (ENV_SWING, ENV_TENNIS, F_AUTO_RESET, F_DEFAULT, F_NET, F_RACKET_GROUND, STATE_WORDS, default_params,
+                                     reference_rolling_friction)
 
 pytestmark = pytest.mark.gpu
 
@@ -86,7 +87,7 @@ def run_lockstep(torch, env, ref, steps, rng, what, check_state_every=1):
 def test_native_library_is_the_one_running(torch):
     from tennisbot_rl_amd import stepper
     L = stepper.load_library()
-    assert L.tb_abi_version() == 1
+    assert L.tb_abi_version() == 2
     with open("/proc/self/maps") as f:
         assert "libtb_stepper.so" in f.read()
 
@@ -216,18 +217,21 @@ def test_forced_contacts_exercise_the_solver(torch):
     env.close()
 
 
-@pytest.mark.parametrize("kind,rg", [(ENV_TENNIS, False), (ENV_SWING, False), (ENV_TENNIS, True), (ENV_SWING, True)])
-def test_fuzzed_states_around_the_racket_stay_bit_exact(torch, kind, rg):
+@pytest.mark.parametrize("kind,rg,roll", [(ENV_TENNIS, False, False), (ENV_SWING, False, False), (ENV_TENNIS, True, False), (ENV_SWING, True, False),
+                                          (ENV_TENNIS, False, True), (ENV_SWING, False, True), (ENV_TENNIS, True, True)])
+def test_fuzzed_states_around_the_racket_stay_bit_exact(torch, kind, rg, roll):
     """16 384 random states with the ball anywhere in a thin shell around a randomly oriented (Tennisbot:
     randomly scaled) racket that itself hovers close to the court -- faces, rim, handle, corners, grazing
     and deep overlaps, ball on racket AND ground at once -- stepped 8 times: every output and the whole
     state bit-exact against the oracle. The outline sweep's inside / edge / corner cases and the
     multi-row solver only occur by accident in the policy-driven tests. rg: with the opt-in
-    racket<->court contact as well (racket, ball and court in one solve)."""
+    racket<->court contact as well (racket, ball and court in one solve); roll: with the opt-in
+    rolling-friction rows (TbParams.roll_*) in every ball contact."""
     n = 2048 if rg else 16384
-    rng = np.random.default_rng(97 + kind + 10 * rg)
+    rng = np.random.default_rng(97 + kind + 10 * rg + 100 * roll)
     p = default_params()
-    env, ref = make_pair(torch, kind, n, auto_reset=False, flags=F_DEFAULT | (F_RACKET_GROUND if rg else 0))
+    over = reference_rolling_friction() if roll else {}
+    env, ref = make_pair(torch, kind, n, auto_reset=False, flags=F_DEFAULT | (F_RACKET_GROUND if rg else 0), **over)
     ref.L.tbo_set_threads(ref.h, 8)
     scale = rng.uniform(1.0, 3.0, n) if kind == ENV_TENNIS else np.ones(n)
     q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
@@ -261,8 +265,14 @@ def test_fuzzed_states_around_the_racket_stay_bit_exact(torch, kind, rg):
         A = 6
     w, d = make_words(kind, n, **fields)
     env.set_state_words(w.view(np.int32), d); ref.set_state_words(w, d)
+    plain = None
+    if roll:  # the same states without the rolling rows: they must end up elsewhere
+        plain, _ = make_pair(torch, kind, n, auto_reset=False, flags=F_DEFAULT | (F_RACKET_GROUND if rg else 0))
+        plain.set_state_words(w.view(np.int32), d)
     for t in range(4 if rg else 8):
         a = rng.uniform(-1, 1, (n, A)).astype(np.float32)
+        if plain is not None:
+            plain.step(torch.from_numpy(a).cuda())
         obs, rew, done = env.step(torch.from_numpy(a).cuda())
         o2, r2, d2, s2 = ref.step(a)
         same(done.cpu().numpy(), d2, "fuzz done %d" % t)
@@ -272,7 +282,41 @@ def test_fuzzed_states_around_the_racket_stay_bit_exact(torch, kind, rg):
         compare_state(env, ref, "fuzz %d" % t)
     c = env.counters()
     assert c["racket_ball_contact_substeps"] > n // 8 and c["nonfinite_states"] == 0
+    if plain is not None:
+        differ = (env.get_state_words()[0] != plain.get_state_words()[0]).any(0)
+        assert int(differ.sum()) > n // 8
+        plain.close()
     env.close()
+
+
+@pytest.mark.parametrize("kind,n,steps", [(ENV_SWING, 4096, 46), (ENV_TENNIS, 1000, 700)])
+def test_rolling_friction_rows_in_lockstep_and_not_a_no_op(torch, kind, n, steps):
+    """whole episodes with the opt-in rolling-friction rows: bit-exact against the oracle, the
+    same through the pipelined fast-forward kernel on SwingRacket, and the rows do change what balls do"""
+    from tennisbot_rl_amd.stepper import BatchedEnv, StepperError
+    roll = reference_rolling_friction()
+    env, ref = make_pair(torch, kind, n, **roll)
+    ref.L.tbo_set_threads(ref.h, 8)
+    run_lockstep(torch, env, ref, steps, np.random.default_rng(5), "rolling kind %d" % kind, check_state_every=13)
+    rng = np.random.default_rng(5)
+    acts = torch.from_numpy(rng.uniform(-1, 1, (steps, n, env.act_dim)).astype(np.float32)).cuda()
+    # a second pass next to an env without the rows; on SwingRacket through tb_ff_kernel<extended> on the side streams
+    plain, _ = make_pair(torch, kind, n)
+    again = BatchedEnv(kind, n, device="cuda:0", seed=11, params=default_params(**roll), pipeline=kind == ENV_SWING)
+    plain.reset(); again.reset()
+    differ = torch.zeros(n, dtype=torch.bool, device="cuda")
+    for t in range(steps):
+        differ |= (again.step(acts[t])[0] != plain.step(acts[t])[0]).any(1)
+    again.flush()
+    assert torch.equal(env.get_state_words()[0], again.get_state_words()[0]) and env.counters() == again.counters()
+    if kind == ENV_TENNIS:  # balls that bounce on the court before they reach the racket; SwingRacket's contacts are
+        assert int(differ.sum()) > 0  # rare under random actions (the fuzz test forces them)
+    others = [plain, again]
+    with pytest.raises(StepperError):  # the fused policy kernels are built without the extended contact set
+        env.policy_step(torch.zeros(env.policy_floats(), device="cuda"), env.reset())
+    env.close()
+    for e in others:
+        e.close()
 
 
 def test_rollout_equals_repeated_steps(torch):

@@ -30,12 +30,19 @@ def rollout_rewards(num_envs=4096, episodes=4, seed=0, **overrides):
     blob = pack_policy(policy)
     env = BatchedEnv(ENV_SWING, num_envs, device="cuda:0", seed=seed, pipeline=True, track_terminal_obs=False, params=default_params(**overrides))
     obs = env.reset()
-    total = torch.zeros(num_envs, device="cuda:0")
+    # the fused policy kernels are built without the extended contact set: roll the torch module out instead
+    fused = not any(k.startswith("roll_") and v > 0 for k, v in overrides.items())
+    torch.manual_seed(seed + 17)
     out = []
     for ep in range(episodes):
         steps = []
         for t in range(26):
-            (obs, rew, done), _ = env.policy_step(blob, obs, seed=seed + 17)
+            if fused:
+                (obs, rew, done), _ = env.policy_step(blob, obs, seed=seed + 17)
+            else:
+                with torch.no_grad():
+                    act, _, _ = policy.act(obs)
+                obs, rew, done = env.step(act.clamp(-1.0, 1.0))
             steps.append((rew, done))
         env.flush()  # terminal rewards arrive from the side streams
         ret = torch.stack([r for r, _ in steps]).sum(0)
@@ -67,6 +74,10 @@ def main():
                 "ball recomputed, racket as in the URDF": dict(racket_inertia=(0.04, 0.08, 0.12), ball_inertia=bullet_recomputed_inertia()["ball_inertia"])}
     if len(sys.argv) > 1 and sys.argv[1] == "--default-only":
         variants = {"default parameters": {}}
+    if len(sys.argv) > 1 and sys.argv[1] == "--rolling":
+        from tennisbot_rl_amd.params import reference_rolling_friction
+        variants = {"default parameters": {}, "rolling-friction rows on": reference_rolling_friction(),
+                    "rolling-friction rows on, 10 x the coefficient": {k: 10 * v for k, v in reference_rolling_friction().items()}}
     if len(sys.argv) > 1 and sys.argv[1] == "--sensitivity":
         # not a fit (100 episodes cannot carry one): which recalled constants does the record constrain at all?
         variants = {"default parameters": {}, "no damping": dict(lin_damp=0.0, ang_damp=0.0), "damping 0.02": dict(lin_damp=0.02, ang_damp=0.02),
