@@ -58,7 +58,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1040, help="timed agent steps (default 40 Swing episodes of 26)")
-    ap.add_argument("--warmup", type=int, default=52)
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps after reset (default 52 SwingRacket / 1040 Tennisbot: its envs are reset together and their first episode -- every ball still in flight -- steps 12 %% faster than the steady state; with a graph, its K steps are also replayed once before the clock starts)")
     ap.add_argument("--env", choices=["swing", "tennis"], default="swing")
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--contact-off", action="store_true", help="BASELINE configs[1] bench mode: racket<->ball pair disabled")
@@ -70,10 +70,13 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work per baseline leg (1 core, all cores)")
     ap.add_argument("--sweep", action="store_true", help="also time N = 4096 .. 4M envs on one GPU (extra JSON key)")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--gather-chunks", type=int, default=1, help="N > 1: ship the rollout in this many step-chunks, each all-gather overlapped with later chunks' steps (one hipGraph per chunk); default 1 = ONE all-gather at the collect boundary, as BASELINE.json's north_star words it")
+    ap.add_argument("--gather-chunks", type=int, default=0, help="multi-rank exchange of the rollout: 1 = ONE all-gather at the collect boundary; C > 1 = C step-chunks, each all-gather overlapped with later chunks' steps; 0 (default) = measure both on the node, untimed, and time the faster")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of replaying one captured hipGraph")
     ap.add_argument("--no-pipeline", action="store_true", help="run the SwingRacket fast-forward inside the step kernel instead of a side stream")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.warmup is None:
+        args.warmup = 52 if args.env == "swing" else 1040
+    return args
 
 
 def fill_actions(buf_actions, seed, torch):
@@ -89,86 +92,112 @@ def fill_actions(buf_actions, seed, torch):
         buf_actions[t0:t0 + n].copy_(a[:n])
 
 
-GRAPH_STATE = {"used": True, "chunks": 1, "gather_ok": None}
+GRAPH_STATE = {"used": True, "chunks": 1, "priority": 0, "gather_ok": None, "tuning": None}
 
 
-def time_steps(env, buf, steps, warmup, torch, dist_on, tail_gather=True, graph=False, gather_chunks=1, force_collective=False):
+def time_steps(env, buf, steps, warmup, torch, dist_on, tail_gather=True, graph=False, gather_chunks=0, force_collective=False):
     """W untimed + K timed steps; returns (wall seconds, HIP-event seconds of the K launches).
     graph=True: the K timed steps are captured once into a hipGraph (outside the timed region) and
     the timed region replays it -- same kernels, same buffers, no per-step host work.
-    gather_chunks=C > 1 (multi-rank): the rollout is exchanged in C step-chunks; chunk c's all-gather
-    is issued from a side stream that waits for the chunk's steps and for the fast-forwards that still
-    owe them rewards, while the main stream goes on stepping chunk c+1. With graph=True every chunk is
-    its own hipGraph (RolloutBuffer.capture_chunks: episode ends near a chunk's end are parked and
-    their fast-forwards launched by the next graph, so no graph stalls on a join) and the collectives
-    are issued eagerly between the replays; otherwise the chunks are enqueued by tb_step_sequence."""
+    The exchange at the collect boundary (multi-rank only) has two forms: ONE all-gather after the K
+    steps, or C step-chunks whose all-gathers run on a side stream while the main stream goes on
+    stepping (the K steps stay ONE hipGraph with a progress mark behind every chunk,
+    RolloutBuffer.capture_marked; the host watches the marks and issues each chunk's collective as
+    soon as its records are final; only this library's kernels are captured, the collectives are
+    plain asynchronous RCCL calls). gather_chunks = 1 / C > 1 picks a form; 0 = try ONE, and 8
+    chunks at both stream priorities, untimed, on the node itself, and time the fastest (all ranks
+    agree through an all-reduce): which one overlaps best depends on how the runtime maps streams to
+    hardware queues, and is measured rather than assumed."""
     dev = env.device
     T = buf.T
     for t in range(warmup):
         buf.step_into(env, t % T)
-    collective = dist_on or force_collective
-    chunks = gather_chunks if (collective and tail_gather and gather_chunks > 1 and steps == T and steps % gather_chunks == 0) else 1
-    seg = steps // chunks
-    if collective and tail_gather:  # RCCL's first use of a collective (channels, buffers) stays outside the timed region
-        if chunks > 1:
-            buf.begin_gather(chunks, force=force_collective)
-            for c in range(chunks):
-                buf.gather_chunk(c, env=env, force=force_collective)
-            buf.finish_gather()
-        else:
-            buf.all_gather(force=force_collective)
-        torch.cuda.synchronize(dev)
+    collective = (dist_on or force_collective) and tail_gather
+    chunkable = collective and steps == T
 
-    def chunked_body():  # host-issued variant (--no-graph, or capture failed)
-        for c in range(chunks):
-            buf.step_range(env, c * seg, (c + 1) * seg)
-            buf.gather_chunk(c, env=env, force=force_collective)
-        env.flush()
+    def usable(c):
+        return c > 1 and chunkable and steps % c == 0
+    if gather_chunks == 0:
+        modes = [(1, 0)] + ([(8, -1), (8, 0)] if usable(8) else [])
+    elif usable(gather_chunks):
+        modes = [(gather_chunks, -1 if getattr(env, "pipeline", False) else 0)]
+    else:
+        modes = [(1, 0)]
 
-    g, chunk_graphs = None, None
+    plain, marked = None, {}
     if graph:
         try:
-            if chunks > 1:
-                chunk_graphs = buf.capture_chunks(env, chunks)  # only this library's kernels are captured; the collectives stay eager
-                g = chunk_graphs[0][0]
-            else:
-                def body():
-                    for t in range(steps):
-                        buf.step_into(env, t % T)
-                g = env.capture(body)
+            def body():
+                for t in range(steps):
+                    buf.step_into(env, t % T)
+            # a capture advances the library's episode-phase hint by K steps without running them: replay each
+            # graph once before anything else is captured or stepped
+            if any(c == 1 for c, _ in modes):
+                plain = env.capture(body)
+                plain.replay()
+                torch.cuda.synchronize(dev)
+            for c in sorted({c for c, _ in modes if c > 1}):
+                marked[c] = buf.capture_marked(env, c)
+                marked[c].replay()
+                torch.cuda.synchronize(dev)
         except Exception as exc:  # fall back to host-issued launches and say so
             print("hipGraph capture failed (%s: %s); issuing the steps from the host" % (type(exc).__name__, exc), file=sys.stderr)
-            g, chunk_graphs = None, None
-    GRAPH_STATE["used"] = g is not None
-    if dist_on:
-        torch.distributed.barrier()
-    torch.cuda.synchronize(dev)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(torch.cuda.current_stream(dev))  # the stream the step kernel is launched on
-    if chunk_graphs is not None:
-        buf.replay_chunks(chunk_graphs[0], chunk_graphs[1], gather=True, force=force_collective)
-    elif g is not None:
-        g.replay()
-    elif chunks > 1:
-        chunked_body()
-    else:
-        for t0_ in range(0, steps, T):
-            buf.step_range(env, 0, min(T, steps - t0_))
-        env.flush()  # pipelined fast-forwards: every step's outputs are complete from here on
-    ev1.record(torch.cuda.current_stream(dev))
-    if chunks > 1:
-        buf.finish_gather()
-    elif tail_gather:
-        buf.all_gather(force=force_collective)  # collect boundary: one collective (no-op for a single rank)
-    if dist_on:
-        torch.distributed.barrier()
-    torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - t0
-    GRAPH_STATE["chunks"] = chunks
-    if collective and tail_gather:  # after the clock: every rank must hold every shard, starting with its own
+            plain, marked, graph = None, {}, False
+    GRAPH_STATE["used"] = bool(graph)
+
+    def run(mode):
+        chunks, prio = mode
+        seg = steps // chunks
+        if chunks > 1:
+            buf.begin_gather(chunks, force=force_collective, priority=prio)
+        if dist_on:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(torch.cuda.current_stream(dev))  # the stream the step kernel is launched on
+        if chunks > 1 and graph:
+            buf.replay_marked(marked[chunks], env, chunks, gather=True, force=force_collective)
+        elif chunks > 1:  # host-issued variant (--no-graph, or capture failed): the side stream waits by event
+            for c in range(chunks):
+                buf.step_range(env, c * seg, (c + 1) * seg)
+                buf.gather_chunk(c, env=env, force=force_collective)
+            env.flush()
+        elif graph:
+            plain.replay()
+        else:
+            for t0_ in range(0, steps, T):
+                buf.step_range(env, 0, min(T, steps - t0_))
+            env.flush()  # pipelined fast-forwards: every step's outputs are complete from here on
+        ev1.record(torch.cuda.current_stream(dev))
+        if chunks > 1:
+            buf.finish_gather()
+        elif tail_gather:
+            buf.all_gather(force=force_collective)  # collect boundary: one collective (no-op for a single rank)
+        if dist_on:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0, ev0.elapsed_time(ev1) * 1e-3
+
+    if collective:  # RCCL's first use of each collective shape (channels, buffers) stays outside the timed region; so does the tuning
+        trial = []
+        for mode in modes:
+            run(mode)
+            best = min(run(mode)[0] for _ in range(2)) if len(modes) > 1 else 0.0
+            trial.append(best)
+        if len(modes) > 1:
+            tt = torch.tensor(trial, dtype=torch.float64, device=dev)
+            if dist_on:
+                torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            trial = [float(x) for x in tt.tolist()]
+            GRAPH_STATE["tuning"] = {"%d chunk%s, stream priority %d" % (c, "" if c == 1 else "s", p): round(x * 1e3, 3) for (c, p), x in zip(modes, trial)}
+            modes = [modes[trial.index(min(trial))]]
+    env.counters_reset()  # from here on the counters hold the timed steps only
+    wall, ev_s = run(modes[0])
+    GRAPH_STATE["chunks"], GRAPH_STATE["priority"] = modes[0]
+    if collective:  # after the clock: every rank must hold every shard, starting with its own
         GRAPH_STATE["gather_ok"] = bool(buf.check_gathered())
-    return wall, ev0.elapsed_time(ev1) * 1e-3
+    return wall, ev_s
 
 
 def open_loop_rate(kind, N, flags, pipeline, dev, seed, torch):
@@ -181,7 +210,7 @@ def open_loop_rate(kind, N, flags, pipeline, dev, seed, torch):
     K = 1040
     acts = torch.empty((K, N, env.act_dim), dtype=torch.float32, device=dev).uniform_(-1.0, 1.0)
     env.reset()
-    env.rollout(acts[:52])
+    env.rollout(acts[:52] if pipeline else acts)  # Tennisbot: past the first (synchronised, cheaper) episodes
     env.flush()
     g = env.capture(lambda: env.rollout(acts))
     torch.cuda.synchronize(dev)
@@ -288,7 +317,16 @@ def main():
     env.reset()
     env.counters_reset()
     use_graph = not args.no_graph
-    chunks = max(1, args.gather_chunks)
+    chunks = max(0, args.gather_chunks)
+    fake_us = float(os.environ.get("TB_BENCH_FAKE_GATHER_US", "0"))
+    if fake_us > 0 and force_collective:
+        # one-GPU rehearsal of the overlap: every exchange of the whole rollout is preceded, on the stream that
+        # carries it, by a kernel that just runs for fake_us in total (split over the chunks)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(1000); torch.cuda.synchronize(dev)
+        e0.record(); torch.cuda._sleep(10_000_000); e1.record(); torch.cuda.synchronize(dev)
+        cycles_per_us = 10_000_000 / (e0.elapsed_time(e1) * 1e3)
+        buf.rehearsal_total_cycles = int(fake_us * cycles_per_us)
     wall, ev_s = time_steps(env, buf, args.steps, args.warmup, torch, dist_on, graph=use_graph, gather_chunks=chunks, force_collective=force_collective)
     gather_note = ""
     if GRAPH_STATE["gather_ok"] is False:
@@ -296,7 +334,9 @@ def main():
     if dist_on or force_collective:
         gather_note = (", 1 RCCL all-gather of rollouts at the collect boundary" if GRAPH_STATE["chunks"] == 1 else
                        ", rollouts all-gathered (RCCL) in %d step-chunks, each overlapped with the next chunk's steps%s" % (
-                           GRAPH_STATE["chunks"], " (one hipGraph per chunk)" if GRAPH_STATE["used"] else " (steps enqueued by tb_step_sequence)"))
+                           GRAPH_STATE["chunks"], " (one hipGraph, progress marks watched by the host)" if GRAPH_STATE["used"] else " (steps enqueued by tb_step_sequence)"))
+        if GRAPH_STATE["tuning"]:
+            gather_note += "; exchange form chosen on this node before the clock started, ms per K steps + exchange: %s" % json.dumps(GRAPH_STATE["tuning"])
     c = env.counters()
 
     wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
@@ -305,8 +345,7 @@ def main():
         torch.distributed.all_reduce(wall_t, op=torch.distributed.ReduceOp.MAX)
         torch.distributed.all_reduce(sub_t, op=torch.distributed.ReduceOp.SUM)
     wall_max = float(wall_t.item())
-    # warm-up substeps are in the counter too: scale to the timed share
-    timed_substeps = float(sub_t.item()) * args.steps / (args.steps + args.warmup)
+    timed_substeps = float(sub_t.item())  # time_steps resets the counters right before the timed steps
 
     result = None
     if rank == 0:
@@ -352,7 +391,7 @@ def main():
             b2.bind(e2)
             e2.reset()
             k = 52 if n >= 1048576 else 104
-            w, evs = time_steps(e2, b2, k, 26, torch, False, tail_gather=False, graph=use_graph)
+            w, evs = time_steps(e2, b2, k, 26 if kind == ENV_SWING else 1040, torch, False, tail_gather=False, graph=use_graph)  # Tennisbot: steady state, past the first episodes
             ab = ALGO_BYTES[args.env]
             sweep.append({"envs": n, "steps_per_s": n * k / w, "launch_us": evs / k * 1e6,
                           "achieved_GBs": (ab["read"] + ab["write"]) * n / (evs / k) / 1e9})

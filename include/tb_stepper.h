@@ -38,6 +38,7 @@ extern "C" {
 #define TB_E_NODEVICE (-2) /* no usable HIP device / device index out of range */
 #define TB_E_PARAMS (-3)   /* TbParams failed validation (n_hull, dt, masses, ...) */
 #define TB_E_UNSUPPORTED (-4)
+#define TB_E_TIMEOUT (-5)    /* tb_mark_host_wait: the mark did not fire in time */
 
 /* env kinds: tennisbot/__init__.py:3-11 registers exactly these two ids */
 #define TB_ENV_SWING 0  /* SwingRacket-v0 -> tennisbot/envs/swingracket_env.py */
@@ -295,6 +296,30 @@ int tb_flush(TbHandle *h, void *stream);
 int tb_set_defer(TbHandle *h, int on);
 int tb_ff_launch_pending(TbHandle *h, void *stream);
 int tb_pipeline_join(TbHandle *h, void *stream);
+/*
+ * Progress marks (for callers that ship a rollout in chunks while ONE hipGraph is still producing it). A mark
+ * tells the HOST that everything tb_step was asked to do before it is final in the caller's buffers -- the steps
+ * themselves AND the late fast-forward writes they are still owed -- without making any stream wait for
+ * anything: nothing is forked or joined, the graph keeps the shape it has without marks.
+ * tb_mark_enable(h, 1): from now on every fast-forward kernel is followed on its side stream by a one-thread
+ * kernel that counts it as finished in pinned host memory (off by default: plain graphs carry nothing extra);
+ * call it before issuing -- or capturing -- the steps that marks will cover.
+ * tb_mark_record(h, k, stream): the same one-thread kernel on `stream`, incrementing counter k; the library
+ * remembers how many fast-forwards were enqueued before the mark. Captured into a graph these are ordinary kernel nodes: every replay fires them again.
+ * tb_mark_begin(h): snapshot of the counters; call it right before launching the work that contains the marks,
+ * with nothing of this handle in flight (e.g. after a stream synchronize).
+ * tb_mark_host_wait(h, k, timeout_ms): spin on the host until mark k has fired since tb_mark_begin and the
+ * fast-forwards enqueued before it have finished; TB_E_TIMEOUT otherwise. The host waits, never a stream: a
+ * stream-side wait queued on a hardware queue that the graph's own later kernels share would stall the very work
+ * it waits for. One marked graph per handle at a time; 0 <= k < TB_MAX_MARKS.
+ * tb_mark_count(h, k): how often mark k has fired since tb_create (a host read, no HIP call).
+ */
+#define TB_MAX_MARKS 64
+int tb_mark_enable(TbHandle *h, int on);
+int tb_mark_record(TbHandle *h, int k, void *stream);
+int tb_mark_begin(TbHandle *h);
+int tb_mark_host_wait(TbHandle *h, int k, int timeout_ms);
+long long tb_mark_count(TbHandle *h, int k);
 /* Stream-capture support (hipGraph): events recorded inside a capture are meaningless outside
  * it and vice versa. Call with host_wait = 1 right BEFORE beginning a capture that will contain
  * tb_step calls (drains the side streams on the host and forgets their events), capture

@@ -629,9 +629,10 @@ template <> struct Rows<false> { RowR rk; RowS st[3]; bool on[4]; };
 template <> struct Rows<true> { RowR rk; RowS st[3]; bool on[4]; RowG rg[TB_MAX_RG]; int nrg; RollR qrk; RollS qst[3]; };
 
 // REGROWS: the three static rows statically indexed too, i.e. in registers (~40 VGPRs more): the right
-// trade where balls bounce on the court all the time and occupancy matters little -- Tennisbot up to
-// 131072 envs (+12 % on whole episodes; tb_create decides); for SwingRacket the registers cost more
-// than they give at every size (-2 % at 4096 envs, -17 % at 1 M). Same arithmetic either way.
+// trade where balls bounce on the court all the time -- Tennisbot at every batch size (+8 ... +28 % in
+// the steady state; tb_create decides) and SwingRacket's loop-free pipelined step kernel up to 131072
+// envs (+2.7 % at 4096); in SwingRacket's fast-forward loop the registers cost more than they give
+// (-6 % at 4096 envs, -17 % at 1 M). Same arithmetic either way.
 template <bool RG, bool REGROWS>
 TB_DEV void solve_contacts(const KParams& P, Rows<RG>& R, Racket& rk, Ball& b) {
   float jref = 0.0f;

@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
 
 #include "../../include/tb_stepper.h"
 #include "tb_device.hpp"
@@ -571,6 +572,13 @@ __global__ void __launch_bounds__(320) tb_policy_rollout_kernel(KArgs A) {
   if (blockIdx.x == 0 && lane == 0) atomicAdd(&A.counters[6], (unsigned long long)A.n * (unsigned long long)A.T);
 }
 
+// progress mark (tb_mark_record): one thread bumps a counter in pinned host memory. Relaxed on purpose: the kernels this
+// one is ordered behind have completed, their end-of-kernel release included, before it starts; a release of its own
+// would only write the L2 back once more, under the step kernels that are running by then
+__global__ void tb_mark_kernel(unsigned long long* count) {
+  __hip_atomic_fetch_add(count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // finishes parked SwingRacket fast-forwards (side stream): same device code as the in-step loop
 template <bool RG>
 __global__ void __launch_bounds__(256) tb_ff_kernel(KArgs A) {
@@ -736,7 +744,7 @@ void to_kparams(const TbParams* p, KParams* k) {
 
 struct TbHandle {
   int device, kind, n, block;
-  int reg_rows;  // Tennisbot step kernel with the static contact rows in registers (small batches)
+  int reg_rows;  // Tennisbot step kernel with the static contact rows in registers
   int swing_reg_rows;  // the same for the pipelined SwingRacket step kernel (+2.7 % at 4096 envs; NOT for tb_ff_kernel)
   uint64_t seed, env_id_base;
   TbParams params;
@@ -760,11 +768,27 @@ struct TbHandle {
   uint8_t* d_ff_flag[TB_FF_SLOTS];
   hipEvent_t ev_step[TB_FF_SLOTS], ev_ff[TB_FF_SLOTS];
   int ff_busy[TB_FF_SLOTS], next_slot;
+  // progress marks (tb_mark_record). h_marks: pinned host counters written by tb_mark_kernel -- [k] firings of mark k
+  // (a kernel on the caller's own stream), [TB_MAX_MARKS] fast-forwards finished (a kernel behind every tb_ff_kernel on
+  // its side stream). No extra streams, no extra graph edges: a mark never makes anything wait. What a mark still has
+  // to wait for -- the fast-forwards enqueued before it -- is host arithmetic over these two kinds of counters.
+  unsigned long long* h_marks;
+  unsigned long long snap_ff, snap_marks[TB_MAX_MARKS];  // the counters at tb_mark_begin (nothing of this handle in flight)
+  int marks_on;                               // tb_mark_enable: fast-forwards are followed by their counting kernel
+  long long ff_cap, ff_eager;                 // fast-forwards enqueued: inside the current / latest capture; eagerly since tb_mark_begin
+  long long mark_ff_before[TB_MAX_MARKS];     // recorded inside a capture: ff_cap at that point; eagerly: -1 - ff_eager
 };
 
 namespace {
 
 int words_of(int kind) { return kind == TB_ENV_SWING ? TB_SWING_WORDS : TB_TENNIS_WORDS; }
+
+int ensure_marks(TbHandle* h) {
+  if (h->h_marks) return TB_OK;
+  HIP_TRY(hipHostMalloc((void**)&h->h_marks, sizeof(unsigned long long) * (TB_MAX_MARKS + 1), hipHostMallocDefault));
+  memset(h->h_marks, 0, sizeof(unsigned long long) * (TB_MAX_MARKS + 1));
+  return TB_OK;
+}
 
 // small batches: one wave per workgroup so the waves spread over as many CUs as possible
 // (4096 envs = 64 waves -> 64 CUs); large batches: 256-thread workgroups amortise the LDS staging
@@ -811,6 +835,13 @@ int launch_ff(TbHandle* h, int slot, const KArgs& a, const void* term, const voi
   if (extended_contacts(h->kp)) hipLaunchKernelGGL(tb_ff_kernel<true>, grid, block, 0, h->side[slot], a);
   else hipLaunchKernelGGL(tb_ff_kernel<false>, grid, block, 0, h->side[slot], a);
   HIP_TRY(hipGetLastError());
+  if (h->h_marks && h->marks_on) {  // progress marks: count this fast-forward as finished, in stream order behind it
+    hipLaunchKernelGGL(tb_mark_kernel, dim3(1), dim3(1), 0, h->side[slot], h->h_marks + TB_MAX_MARKS);
+    HIP_TRY(hipGetLastError());
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    HIP_TRY(hipStreamIsCapturing(s, &st));
+    if (st == hipStreamCaptureStatusActive) h->ff_cap++; else h->ff_eager++;
+  }
   HIP_TRY(hipEventRecord(h->ev_ff[slot], h->side[slot]));
   h->ff_busy[slot] = 1; h->last_slot = slot; h->last_term = term; h->last_sub = substeps;
   return TB_OK;
@@ -977,10 +1008,11 @@ int tb_create(const TbParams* params, int env_kind, int n_envs, int device, uint
   if (!h) return fail(TB_E_INVAL, "tb_create: out of host memory");
   h->device = device; h->kind = env_kind; h->n = n_envs; h->seed = seed; h->env_id_base = env_id_base;
   h->params = *params; to_kparams(params, &h->kp); h->block = pick_block(n_envs);
-  {  // measured: +12 % from 4096 to 131072 envs on whole episodes; at 1 M envs +7 % while balls bounce but -3 % in
-     // the contact-free phase, where the kernel runs at 70 % of HBM peak and occupancy counts
+  {  // Tennisbot, measured in the steady state (envs past their first, synchronised episodes): +28 % at 4096 envs,
+     // +8 % at 256 K, +16 % at 1 M, +12 % at 4 M; only the contact-free first episode after a common reset, where the
+     // kernel runs at 70 % of HBM peak and occupancy counts, loses 3 % at 1 M envs
     const char* rr = getenv("TB_TENNIS_REG_ROWS");
-    h->reg_rows = env_kind == TB_ENV_TENNIS && (rr ? atoi(rr) != 0 : n_envs <= 131072);
+    h->reg_rows = env_kind == TB_ENV_TENNIS && (rr ? atoi(rr) != 0 : 1);
     const char* sr = getenv("TB_SWING_REG_ROWS");
     h->swing_reg_rows = env_kind == TB_ENV_SWING && (sr ? atoi(sr) != 0 : n_envs <= 131072);
   }
@@ -1019,6 +1051,7 @@ int tb_destroy(TbHandle* h) {
   }
   for (int k = 0; k < TB_FF_SLOTS; ++k)
     if (h->side[k]) (void)hipStreamDestroy(h->side[k]);
+  if (h->h_marks) (void)hipHostFree(h->h_marks);
   free(h);
   return TB_OK;
 }
@@ -1053,6 +1086,7 @@ int tb_pipeline_sync(TbHandle* h, int host_wait) {
   }
   h->last_slot = -1;
   if (host_wait) {
+    h->ff_cap = 0;
     h->phase_at_capture = h->phase; h->phase_valid_at_capture = h->phase_valid;
     h->n_pending_at_capture = h->n_pending;
     memcpy(h->pending_at_capture, h->pending, sizeof h->pending);
@@ -1081,6 +1115,7 @@ int tb_pipeline_recover(TbHandle* h) {
     HIP_TRY(hipEventCreateWithFlags(&h->ev_ff[k], hipEventDisableTiming));
   }
   h->last_slot = -1; h->last_term = nullptr; h->last_sub = nullptr;
+  h->ff_cap = 0;  // nothing of the abandoned capture will ever run
   return TB_OK;
 }
 
@@ -1101,6 +1136,60 @@ int tb_ff_launch_pending(TbHandle* h, void* stream) {
   if (!h) return fail(TB_E_INVAL, "tb_ff_launch_pending: null handle");
   DeviceGuard g(h->device);
   return launch_pending(h, (hipStream_t)stream);
+}
+
+int tb_mark_record(TbHandle* h, int k, void* stream) {
+  if (!h || k < 0 || k >= TB_MAX_MARKS) return fail(TB_E_INVAL, "tb_mark_record: bad handle or mark index");
+  DeviceGuard g(h->device);
+  hipStream_t s = (hipStream_t)stream;
+  if (!h->marks_on) return fail(TB_E_UNSUPPORTED, "tb_mark_record needs tb_mark_enable(h, 1) before the steps it covers (their fast-forwards must be counted)");
+  if (int rc = launch_pending(h, s)) return rc;  // parked lanes owe rewards to the steps this mark covers
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  HIP_TRY(hipStreamIsCapturing(s, &st));
+  hipLaunchKernelGGL(tb_mark_kernel, dim3(1), dim3(1), 0, s, h->h_marks + k);
+  HIP_TRY(hipGetLastError());
+  h->mark_ff_before[k] = st == hipStreamCaptureStatusActive ? h->ff_cap : -1 - h->ff_eager;
+  return TB_OK;
+}
+
+int tb_mark_enable(TbHandle* h, int on) {
+  if (!h) return fail(TB_E_INVAL, "tb_mark_enable: null handle");
+  if (on) { if (int rc = ensure_marks(h)) return rc; }
+  h->marks_on = on ? 1 : 0;
+  return TB_OK;
+}
+
+int tb_mark_begin(TbHandle* h) {
+  if (!h) return fail(TB_E_INVAL, "tb_mark_begin: null handle");
+  if (int rc = ensure_marks(h)) return rc;
+  h->snap_ff = __atomic_load_n(h->h_marks + TB_MAX_MARKS, __ATOMIC_ACQUIRE);
+  for (int k = 0; k < TB_MAX_MARKS; ++k) h->snap_marks[k] = __atomic_load_n(h->h_marks + k, __ATOMIC_ACQUIRE);
+  h->ff_eager = 0;
+  return TB_OK;
+}
+
+long long tb_mark_count(TbHandle* h, int k) {
+  if (!h || k < 0 || k >= TB_MAX_MARKS) return fail(TB_E_INVAL, "tb_mark_count: bad handle or mark index");
+  if (!h->h_marks) return 0;
+  return (long long)__atomic_load_n(h->h_marks + k, __ATOMIC_ACQUIRE);
+}
+
+int tb_mark_host_wait(TbHandle* h, int k, int timeout_ms) {
+  if (!h || k < 0 || k >= TB_MAX_MARKS || !h->h_marks) return fail(TB_E_INVAL, "tb_mark_host_wait: bad handle, mark index, or no mark recorded yet");
+  // fired once more than at tb_mark_begin, and every fast-forward enqueued before the mark has finished: those of the
+  // graph that holds it (counted at capture time) plus whatever was launched eagerly since (over-waiting at worst)
+  const long long before = h->mark_ff_before[k];
+  const unsigned long long ff_target = h->snap_ff + (unsigned long long)(before >= 0 ? before + h->ff_eager : -1 - before);
+  const unsigned long long count = h->snap_marks[k] + 1;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; ++spins) {
+    if (__atomic_load_n(h->h_marks + k, __ATOMIC_ACQUIRE) >= count && __atomic_load_n(h->h_marks + TB_MAX_MARKS, __ATOMIC_ACQUIRE) >= ff_target)
+      return TB_OK;
+    if ((spins & 1023u) == 1023u &&
+        std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_ms)
+      return fail(TB_E_TIMEOUT, "tb_mark_host_wait: the mark did not fire in time");
+    __builtin_ia32_pause();
+  }
 }
 
 int tb_pipeline_join(TbHandle* h, void* stream) {

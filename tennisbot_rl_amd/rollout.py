@@ -118,6 +118,39 @@ class RolloutBuffer:
         tail = env.capture(lambda: None) if piped else None  # capture() ends with flush(): launch what is parked, join
         return graphs, tail
 
+    def capture_marked(self, env, n_chunks):
+        """The T steps of this buffer as ONE hipGraph with a progress mark (BatchedEnv.mark) after each of
+        n_chunks step-chunks: the graph keeps its shape and speed -- a mark is one tiny kernel in the step
+        stream, nothing forks or joins -- while replay_marked ships chunk c from a side stream as soon as
+        the host sees mark c and the fast-forwards that chunk is owed."""
+        if getattr(self, "_bound", None) is not env:
+            raise ValueError("capture_marked needs bind(env) first")
+        if self.T % n_chunks:
+            raise ValueError("n_steps %d is not divisible into %d chunks" % (self.T, n_chunks))
+        seg = self.T // n_chunks
+
+        def body():
+            for c in range(n_chunks):
+                self.step_range(env, c * seg, (c + 1) * seg)
+                env.mark(c)
+        env.mark_enable(True)
+        try:
+            return env.capture(body)
+        finally:
+            env.mark_enable(False)  # what was captured keeps its counting kernels; later plain captures get none
+
+    def replay_marked(self, graph, env, n_chunks, gather=False, force=False):
+        """replay capture_marked's graph; gather=True (after begin_gather(n_chunks)): the host waits for each
+        chunk's mark in turn and issues that chunk's all-gather on the gather stream while the graph goes on
+        stepping. The wait is on the host on purpose (see tb_mark_host_wait): nothing queued on the device
+        ever waits for the graph."""
+        env.mark_begin()  # nothing of env is in flight here: the caller has joined the previous rollout
+        graph.replay()
+        if gather:
+            for c in range(n_chunks):
+                env.mark_host_wait(c)
+                self.gather_chunk(c, force=force, after_mark=True)
+
     def replay_chunks(self, graphs, tail, gather=False, force=False):
         """replay capture_chunks' graphs in order; gather=True issues each chunk's all-gather
         (begin_gather(len(graphs)) first) as soon as the graph that completes it is enqueued"""
@@ -148,6 +181,8 @@ class RolloutBuffer:
         t = self.torch
         if getattr(self, "_gathered", None) is None or self._gathered.numel() != world * self.nbytes:
             self._gathered = t.empty(world * self.nbytes, dtype=t.uint8, device=self.device)
+        if getattr(self, "rehearsal_total_cycles", 0):  # one-GPU rehearsal: stand in for the time a real exchange takes
+            t.cuda._sleep(int(self.rehearsal_total_cycles))
         t.distributed.all_gather_into_tensor(self._gathered, self.raw, group=group)
         return [self.views(self._gathered[r * self.nbytes: (r + 1) * self.nbytes], self.T) for r in range(world)]
 
@@ -155,7 +190,10 @@ class RolloutBuffer:
     #    from a side stream that waits for (a) the chunk's step kernels and (b) the fast-forwards
     #    that still owe rewards to those steps -- so the stream that steps the envs never stalls:
     #    it neither waits for the fast-forwards nor for the collective. finish_gather() joins.
-    def begin_gather(self, n_chunks, group=None, force=False):
+    def begin_gather(self, n_chunks, group=None, force=False, priority=-1):
+        """priority: of the stream that carries the chunks' collectives. The runtime pools hardware queues per
+        priority, so -1 (high) keeps a collective that runs for a while out of the queues the step kernels and
+        the side-stream fast-forwards use; which setting overlaps best is measured, not assumed (bench.py tries both)."""
         if self.T % n_chunks:
             raise ValueError("n_steps %d is not divisible into %d chunks" % (self.T, n_chunks))
         world, t = self._world(group), self.torch
@@ -165,14 +203,18 @@ class RolloutBuffer:
         if (world > 1 or force) and (getattr(self, "_gath_chunks", None) is None or len(self._gath_chunks) != n_chunks
                                      or self._gath_chunks[0].numel() != world * cb):
             self._gath_chunks = [t.empty(world * cb, dtype=t.uint8, device=self.device) for _ in range(n_chunks)]
-        if self.device.type == "cuda" and getattr(self, "_gather_stream", None) is None:
-            self._gather_stream = t.cuda.Stream(device=self.device)
+        if self.device.type == "cuda":
+            streams = self.__dict__.setdefault("_gather_streams", {})
+            if priority not in streams:
+                streams[priority] = t.cuda.Stream(device=self.device, priority=int(priority))
+            self._gather_stream = streams[priority]
 
-    def gather_chunk(self, c, env=None, force=False):
+    def gather_chunk(self, c, env=None, force=False, after_mark=None):
         """call after the steps [c*S, (c+1)*S) have been enqueued on the current stream. `env`: the
         pipelined BatchedEnv whose fast-forwards write late into this buffer (its flush is put on
         the gather stream, not on the caller's). force: issue the collective for a single rank too
-        (rehearsal of the multi-rank path on one GPU)."""
+        (rehearsal of the multi-rank path on one GPU). after_mark=True: the caller has already waited for the
+        chunk's progress mark on the host (replay_marked): the gather stream starts at once."""
         world, t = self._world(self._group), self.torch
         if world == 1 and not force:
             return
@@ -182,10 +224,13 @@ class RolloutBuffer:
         if gs is None:  # CPU tensors (gloo tests)
             self._works.append(t.distributed.all_gather_into_tensor(self._gath_chunks[c], src, group=self._group, async_op=True))
             return
-        gs.wait_stream(t.cuda.current_stream(self.device))
+        if not after_mark:
+            gs.wait_stream(t.cuda.current_stream(self.device))
         with t.cuda.stream(gs):
             if env is not None and getattr(env, "pipeline", False):
                 env.flush()  # makes `gs` wait for the outstanding fast-forwards
+            if getattr(self, "rehearsal_total_cycles", 0):  # one-GPU rehearsal: stand in for the time a real exchange takes
+                t.cuda._sleep(int(self.rehearsal_total_cycles) // self._chunks)
             self._works.append(t.distributed.all_gather_into_tensor(self._gath_chunks[c], src, group=self._group, async_op=True))
 
     def finish_gather(self):

@@ -80,6 +80,16 @@ def load_library():
     L.tb_pipeline_join.restype = i32
     L.tb_pipeline_recover.argtypes = [vp]
     L.tb_pipeline_recover.restype = i32
+    L.tb_mark_record.argtypes = [vp, i32, vp]
+    L.tb_mark_record.restype = i32
+    L.tb_mark_count.argtypes = [vp, i32]
+    L.tb_mark_count.restype = ctypes.c_longlong
+    L.tb_mark_host_wait.argtypes = [vp, i32, i32]
+    L.tb_mark_host_wait.restype = i32
+    L.tb_mark_begin.argtypes = [vp]
+    L.tb_mark_begin.restype = i32
+    L.tb_mark_enable.argtypes = [vp, i32]
+    L.tb_mark_enable.restype = i32
     L.tb_diag_stream_copy.argtypes = [vp, vp, i32, i32, i32, vp]
     L.tb_diag_stream_copy.restype = i32
     for f in ("tb_create", "tb_destroy", "tb_set_params", "tb_reset", "tb_step", "tb_rollout", "tb_get_state",
@@ -287,6 +297,36 @@ class BatchedEnv:
         """pipelined mode: park finished episodes without launching their fast-forward until
         launch_pending() / flush() (tb_set_defer; for rollouts cut into several graphs)"""
         _check(self.L, self.L.tb_set_defer(self._h, 1 if on else 0), "tb_set_defer")
+
+    def mark(self, k):
+        """progress mark k (tb_mark_record) at the current stream's position: a counter in pinned host memory goes
+        up by one when the stream gets there; together with the library's count of finished fast-forwards it
+        tells the host (mark_host_wait) that every step issued so far, late fast-forward writes included, is
+        final in the caller's buffers. No stream waits for anything. Inside capture() it is a kernel node that
+        every replay fires again."""
+        _check(self.L, self.L.tb_mark_record(self._h, int(k), self._stream()), "tb_mark_record")
+
+    def mark_enable(self, on=True):
+        """count finished fast-forwards from now on (tb_mark_enable): needed before the steps that marks cover
+        are issued or captured; off by default, so plain graphs carry nothing extra"""
+        _check(self.L, self.L.tb_mark_enable(self._h, 1 if on else 0), "tb_mark_enable")
+
+    def mark_begin(self):
+        """snapshot of the mark counters: call right before launching the work that contains the marks, with
+        nothing of this env in flight"""
+        _check(self.L, self.L.tb_mark_begin(self._h), "tb_mark_begin")
+
+    def mark_count(self, k):
+        """how often mark k has fired so far (a host read)"""
+        c = self.L.tb_mark_count(self._h, int(k))
+        if c < 0:
+            _check(self.L, int(c), "tb_mark_count")
+        return int(c)
+
+    def mark_host_wait(self, k, timeout_ms=10000):
+        """spin on the host (GIL released) until mark k has fired since mark_begin() and the fast-forwards
+        enqueued before it have finished"""
+        _check(self.L, self.L.tb_mark_host_wait(self._h, int(k), int(timeout_ms)), "tb_mark_host_wait")
 
     def launch_pending(self):
         """launch the deferred fast-forwards on the side streams, ordered after the current stream"""

@@ -668,6 +668,61 @@ def test_chunk_graphs_with_deferred_fast_forwards_are_bit_identical(torch, n_chu
     assert torch.equal(wa, wb) and torch.equal(da, db)
 
 
+@pytest.mark.parametrize("kind,n_chunks", [(ENV_SWING, 4), (ENV_SWING, 13), (ENV_TENNIS, 8)])
+def test_progress_marks_release_each_chunk_of_one_graph(torch, kind, n_chunks):
+    """RolloutBuffer.capture_marked: the whole rollout is ONE hipGraph; mark c (tb_mark_record: a counter in
+    pinned host memory, bumped by a kernel node behind chunk c's steps; the fast-forwards the chunk is owed are
+    counted the same way) tells the host that chunk c's records are final while the graph is still stepping. A copy issued on a
+    side stream right after the host saw the mark must hold exactly this replay's chunk; issued any earlier it
+    would pick up the previous replay's bytes. Also bit-identical to call-by-call stepping."""
+    from tennisbot_rl_amd.rollout import RolloutBuffer
+    from tennisbot_rl_amd.stepper import BatchedEnv, StepperError
+    n, T = 4096, 104
+    A = 6 if kind == ENV_SWING else 2
+    rng = np.random.default_rng(21)
+    acts = torch.from_numpy(rng.uniform(-1, 1, (T, n, A)).astype(np.float32)).cuda()
+    piped = kind == ENV_SWING
+    ref_env = BatchedEnv(kind, n, device="cuda:0", seed=8, track_terminal_obs=False, pipeline=piped)
+    ref = RolloutBuffer(kind, T, n, "cuda:0").bind(ref_env)
+    env = BatchedEnv(kind, n, device="cuda:0", seed=8, track_terminal_obs=False, pipeline=piped)
+    buf = RolloutBuffer(kind, T, n, "cuda:0").bind(env)
+    ref.actions.copy_(acts); buf.actions.copy_(acts)
+    main, side = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(main):
+        ref_env.reset(); env.reset()
+        for t in range(5):  # chunk boundaries off the episode grid
+            ref.step_into(ref_env, t); buf.step_into(env, t)
+        graph = buf.capture_marked(env, n_chunks)
+        assert [env.mark_count(c) for c in range(n_chunks)] == [0] * n_chunks  # a capture runs nothing
+        shadow = torch.zeros_like(buf.raw)
+        cb = buf.record * (T // n_chunks)
+        early = 0
+        for rnd in range(3):
+            for t in range(T):
+                ref.step_into(ref_env, t)
+            ref_env.flush()
+            main.synchronize()
+            env.mark_begin()
+            graph.replay()
+            early += env.mark_count(n_chunks - 1) == rnd  # the last mark has not fired yet: the host really runs ahead of the graph
+            for c in range(n_chunks):
+                env.mark_host_wait(c)
+                with torch.cuda.stream(side):
+                    shadow[c * cb:(c + 1) * cb].copy_(buf.raw[c * cb:(c + 1) * cb], non_blocking=True)
+            side.synchronize(); main.synchronize()
+            assert [env.mark_count(c) for c in range(n_chunks)] == [rnd + 1] * n_chunks
+            assert torch.equal(ref.raw, buf.raw), "round %d" % rnd
+            bad = [c for c in range(n_chunks) if not torch.equal(shadow[c * cb:(c + 1) * cb], buf.raw[c * cb:(c + 1) * cb])]
+            assert not bad, "round %d: chunks %s were copied before they were final" % (rnd, bad)
+        assert early == 3
+        assert env.counters() == ref_env.counters()
+        env.mark_begin()
+        with pytest.raises(StepperError):  # a mark that nobody fires: the wait gives up
+            env.mark_host_wait(0, timeout_ms=20)
+    env.close(); ref_env.close()
+
+
 def test_deferred_fast_forward_is_launched_by_flush_and_by_slot_reuse(torch):
     """tb_set_defer without anyone calling tb_ff_launch_pending: flush() must deliver, and so must a
     ninth parked episode end that needs the first one's slot back (the handle has 8 slots)"""
