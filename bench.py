@@ -212,7 +212,10 @@ def time_steps(env, buf, steps, warmup, torch, dist_on, tail_gather=True, graph=
     wall, ev_s = run(modes[0])
     GRAPH_STATE["chunks"], GRAPH_STATE["priority"] = modes[0]
     if collective:  # after the clock: every rank must hold every shard, starting with its own
-        GRAPH_STATE["gather_ok"] = bool(buf.check_gathered())
+        ok = torch.tensor([1.0 if buf.check_gathered() else 0.0], device=dev)
+        if dist_on:  # one verdict for all ranks: whatever follows, they do it together
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+        GRAPH_STATE["gather_ok"] = bool(ok.item() > 0.5)
     return wall, ev_s
 
 
