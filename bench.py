@@ -10,8 +10,10 @@ agent steps 1-25 of an episode and 1 + (up to 775) substeps on the 26th (the fas
 of swingracket_env.py:105-141), plus the in-kernel auto-reset. Inputs (state, synthetic
 U(-1,1) actions from PCG64) are resident in HBM before the timed region; every step writes
 obs / reward / done straight into the rank's rollout buffer, and with N > 1 the timed
-region ends with the ONE all-gather of the rollout shards (RCCL over xGMI) that the PPO
-collect boundary needs. Rank 0 prints ONE JSON line.
+region contains the exchange of the rollout shards (RCCL all-gather over xGMI) that the PPO
+collect boundary needs: ONE collective after the K steps, or the same bytes in 8 step-chunks
+overlapped with the steps -- whichever was faster on this node in untimed trials before the
+clock started (--gather-chunks pins a form; the line says which ran). Rank 0 prints ONE JSON line.
 
 Also in that line:
   roofline     -- HBM roofline of the step kernel: algorithmic bytes per launch (267 B/env
