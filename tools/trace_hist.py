@@ -24,6 +24,13 @@ def main(path, needle):
     if len(dur) % 26 == 0:
         ph = dur.reshape(-1, 26).mean(0)
         print("mean duration by launch index mod 26: " + " ".join("%.1f" % x for x in ph))
+    # the last 1040 launches = bench.py's timed replay: start-to-start intervals by position in the 26-step episode
+    # (the launch at index 25 ends the episode and forks the fast-forward)
+    if len(d) >= 1041:
+        st = np.array([x[0] for x in d[-1041:]], dtype=np.float64) / 1e3
+        iv = np.diff(st)
+        print("timed replay: start-to-start us mean %.2f p10 %.2f p50 %.2f p90 %.2f; sum %.0f us" % (iv.mean(), *np.percentile(iv, [10, 50, 90]), iv.sum()))
+        print("mean start-to-start by launch index mod 26 (interval FOLLOWING launch k): " + " ".join("%.1f" % x for x in iv.reshape(-1, 26).mean(0)))
 
 
 if __name__ == "__main__":
