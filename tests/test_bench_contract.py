@@ -37,3 +37,21 @@ def test_bench_json_contract(extra):
     if "cpu_baseline" in d:
         c = d["cpu_baseline"]
         assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["unit"] == "env steps/s"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("steps,expect_tuning", [("208", True), ("200", False)])
+def test_bench_exchange_forms_with_one_rank(steps, expect_tuning):
+    """the multi-rank exchange path rehearsed with a single rank (TB_BENCH_FORCE_COLLECTIVE=1: RCCL is initialised and every
+    collective is issued): with K a whole number of episodes the three exchange forms are tried and one is timed; otherwise
+    the pipelined graph can run only once, nothing is tuned, and the single all-gather is timed"""
+    env = dict(os.environ, TB_BENCH_FORCE_COLLECTIVE="1", TB_BENCH_FAKE_GATHER_US="1000")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", steps, "--warmup", "26", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    w = d["config"]["workload"]
+    assert d["value"] > 0 and "all-gather" in w
+    assert ("exchange form chosen on this node" in w) == expect_tuning
+    if not expect_tuning:
+        assert "1 RCCL all-gather of rollouts at the collect boundary" in w
