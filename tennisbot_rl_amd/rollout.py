@@ -11,7 +11,8 @@ Packed layout per rank: T per-step records, each `obs f32 [N][O] | act f32 [N][A
 done u8 [N]` (every part padded to 16 B), so any range of steps is one contiguous byte range:
 the whole buffer goes out in ONE all-gather, and begin_gather / gather_chunk / finish_gather can
 instead ship it in a few step-chunks from a side stream while later steps are still being computed
-(capture_chunks cuts the rollout into one hipGraph per chunk for that). n_steps defaults
+(capture_marked keeps the rollout ONE hipGraph and tells the host when each chunk is final; capture_chunks,
+the older form, cuts it into one hipGraph per chunk). n_steps defaults
 to the reference's 1100 (train_swing.py:49-50).
 """
 import numpy as np
