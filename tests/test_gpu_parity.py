@@ -435,6 +435,52 @@ def test_scaled_racket_and_spin_extensions(torch):
     env.close()
 
 
+@pytest.mark.parametrize("kind", [ENV_SWING, ENV_TENNIS])
+def test_randomised_engine_parameters_stay_bit_exact(torch, kind):
+    """every engine constant recalled from Bullet is a TbParams field: six random draws of all
+    of them at once -- gravity, damping, restitution / friction / rolling coefficients, ERP, thresholds, masses,
+    inertia, solver cap and tolerance, Magnus and spin extensions, racket scale -- and the HIP path still follows the
+    oracle bit for bit through whole episodes, forced contacts included (the ball is dropped onto the racket)"""
+    rng = np.random.default_rng(1234 + kind)
+    n = 1024
+    for trial in range(6):
+        over = dict(
+            gravity=rng.uniform(3.0, 15.0), lin_damp=rng.uniform(0.0, 0.1), ang_damp=rng.uniform(0.0, 0.1),
+            max_ang_step=rng.uniform(0.3, 1.2), rest_vel_threshold=rng.uniform(0.0, 1.0), erp=rng.uniform(0.02, 0.4),
+            contact_threshold=rng.uniform(2e-4, 3e-3), solver_iters=int(rng.integers(4, 80)), solver_tol=10.0 ** rng.uniform(-7, -4),
+            racket_mass=rng.uniform(1.0, 8.0), racket_inertia=tuple(rng.uniform(0.02, 0.3, 3)), ball_mass=rng.uniform(0.03, 0.2),
+            ball_inertia=10.0 ** rng.uniform(-5, -3), rest_racket=rng.uniform(0.0, 1.0), rest_court=rng.uniform(0.0, 1.0),
+            rest_goal=rng.uniform(0.0, 0.9), fric_racket=rng.uniform(0.0, 0.8), fric_court=rng.uniform(0.0, 0.8), fric_goal=rng.uniform(0.0, 0.8),
+            magnus_k=rng.choice([0.0, 1e-4, 5e-4]), ball_spin_max=rng.choice([0.0, 50.0, 200.0]))
+        if trial % 2:
+            over.update(roll_racket=rng.uniform(0, 2e-3), roll_court=rng.uniform(0, 2e-3), roll_goal=rng.uniform(0, 2e-3))
+        scale = float(rng.uniform(1.0, 3.0)) if kind == ENV_TENNIS else 1.0
+        env, ref = make_pair(torch, kind, n, seed=100 + trial, racket_scale=scale, **over)
+        ref.L.tbo_set_threads(ref.h, 8)
+        what = "params trial %d kind %d" % (trial, kind)
+        run_lockstep(torch, env, ref, 60 if kind == ENV_SWING else 200, rng, what, check_state_every=20)
+        # ... and from states in which the ball sits on the racket face (a solve on the first step)
+        w, d = env.get_state_words()
+        w = w.cpu().numpy().copy().view(np.uint32)
+        f = w.view(np.float32)
+        rp = f[0:3].copy()  # racket COM rows
+        f[13:16] = rp + np.array([[-(float(env.params.racket_half_thick) * scale + float(env.params.ball_radius))], [0.0], [0.0]], np.float32)
+        f[16:19] = np.array([[4.0], [0.5], [-0.5]], np.float32)
+        dn = d.cpu().numpy()
+        env.set_state_words(w.view(np.int32), dn)
+        ref.set_state_words(w, dn)
+        for t in range(12):
+            a = rng.uniform(-1, 1, (n, env.act_dim)).astype(np.float32)
+            obs, rew, done = env.step(torch.from_numpy(a).cuda())
+            o2, r2, d2, s2 = ref.step(a)
+            same(obs.cpu().numpy(), o2, what + " contact obs %d" % t)
+            same(rew.cpu().numpy(), r2, what + " contact reward %d" % t)
+            same(done.cpu().numpy(), d2, what + " contact done %d" % t)
+        compare_state(env, ref, what + " after contacts")
+        assert env.counters()["racket_ball_contact_substeps"] > 0
+        env.close()
+
+
 def test_float32_drift_vs_float64_truth(torch):
     """stated float32 tolerance: over one Swing episode without contacts the float32 state stays
     within 2e-4 (abs, metres / m/s) of the float64 oracle; done and step counters agree wherever
