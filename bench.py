@@ -94,7 +94,7 @@ def fill_actions(buf_actions, seed, torch):
         buf_actions[t0:t0 + n].copy_(a[:n])
 
 
-GRAPH_STATE = {"used": True, "form": "forked", "chunks": 1, "priority": 0, "gather_ok": None, "tuning": None}
+GRAPH_STATE = {"used": True, "chunks": 1, "priority": 0, "gather_ok": None, "tuning": None}
 
 
 def time_steps(env, buf, steps, warmup, torch, dist_on, tail_gather=True, graph=False, gather_chunks=0, force_collective=False):
@@ -122,21 +122,15 @@ def time_steps(env, buf, steps, warmup, torch, dist_on, tail_gather=True, graph=
     # A pipelined SwingRacket graph bakes in which of its steps end an episode (and fork a fast-forward): it can be
     # replayed again and again only if K is a whole number of 26-step episodes. Otherwise it runs exactly once --
     # the timed run -- and nothing is tuned.
-    piped = bool(getattr(env, "pipeline", False))
-    repeatable = not piped or steps % 26 == 0
-    # hosted fast-forwards (RolloutBuffer.capture_hosted): the rollout graph stays a LINEAR chain, the host launches the
-    # fast-forwards while it runs. Needs whole episodes from the first step on; tried next to the forked graph, the faster is timed.
-    hostable = piped and graph and repeatable and steps == T and env.num_envs <= 131072 and env.episode_phase() == 0 and os.environ.get("TB_BENCH_NO_HOSTED") != "1"
+    repeatable = not getattr(env, "pipeline", False) or steps % 26 == 0
     if gather_chunks == 0:
-        modes = [("forked", 1, 0)] + ([("forked", 8, -1), ("forked", 8, 0)] if (usable(8) and repeatable) else [])
-        if hostable:
-            modes += [("hosted", 1, 0)] + ([("hosted", 8, -1)] if (usable(8) and (steps // 8) % 26 == 0) else [])
+        modes = [(1, 0)] + ([(8, -1), (8, 0)] if (usable(8) and repeatable) else [])
     elif usable(gather_chunks):
-        modes = [("forked", gather_chunks, -1 if piped else 0)]
+        modes = [(gather_chunks, -1 if getattr(env, "pipeline", False) else 0)]
     else:
-        modes = [("forked", 1, 0)]
+        modes = [(1, 0)]
 
-    plain, marked, hosted = None, {}, None
+    plain, marked = None, {}
     if graph:
         try:
             def body():
@@ -144,28 +138,23 @@ def time_steps(env, buf, steps, warmup, torch, dist_on, tail_gather=True, graph=
                     buf.step_into(env, t % T)
             # a capture advances the library's episode-phase hint by K steps without running them: replay each
             # graph once before anything else is captured or stepped
-            if any(f == "forked" and c == 1 for f, c, _ in modes):
+            if any(c == 1 for c, _ in modes):
                 plain = env.capture(body)
                 if repeatable:
                     plain.replay()
                     torch.cuda.synchronize(dev)
-            for c in sorted({c for f, c, _ in modes if f == "forked" and c > 1}):
+            for c in sorted({c for c, _ in modes if c > 1}):
                 marked[c] = buf.capture_marked(env, c)
                 if repeatable:
                     marked[c].replay()
                     torch.cuda.synchronize(dev)
-            if any(f == "hosted" for f, _, _ in modes):
-                hosted = buf.capture_hosted(env)
-                buf.replay_hosted(hosted, env)
-                torch.cuda.synchronize(dev)
         except Exception as exc:  # fall back to host-issued launches and say so
             print("hipGraph capture failed (%s: %s); issuing the steps from the host" % (type(exc).__name__, exc), file=sys.stderr)
-            plain, marked, hosted, graph = None, {}, None, False
-            modes = [m for m in modes if m[0] == "forked"][:1] or [("forked", 1, 0)]
+            plain, marked, graph = None, {}, False
     GRAPH_STATE["used"] = bool(graph)
 
     def run(mode):
-        form, chunks, prio = mode
+        chunks, prio = mode
         seg = steps // chunks
         if chunks > 1:
             buf.begin_gather(chunks, force=force_collective, priority=prio)
@@ -175,9 +164,7 @@ def time_steps(env, buf, steps, warmup, torch, dist_on, tail_gather=True, graph=
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record(torch.cuda.current_stream(dev))  # the stream the step kernel is launched on
-        if form == "hosted":
-            buf.replay_hosted(hosted, env, gather=chunks > 1, n_chunks=chunks, force=force_collective)
-        elif chunks > 1 and graph:
+        if chunks > 1 and graph:
             buf.replay_marked(marked[chunks], env, chunks, gather=True, force=force_collective)
         elif chunks > 1:  # host-issued variant (--no-graph, or capture failed): the side stream waits by event
             for c in range(chunks):
@@ -200,12 +187,8 @@ def time_steps(env, buf, steps, warmup, torch, dist_on, tail_gather=True, graph=
         torch.cuda.synchronize(dev)
         return time.perf_counter() - t0, ev0.elapsed_time(ev1) * 1e-3
 
-    def label(mode):
-        form, chunks, prio = mode
-        return "%s graph, %d chunk%s%s" % (form, chunks, "" if chunks == 1 else "s", "" if chunks == 1 else ", stream priority %d" % prio)
-
     if collective and not (repeatable or not graph):  # the graph runs once: warm the collective up without it
-        _, chunks, prio = modes[0]
+        chunks, prio = modes[0]
         if chunks > 1:
             buf.begin_gather(chunks, force=force_collective, priority=prio)
             for c in range(chunks):
@@ -214,33 +197,22 @@ def time_steps(env, buf, steps, warmup, torch, dist_on, tail_gather=True, graph=
         else:
             buf.all_gather(force=force_collective)
         torch.cuda.synchronize(dev)
-    elif collective or len(modes) > 1:
-        # RCCL's first use of each collective shape (channels, buffers) stays outside the timed region; so does the choice
-        # between the forms. A hosted run in which the host fell behind (the library counts it) is out.
+    elif collective:  # RCCL's first use of each collective shape (channels, buffers) stays outside the timed region; so does the tuning
         trial = []
         for mode in modes:
             run(mode)
             best = min(run(mode)[0] for _ in range(2)) if len(modes) > 1 else 0.0
-            if mode[0] == "hosted" and env.counters()["nonfinite_states"]:
-                best = float("inf")
             trial.append(best)
         if len(modes) > 1:
             tt = torch.tensor(trial, dtype=torch.float64, device=dev)
             if dist_on:
                 torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             trial = [float(x) for x in tt.tolist()]
-            GRAPH_STATE["tuning"] = {label(m): (round(x * 1e3, 3) if x < 1e9 else None) for m, x in zip(modes, trial)}
+            GRAPH_STATE["tuning"] = {"%d chunk%s, stream priority %d" % (c, "" if c == 1 else "s", p): round(x * 1e3, 3) for (c, p), x in zip(modes, trial)}
             modes = [modes[trial.index(min(trial))]]
     env.counters_reset()  # from here on the counters hold the timed steps only
     wall, ev_s = run(modes[0])
-    if modes[0][0] == "hosted" and env.counters()["nonfinite_states"] and plain is not None:
-        # the host fell behind during the timed run of all runs: the result is wrong and says so; time the forked graph instead
-        print("hosted fast-forwards: the host fell behind; timing the forked graph instead", file=sys.stderr)
-        modes = [("forked", 1, 0)]
-        env.flush()  # the envs themselves are unharmed (only late rewards were lost) and still at the graph's phase
-        env.counters_reset()
-        wall, ev_s = run(modes[0])
-    GRAPH_STATE["form"], GRAPH_STATE["chunks"], GRAPH_STATE["priority"] = modes[0]
+    GRAPH_STATE["chunks"], GRAPH_STATE["priority"] = modes[0]
     if collective:  # after the clock: every rank must hold every shard, starting with its own
         ok = torch.tensor([1.0 if buf.check_gathered() else 0.0], device=dev)
         if dist_on:  # one verdict for all ranks: whatever follows, they do it together
@@ -388,9 +360,8 @@ def main():
         gather_note = (", 1 RCCL all-gather of rollouts at the collect boundary" if GRAPH_STATE["chunks"] == 1 else
                        ", rollouts all-gathered (RCCL) in %d step-chunks, each overlapped with the next chunk's steps%s" % (
                            GRAPH_STATE["chunks"], " (one hipGraph, progress marks watched by the host)" if GRAPH_STATE["used"] else " (steps enqueued by tb_step_sequence)"))
-    if GRAPH_STATE["tuning"]:
-        gather_note += "; form chosen on this node before the clock started, ms per K steps%s: %s" % (
-            " + exchange" if (dist_on or force_collective) else "", json.dumps(GRAPH_STATE["tuning"]))
+        if GRAPH_STATE["tuning"]:
+            gather_note += "; exchange form chosen on this node before the clock started, ms per K steps + exchange: %s" % json.dumps(GRAPH_STATE["tuning"])
     c = env.counters()
     if c["nonfinite_states"]:
         sys.exit("%d env states went non-finite or left the lockstep the pipelined kernels rely on: result discarded" % c["nonfinite_states"])
@@ -424,8 +395,7 @@ def main():
                 ("racket<->ball contact off (configs[1] bench mode)" if args.contact_off else "full contact semantics") + (" + racket<->court contact" if args.racket_ground else "")
                 + (" + rolling-friction rows" if args.rolling_friction else "")
                 + (" + Magnus k=%g, spin<=%g rad/s (extension, not in the reference)" % (args.magnus, args.spin_max) if (args.magnus or args.spin_max) else ""),
-                T_buf, ", fast-forward pipelined on side streams" if pipeline else "",
-                (", K steps replayed as one LINEAR hipGraph, fast-forwards launched by the host while it runs" if GRAPH_STATE["form"] == "hosted" else ", K steps replayed as one hipGraph") if (use_graph and GRAPH_STATE["used"]) else "",
+                T_buf, ", fast-forward pipelined on side streams" if pipeline else "", ", K steps replayed as one hipGraph" if (use_graph and GRAPH_STATE["used"]) else "",
                 gather_note),
                 "envs_per_gpu": N, "global_envs": world * N, "parallelism": "env-sharded x%d" % world},
             "substeps_per_s": timed_substeps / wall_max,

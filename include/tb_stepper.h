@@ -297,29 +297,6 @@ int tb_set_defer(TbHandle *h, int on);
 int tb_ff_launch_pending(TbHandle *h, void *stream);
 int tb_pipeline_join(TbHandle *h, void *stream);
 /*
- * Hosted fast-forwards (pipelined SwingRacket-v0, episodes in lockstep; for rollouts replayed as ONE hipGraph).
- * A hipGraph with branches replays markedly slower PER NODE than a linear chain in this runtime (6.6 vs 4.9 us per
- * step at 4096 envs), and the side-stream fast-forwards are the only branches of a rollout graph; a linear graph also
- * returns from its launch call within ~0.4 ms per 1000 nodes, so the host is free while it runs. After
- * tb_set_hosted(h, 1) the one-step launches that are CAPTURED fork nothing: an episode end parks its lanes as always,
- * and every workgroup of that launch then bumps a counter in pinned host memory (after a system-scope fence); the
- * fast-forwards of the capture are kept as jobs (tb_ff_jobs), in episode order. Per replay:
- *   tb_ff_arm(h, stream)            snapshot the counter; `stream` = the one the graph is launched on, idle w.r.t. this
- *                                   handle (the first call also finds the side streams that run concurrently with it)
- *   <launch the graph on stream>
- *   tb_ff_service(h, upto, timeout) the HOST waits for each parking step in turn and launches its fast-forward, an
- *                                   ordinary kernel on a side stream; upto < 0: all jobs, else jobs below `upto`
- *   tb_flush(h, stream)             as always: `stream` waits for the fast-forwards
- * Nothing on the device ever waits for the host. What stream order guaranteed before -- a slot is not parked into while
- * its previous fast-forward still reads it (16 slots: the host has ~2 ms) -- is CHECKED here instead: a violation is
- * counted in the lockstep / non-finite counter (tb_counters index 7), never silent. Results are bit-identical.
- */
-int tb_episode_phase(TbHandle *h); /* SwingRacket, every env reset together: agent steps into the current episode (0..25); else -1 */
-int tb_set_hosted(TbHandle *h, int on);
-int tb_ff_jobs(TbHandle *h);
-int tb_ff_arm(TbHandle *h, void *stream);
-int tb_ff_service(TbHandle *h, int upto, int timeout_ms, void *stream);
-/*
  * Progress marks (for callers that ship a rollout in chunks while ONE hipGraph is still producing it). A mark
  * tells the HOST that everything tb_step was asked to do before it is final in the caller's buffers -- the steps
  * themselves AND the late fast-forward writes they are still owed -- without making any stream wait for

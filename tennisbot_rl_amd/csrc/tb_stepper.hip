@@ -49,7 +49,6 @@ struct KArgs {
   // the env's pre-loop state in a slot and resets the env; tb_ff_kernel finishes it on a side stream
   uint32_t* ff_words;     // [W][n] slot
   uint8_t* ff_flag;       // [n]: 1 = parked, waiting for tb_ff_kernel
-  unsigned long long* host_parked;  // hosted fast-forwards (tb_set_hosted): pinned host counter of launches that have started
   int defer;
   // fused policy inference (tb_policy_step): actions are computed in-kernel from pol_obs
   const float* pol_weights;  // packed SB3 MlpPolicy towers, see PolicyNet
@@ -345,13 +344,6 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
   const float4* __restrict__ w_hull = SEP ? k_hull : A.hull;
   const int w_n = SEP ? k_n : A.n, w_nhull = SEP ? k_nhull : A.P.n_hull;
   const bool live = i < w_n;
-  if constexpr (KIND == TB_ENV_SWING && LEAN && !POLICY) {
-    // hosted fast-forwards: the launch that follows a parking one reports that it has STARTED -- everything the launches before
-    // it wrote, the parked episode included, is complete and released by then. One thread, one write over the bus (a launch that
-    // reports ends ~2 us later than one that does not: only these 1-in-26 do).
-    if (A.host_parked && blockIdx.x == 0 && threadIdx.x == 0)
-      __hip_atomic_fetch_add(A.host_parked, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
   EnvRegs e;
 #ifdef TB_DIAG_STAMPS
   const unsigned long long t_entry = stamp_now();
@@ -415,7 +407,6 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
           // done = 1 is known now; reward, terminal obs and substep count of this step are written
           // later by tb_ff_kernel from the parked state. The env itself restarts immediately.
           if (A.ff_words) {
-            if (A.ff_flag[i] != 0) cnt[7]++;  // the slot's previous fast-forward has not finished (stream order rules this out, except in hosted mode): reported, never silent
             store_env<TB_ENV_SWING>(A.ff_words, A.ff_flag, A.n, i, e, true);
             A.ff_flag[i] = 1;
           } else {
@@ -749,8 +740,7 @@ void to_kparams(const TbParams* p, KParams* k) {
 
 }  // namespace
 
-#define TB_FF_SLOTS 16  // parked-state buffers + side streams; h->n_slots in use: 8 (~2.5 fast-forwards are in flight in steady state, up to 3 more are
-                        // deferred across a graph boundary) or all 16 (hosted fast-forwards: slack for the host that launches them)
+#define TB_FF_SLOTS 8  // parked-state buffers + side streams: ~2.5 fast-forwards are in flight in steady state, up to 3 more are deferred across a graph boundary
 
 struct TbHandle {
   int device, kind, n, block;
@@ -770,19 +760,14 @@ struct TbHandle {
   int phase_at_capture, phase_valid_at_capture;  // snapshot taken by tb_pipeline_sync(h, 1), see tb_pipeline_recover
   // deferred fast-forwards (tb_set_defer): parked, not yet launched
   int defer, n_pending, n_pending_at_capture;
-  struct Pending { KArgs a; int slot; const void *term, *sub; int after; } pending[TB_FF_SLOTS], pending_at_capture[TB_FF_SLOTS];
+  struct Pending { KArgs a; int slot; const void *term, *sub; } pending[TB_FF_SLOTS], pending_at_capture[TB_FF_SLOTS];
   hipStream_t side[TB_FF_SLOTS];  // one stream per slot: consecutive fast-forwards overlap each other too
   const void *last_term, *last_sub;  // shared late-written buffers force ordering between fast-forwards
   int last_slot;
   uint32_t* d_ff_words[TB_FF_SLOTS];
   uint8_t* d_ff_flag[TB_FF_SLOTS];
   hipEvent_t ev_step[TB_FF_SLOTS], ev_ff[TB_FF_SLOTS];
-  int ff_busy[TB_FF_SLOTS], next_slot, n_slots, slots_alloc;
-  // hosted fast-forwards (tb_set_hosted): captured steps fork nothing; the fast-forwards of the capture are kept as jobs and
-  // launched by the host (tb_ff_service) when the parking step's workgroups have reported in
-  int hosted; Pending* jobs; int n_jobs, cap_jobs, next_job;
-  unsigned long long* h_parked; unsigned long long parked_base; int n_signals, signal_next;
-  hipStream_t probed_main; int n_good, good[TB_FF_SLOTS];  // side streams that do not share a hardware queue with the step stream
+  int ff_busy[TB_FF_SLOTS], next_slot;
   // progress marks (tb_mark_record). h_marks: pinned host counters written by tb_mark_kernel -- [k] firings of mark k
   // (a kernel on the caller's own stream), [TB_MAX_MARKS] fast-forwards finished (a kernel behind every tb_ff_kernel on
   // its side stream). No extra streams, no extra graph edges: a mark never makes anything wait. What a mark still has
@@ -878,13 +863,6 @@ int flush_all(TbHandle* h, hipStream_t s) {
   return wait_side(h, s);
 }
 
-// hosted fast-forwards apply to CAPTURED one-step launches of a pipelined SwingRacket env in lockstep
-bool hosted_capture(TbHandle* h, hipStream_t s, bool policy) {
-  if (!h->hosted || !h->phase_valid || policy || h->defer || extended_contacts(h->kp)) return false;
-  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-  return hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusActive;
-}
-
 struct PolicyIO {  // non-null weights = fused policy step
   const float* weights; const float* obs_in; float* actions; float* raw; float* logp; float* value;
   unsigned long long seed; int deterministic;
@@ -911,18 +889,14 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
   const bool piped = (T == 1 || lean_multi) && h->pipeline && h->kind == TB_ENV_SWING && (h->kp.flags & TB_F_AUTO_RESET);
   const bool may_park = piped && (T == 1 ? (!h->phase_valid || h->phase == 25) : h->phase + T - 1 == 25);
   int slot = -1;
-  bool park_hosted = false;
   if (may_park) {
     slot = h->next_slot;
-    h->next_slot = (slot + 1) % h->n_slots;
+    h->next_slot = (slot + 1) % TB_FF_SLOTS;
     for (int i = 0; i < h->n_pending; ++i)  // the slot still holds lanes whose fast-forward was deferred: it cannot wait any longer
       if (h->pending[i].slot == slot) { if (int rc = launch_pending(h, s)) return rc; break; }
-    const bool hosted = hosted_capture(h, s, pol != nullptr);
-    if (h->ff_busy[slot] && !hosted) HIP_TRY(hipStreamWaitEvent(s, h->ev_ff[slot], 0));  // slot still in use by an older fast-forward
+    if (h->ff_busy[slot]) HIP_TRY(hipStreamWaitEvent(s, h->ev_ff[slot], 0));  // slot still in use by an older fast-forward
     a.defer = 1; a.ff_words = h->d_ff_words[slot]; a.ff_flag = h->d_ff_flag[slot];
-    park_hosted = hosted;
   }
-  if (h->signal_next && piped && T == 1 && hosted_capture(h, s, pol != nullptr)) { a.host_parked = h->h_parked; h->n_signals++; h->signal_next = 0; }
   const bool rg = extended_contacts(h->kp);  // selects the instantiation that contains racket<->court contact and rolling friction
   (void)hipGetLastError();  // the check below is about THIS launch, not about whatever another library left behind
 #define TB_LAUNCH_STEP(KIND, LEAN, MULTI)                                                                      \
@@ -959,18 +933,7 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
   HIP_TRY(hipGetLastError());
   if (may_park) {
     if (T > 1) a.reward = reward + (size_t)(T - 1) * h->n;  // the fast-forward owes its reward to the step that parked: the last one
-    if (park_hosted) {  // hosted: nothing forks; the job is launched by tb_ff_service once the host has seen the NEXT launch start
-      if (h->n_jobs == h->cap_jobs) {
-        const int cap = h->cap_jobs ? 2 * h->cap_jobs : 64;
-        void* q = realloc(h->jobs, sizeof(TbHandle::Pending) * (size_t)cap);
-        if (!q) return fail(TB_E_INVAL, "out of host memory");
-        h->jobs = (TbHandle::Pending*)q; h->cap_jobs = cap;
-      }
-      TbHandle::Pending& p = h->jobs[h->n_jobs++];
-      p.a = a; p.a.host_parked = nullptr; p.slot = slot; p.term = term; p.sub = substeps;
-      p.after = 0;
-      h->signal_next = 1;  // the next captured launch tells the host that this one is through
-    } else if (h->defer) {  // tb_set_defer: park now, finish when the caller says so (tb_ff_launch_pending / tb_flush)
+    if (h->defer) {  // tb_set_defer: park now, finish when the caller says so (tb_ff_launch_pending / tb_flush)
       TbHandle::Pending& p = h->pending[h->n_pending++];  // (a slot is never parked into twice: n_pending <= TB_FF_SLOTS)
       p.a = a; p.slot = slot; p.term = term; p.sub = substeps;
     } else if (int rc = launch_ff(h, slot, a, term, substeps, s)) {
@@ -994,7 +957,7 @@ int launch_policy_rollout(TbHandle* h, int T, const PolicyIO& pol, float* obs, f
   int slot = -1;
   if (may_park) {
     slot = h->next_slot;
-    h->next_slot = (slot + 1) % h->n_slots;
+    h->next_slot = (slot + 1) % TB_FF_SLOTS;
     for (int i = 0; i < h->n_pending; ++i)
       if (h->pending[i].slot == slot) { if (int rc = launch_pending(h, s)) return rc; break; }
     if (h->ff_busy[slot]) HIP_TRY(hipStreamWaitEvent(s, h->ev_ff[slot], 0));
@@ -1052,7 +1015,6 @@ int tb_create(const TbParams* params, int env_kind, int n_envs, int device, uint
     h->reg_rows = env_kind == TB_ENV_TENNIS && (rr ? atoi(rr) != 0 : 1);
     const char* sr = getenv("TB_SWING_REG_ROWS");
     h->swing_reg_rows = env_kind == TB_ENV_SWING && (sr ? atoi(sr) != 0 : n_envs <= 131072);
-    h->n_slots = 8;
   }
   const int nw = words_of(env_kind);
   hipError_t err;
@@ -1090,8 +1052,6 @@ int tb_destroy(TbHandle* h) {
   for (int k = 0; k < TB_FF_SLOTS; ++k)
     if (h->side[k]) (void)hipStreamDestroy(h->side[k]);
   if (h->h_marks) (void)hipHostFree(h->h_marks);
-  if (h->h_parked) (void)hipHostFree(h->h_parked);
-  free(h->jobs);
   free(h);
   return TB_OK;
 }
@@ -1103,8 +1063,7 @@ int tb_set_pipeline(TbHandle* h, int enable) {
     if (h->kind != TB_ENV_SWING) return fail(TB_E_UNSUPPORTED, "tb_set_pipeline: only SwingRacket-v0 has a fast-forward to overlap");
     const size_t wb = sizeof(uint32_t) * (size_t)TB_SWING_WORDS * h->n;
     h->last_slot = -1;
-    h->slots_alloc = h->n <= 131072 ? TB_FF_SLOTS : 8;  // hosted fast-forwards (small batches only) use all 16
-    for (int k = 0; k < h->slots_alloc; ++k) {
+    for (int k = 0; k < TB_FF_SLOTS; ++k) {
       HIP_TRY(hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
       HIP_TRY(hipMalloc((void**)&h->d_ff_words[k], wb));
       HIP_TRY(hipMalloc((void**)&h->d_ff_flag[k], (size_t)h->n));
@@ -1232,102 +1191,6 @@ int tb_mark_host_wait(TbHandle* h, int k, int timeout_ms) {
     __builtin_ia32_pause();
   }
 }
-
-// one probe per step stream: which of the side streams run concurrently with it? (the runtime maps streams onto a few hardware
-// queues; a fast-forward in the step stream's own queue would wait behind every step kernel already enqueued there)
-__global__ void tb_probe_spin_kernel(unsigned long long ticks) {
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
-}
-__global__ void tb_probe_nop_kernel() {}
-
-int probe_side_streams(TbHandle* h, hipStream_t main) {
-  h->n_good = 0;
-  hipEvent_t ev;
-  HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-  HIP_TRY(hipStreamSynchronize(main));
-  for (int k = 0; k < h->n_slots; ++k) {
-    HIP_TRY(hipStreamSynchronize(h->side[k]));
-    hipLaunchKernelGGL(tb_probe_spin_kernel, dim3(1), dim3(1), 0, main, 40000ull);  // 400 us of 100 MHz ticks
-    hipLaunchKernelGGL(tb_probe_nop_kernel, dim3(1), dim3(1), 0, h->side[k]);
-    HIP_TRY(hipEventRecord(ev, h->side[k]));
-    const auto t0 = std::chrono::steady_clock::now();
-    bool done = false;
-    while (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() < 200) {
-      if (hipEventQuery(ev) == hipSuccess) { done = true; break; }
-    }
-    (void)hipGetLastError();
-    HIP_TRY(hipStreamSynchronize(main));
-    HIP_TRY(hipStreamSynchronize(h->side[k]));
-    if (done) h->good[h->n_good++] = k;
-  }
-  (void)hipEventDestroy(ev);
-  h->probed_main = main;
-  if (h->n_good < 3) return fail(TB_E_UNSUPPORTED, "hosted fast-forwards: fewer than 3 side streams run concurrently with the step stream");
-  return TB_OK;
-}
-
-int tb_episode_phase(TbHandle* h) {
-  if (!h) return fail(TB_E_INVAL, "tb_episode_phase: null handle");
-  return (h->kind == TB_ENV_SWING && h->phase_valid) ? h->phase : -1;
-}
-
-int tb_set_hosted(TbHandle* h, int on) {
-  if (!h) return fail(TB_E_INVAL, "tb_set_hosted: null handle");
-  if (on && !(h->pipeline && h->kind == TB_ENV_SWING && h->slots_alloc == TB_FF_SLOTS))
-    return fail(TB_E_UNSUPPORTED, "tb_set_hosted needs a pipelined SwingRacket-v0 handle of at most 131072 envs");
-  DeviceGuard g(h->device);
-  if (on && !h->h_parked) {
-    HIP_TRY(hipHostMalloc((void**)&h->h_parked, sizeof(unsigned long long), hipHostMallocDefault));
-    *h->h_parked = 0ull;
-  }
-  h->hosted = on ? 1 : 0;
-  if (on) { h->n_jobs = 0; h->n_signals = 0; h->signal_next = 0; h->n_slots = TB_FF_SLOTS; }  // the jobs of the capture that follows; all 16 slots
-  else { h->n_slots = 8; h->next_slot %= 8; }
-  return TB_OK;
-}
-
-int tb_ff_arm(TbHandle* h, void* stream) {
-  if (!h || !h->h_parked) return fail(TB_E_INVAL, "tb_ff_arm: null handle or tb_set_hosted never called");
-  DeviceGuard g(h->device);
-  if (h->probed_main != (hipStream_t)stream || !h->n_good) { if (int rc = probe_side_streams(h, (hipStream_t)stream)) return rc; }
-  h->parked_base = __atomic_load_n(h->h_parked, __ATOMIC_ACQUIRE);
-  h->next_job = 0;
-  return TB_OK;
-}
-
-// launch the fast-forwards of jobs [next_job, upto) of the last hosted capture, each as soon as all workgroups of its parking
-// step have reported in; upto < 0: all of them. The graph must have been launched after tb_ff_arm.
-int tb_ff_service(TbHandle* h, int upto, int timeout_ms, void* stream) {
-  if (!h || !h->h_parked) return fail(TB_E_INVAL, "tb_ff_service: null handle or tb_set_hosted never called");
-  DeviceGuard g(h->device);
-  if (upto < 0 || upto > h->n_jobs) upto = h->n_jobs;
-  dim3 grid((unsigned)((h->n + h->block - 1) / h->block)), block((unsigned)h->block);
-  for (; h->next_job < upto; ++h->next_job) {
-    const int j = h->next_job;
-    const TbHandle::Pending& p = h->jobs[j];
-    if (j >= h->n_signals) {
-      HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // parked by the last launch of the graph: nothing starts after it
-    } else {
-      const unsigned long long want = h->parked_base + (unsigned long long)j + 1ull;  // the launch after the j-th parking one has started
-      const auto t0 = std::chrono::steady_clock::now();
-      for (unsigned spins = 0; __atomic_load_n(h->h_parked, __ATOMIC_ACQUIRE) < want; ++spins) {
-        if ((spins & 1023u) == 1023u &&
-            std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_ms)
-          return fail(TB_E_TIMEOUT, "tb_ff_service: the rollout graph did not get past a parking step in time");
-        __builtin_ia32_pause();
-      }
-    }
-    hipStream_t side = h->side[h->good[j % h->n_good]];
-    hipLaunchKernelGGL(tb_ff_kernel<false>, grid, block, 0, side, p.a);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(h->ev_ff[p.slot], side));
-    h->ff_busy[p.slot] = 1;
-  }
-  return TB_OK;
-}
-
-int tb_ff_jobs(TbHandle* h) { return h ? h->n_jobs : TB_E_INVAL; }
 
 int tb_pipeline_join(TbHandle* h, void* stream) {
   if (!h) return fail(TB_E_INVAL, "tb_pipeline_join: null handle");

@@ -119,36 +119,6 @@ class RolloutBuffer:
         tail = env.capture(lambda: None) if piped else None  # capture() ends with flush(): launch what is parked, join
         return graphs, tail
 
-    def capture_hosted(self, env):
-        """The T steps of this buffer as ONE LINEAR hipGraph (pipelined SwingRacket env, episodes in lockstep): episode ends
-        park their lanes and report to the host, nothing forks; replay_hosted launches the fast-forwards from the host
-        while the graph runs. A linear graph replays at 4.9 us per step where the forked one needs 6.6."""
-        if getattr(self, "_bound", None) is not env:
-            raise ValueError("capture_hosted needs bind(env) first")
-        env.set_hosted(True)
-        try:
-            g = env.capture(lambda: self.step_range(env, 0, self.T), join_only=True)
-        finally:
-            env.set_hosted(False)
-        self._hosted_jobs = env.ff_jobs()
-        return g
-
-    def replay_hosted(self, graph, env, gather=False, n_chunks=1, force=False):
-        """replay capture_hosted's graph: arm, launch, serve the fast-forwards from the host, join. gather=True (after
-        begin_gather(n_chunks); chunks must end where episodes end): the host, which follows the graph's progress anyway,
-        queues chunk c's all-gather on the gather stream as soon as the graph is past the chunk and its fast-forwards are
-        launched (the gather stream waits for those by their events)."""
-        env.ff_arm()
-        graph.replay()
-        if gather:
-            per = self._hosted_jobs // n_chunks  # episodes (= jobs) per chunk
-            for c in range(n_chunks):
-                env.ff_service(upto=(c + 1) * per if c + 1 < n_chunks else -1)
-                self.gather_chunk(c, env=env, force=force, after_mark=True)
-        else:
-            env.ff_service()
-        env.flush()
-
     def capture_marked(self, env, n_chunks):
         """The T steps of this buffer as ONE hipGraph with a progress mark (BatchedEnv.mark) after each of
         n_chunks step-chunks: the graph keeps its shape and speed -- a mark is one tiny kernel in the step

@@ -86,16 +86,6 @@ def load_library():
     L.tb_mark_count.restype = ctypes.c_longlong
     L.tb_mark_host_wait.argtypes = [vp, i32, i32]
     L.tb_mark_host_wait.restype = i32
-    L.tb_episode_phase.argtypes = [vp]
-    L.tb_episode_phase.restype = i32
-    L.tb_set_hosted.argtypes = [vp, i32]
-    L.tb_set_hosted.restype = i32
-    L.tb_ff_jobs.argtypes = [vp]
-    L.tb_ff_jobs.restype = i32
-    L.tb_ff_arm.argtypes = [vp, vp]
-    L.tb_ff_arm.restype = i32
-    L.tb_ff_service.argtypes = [vp, i32, i32, vp]
-    L.tb_ff_service.restype = i32
     L.tb_mark_begin.argtypes = [vp]
     L.tb_mark_begin.restype = i32
     L.tb_mark_enable.argtypes = [vp, i32]
@@ -337,25 +327,6 @@ class BatchedEnv:
         """spin on the host (GIL released) until mark k has fired since mark_begin() and the fast-forwards
         enqueued before it have finished"""
         _check(self.L, self.L.tb_mark_host_wait(self._h, int(k), int(timeout_ms)), "tb_mark_host_wait")
-
-    def episode_phase(self):
-        """SwingRacket with every env reset together: agent steps into the current episode (0..25); otherwise -1"""
-        return int(self.L.tb_episode_phase(self._h))
-
-    def set_hosted(self, on):
-        """hosted fast-forwards (tb_set_hosted): one-step launches captured from now on fork nothing; the host launches
-        their fast-forwards during each replay (ff_arm -> replay -> ff_service -> flush)"""
-        _check(self.L, self.L.tb_set_hosted(self._h, 1 if on else 0), "tb_set_hosted")
-
-    def ff_jobs(self):
-        return int(self.L.tb_ff_jobs(self._h))
-
-    def ff_arm(self):
-        _check(self.L, self.L.tb_ff_arm(self._h, self._stream()), "tb_ff_arm")
-
-    def ff_service(self, upto=-1, timeout_ms=10000):
-        """the host waits for each parking step of the running graph in turn and launches its fast-forward (GIL released)"""
-        _check(self.L, self.L.tb_ff_service(self._h, int(upto), int(timeout_ms), self._stream()), "tb_ff_service")
 
     def launch_pending(self):
         """launch the deferred fast-forwards on the side streams, ordered after the current stream"""

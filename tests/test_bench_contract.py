@@ -52,6 +52,6 @@ def test_bench_exchange_forms_with_one_rank(steps, expect_tuning):
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
     w = d["config"]["workload"]
     assert d["value"] > 0 and "all-gather" in w
-    assert ("form chosen on this node" in w) == expect_tuning
+    assert ("exchange form chosen on this node" in w) == expect_tuning
     if not expect_tuning:
         assert "1 RCCL all-gather of rollouts at the collect boundary" in w

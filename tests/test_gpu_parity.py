@@ -769,50 +769,6 @@ def test_progress_marks_release_each_chunk_of_one_graph(torch, kind, n_chunks):
     env.close(); ref_env.close()
 
 
-@pytest.mark.parametrize("n,T", [(4096, 208), (1000, 468)])
-def test_hosted_fast_forwards_keep_the_rollout_graph_linear_and_bit_identical(torch, n, T):
-    """RolloutBuffer.capture_hosted / replay_hosted (tb_set_hosted, tb_ff_arm, tb_ff_service): the captured steps fork
-    nothing -- an episode end parks its lanes and the launch after it tells the host -- and the host launches the
-    fast-forwards while the graph runs. Three replays against the same envs stepped call by call; then a replay in which
-    the host deliberately serves too late: the library must count the overwritten slots, never pass them silently."""
-    from tennisbot_rl_amd.rollout import RolloutBuffer
-    from tennisbot_rl_amd.stepper import BatchedEnv
-    rng = np.random.default_rng(77)
-    acts = torch.from_numpy(rng.uniform(-1, 1, (T, n, 6)).astype(np.float32)).cuda()
-    ref_env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=13, track_terminal_obs=False, pipeline=True)
-    env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=13, track_terminal_obs=False, pipeline=True)
-    ref = RolloutBuffer(ENV_SWING, T, n, "cuda:0").bind(ref_env)
-    buf = RolloutBuffer(ENV_SWING, T, n, "cuda:0").bind(env)
-    ref.actions.copy_(acts); buf.actions.copy_(acts)
-    main = torch.cuda.Stream()
-    torch.cuda.synchronize()
-    with torch.cuda.stream(main):
-        ref_env.reset(); env.reset()
-        for t in range(7):  # episode ends off the buffer's grid
-            ref.step_into(ref_env, t); buf.step_into(env, t)
-        graph = buf.capture_hosted(env)
-        assert env.ff_jobs() == (T + 7) // 26
-        for rnd in range(3):
-            for t in range(T):
-                ref.step_into(ref_env, t)
-            ref_env.flush()
-            buf.replay_hosted(graph, env)
-            main.synchronize()
-            assert torch.equal(ref.raw, buf.raw), "round %d" % rnd
-        assert env.counters() == ref_env.counters() and env.counters()["nonfinite_states"] == 0
-        wa, da = env.get_state_words(); wb, db = ref_env.get_state_words()
-        assert torch.equal(wa, wb) and torch.equal(da, db)
-        if env.ff_jobs() > 16:  # more episode ends than slots: a host that serves nothing until the graph is through loses some
-            env.ff_arm()
-            graph.replay()
-            main.synchronize()
-            env.ff_service()
-            env.flush()
-            main.synchronize()
-            assert env.counters()["nonfinite_states"] > 0
-    env.close(); ref_env.close()
-
-
 def test_deferred_fast_forward_is_launched_by_flush_and_by_slot_reuse(torch):
     """tb_set_defer without anyone calling tb_ff_launch_pending: flush() must deliver, and so must a
     ninth parked episode end that needs the first one's slot back (the handle has 8 slots)"""
