@@ -25,6 +25,10 @@
 
 #define TB_DEV __device__ __forceinline__
 #define TB_N_CULL 12
+// the outline table in LDS / device memory: 2 float4 per edge, then the cull planes (TB_N_CULL x 3 floats) in 9 float4.
+// The planes used to be kernel arguments: 36 SGPRs the loop-free step kernels had to spill at their very start.
+#define TB_HULL_PLANES (2 * TB_MAX_HULL)
+#define TB_HULL_LDS (2 * TB_MAX_HULL + 9)
 #define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 
 namespace tb {
@@ -105,7 +109,6 @@ struct KParams {
   float static_top;  // highest point of any enabled static shape (host-derived)
   // conservative convex superset of the outline (host-derived): half-planes n.p <= h in the COM
   // (y, z) frame -- 8 fixed directions + the longest edges. dist(p, outline) >= max(n.p - h).
-  float cull_planes[TB_N_CULL][3];
   float ball_kn, ball_kt;  // 1/inv_mass and 1/(inv_mass + inv_inertia r^2): ball-only effective masses (host-derived)
   int n_hull;
 };
@@ -176,8 +179,9 @@ TB_DEV Hit sphere_vs_racket_sweep(const KParams& P, const float4* hull, const Ra
   //      is a narrow wedge: a tumbling racket's ball spends many substeps there.)
   if (((SCALED ? ax * s : ax) - P.hull_margin) - r >= thr) return h;
   float sep = -3.0e38f;
+  const float* cp = reinterpret_cast<const float*>(hull + TB_HULL_PLANES);
 #pragma unroll
-  for (int k = 0; k < TB_N_CULL; ++k) sep = fmaxf(sep, FMA(P.cull_planes[k][1], l.z, P.cull_planes[k][0] * l.y) - P.cull_planes[k][2]);
+  for (int k = 0; k < TB_N_CULL; ++k) sep = fmaxf(sep, FMA(cp[3 * k + 1], l.z, cp[3 * k] * l.y) - cp[3 * k + 2]);
   if (((SCALED ? sep * s : sep) - P.hull_margin) - r >= thr + 1.0e-4f) return h;
 #ifdef TB_DIAG_STAMPS
   {

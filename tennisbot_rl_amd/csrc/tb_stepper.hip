@@ -305,6 +305,7 @@ TB_DEV void flush_counters(unsigned long long* counters, const uint32_t* cnt) {
 
 TB_DEV void stage_hull(float4* s_hull, const KArgs& A) {
   for (int k = threadIdx.x; k < 2 * A.P.n_hull; k += blockDim.x) s_hull[k] = A.hull[k];
+  for (int k = TB_HULL_PLANES + threadIdx.x; k < TB_HULL_LDS; k += blockDim.x) s_hull[k] = A.hull[k];
   __syncthreads();
 }
 
@@ -331,7 +332,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
   // with cannot alias the stores it ends with. (Preloading them into SGPRs at wave launch,
   // -amdgpu-kernarg-preload-count, was measured too: no further gain for Tennisbot, -5 % for SwingRacket.)
   constexpr int NA = Dims<KIND>::A, NO = Dims<KIND>::O;
-  __shared__ float4 s_hull[TB_MAX_HULL * 2];
+  __shared__ float4 s_hull[TB_HULL_LDS];
   __shared__ __attribute__((aligned(16))) float s_mean[POLICY ? 64 * 8 : 4];
   // POLICY: 256-thread workgroups, four waves per 64 envs (see policy_towers); wave 0 steps the envs
   const int i = POLICY ? blockIdx.x * 64 + (threadIdx.x & 63) : blockIdx.x * blockDim.x + threadIdx.x;
@@ -358,8 +359,8 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
   if (POLICY) {
     // one barrier for both hand-offs (outline table, action means); the outline rows are requested
     // before the towers' operands and parked in a register meanwhile
-    static_assert(2 * TB_MAX_HULL <= 256, "one outline row per thread");
-    const bool has_row = (int)threadIdx.x < 2 * w_nhull;
+    static_assert(TB_HULL_LDS <= 256, "one outline row per thread");
+    const bool has_row = (int)threadIdx.x < 2 * w_nhull || ((int)threadIdx.x >= TB_HULL_PLANES && (int)threadIdx.x < TB_HULL_LDS);
     float4 row = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (has_row) row = w_hull[threadIdx.x];
     policy_towers<KIND>(A, s_mean);
@@ -369,6 +370,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
     if (live) policy_sample<KIND>(A, s_mean, i, e, a);
   } else {
     for (int k = threadIdx.x; k < 2 * w_nhull; k += blockDim.x) s_hull[k] = w_hull[k];
+    for (int k = TB_HULL_PLANES + threadIdx.x; k < TB_HULL_LDS; k += blockDim.x) s_hull[k] = w_hull[k];
     __syncthreads();
   }
 #ifdef TB_DIAG_STAMPS
@@ -475,11 +477,12 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
 template <int KIND>
 __global__ void __launch_bounds__(320) tb_policy_rollout_kernel(KArgs A) {
   constexpr int NA = Dims<KIND>::A, NO = Dims<KIND>::O;
-  __shared__ float4 s_hull[TB_MAX_HULL * 2];
+  __shared__ float4 s_hull[TB_HULL_LDS];
   __shared__ __attribute__((aligned(16))) float s_mean[64 * 8];
   __shared__ __attribute__((aligned(16))) float s_obs[64 * NO];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int k = threadIdx.x; k < 2 * A.P.n_hull; k += blockDim.x) s_hull[k] = A.hull[k];
+  for (int k = TB_HULL_PLANES + threadIdx.x; k < TB_HULL_LDS; k += blockDim.x) s_hull[k] = A.hull[k];
   if (wave < 4) {
     constexpr int NP0 = TowerRegs<KIND>::NP0;
     const int tower = wave >> 1, half = wave & 1, h = lane >> 5;
@@ -582,7 +585,7 @@ __global__ void tb_mark_kernel(unsigned long long* count) {
 // finishes parked SwingRacket fast-forwards (side stream): same device code as the in-step loop
 template <bool RG>
 __global__ void __launch_bounds__(256) tb_ff_kernel(KArgs A) {
-  __shared__ float4 s_hull[TB_MAX_HULL * 2];
+  __shared__ float4 s_hull[TB_HULL_LDS];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < A.n && A.ff_flag[i] == 1;
   EnvRegs e;
@@ -691,7 +694,7 @@ int validate_params(const TbParams* p) {
   return TB_OK;
 }
 
-void to_kparams(const TbParams* p, KParams* k) {
+void to_kparams(const TbParams* p, KParams* k, float* planes) {
   k->dt = p->dt; k->inv_dt = p->inv_dt; k->gravity = p->gravity; k->lin_damp = p->lin_damp; k->ang_damp = p->ang_damp;
   k->max_ang_step = p->max_ang_step; k->rest_vel_threshold = p->rest_vel_threshold; k->erp = p->erp;
   k->contact_threshold = p->contact_threshold; k->solver_iters = p->solver_iters; k->flags = p->flags; k->solver_tol = p->solver_tol;
@@ -717,7 +720,7 @@ void to_kparams(const TbParams* p, KParams* k) {
     for (int d = 0; d < 8; ++d) {
       double ang = d * 0.78539816339744830962, ny = cos(ang), nz = sin(ang), hmax = -1e30;
       for (int i = 0; i < p->n_hull; ++i) { double v = ny * p->hull_edges[i][0] + nz * p->hull_edges[i][1]; hmax = v > hmax ? v : hmax; }
-      k->cull_planes[np][0] = (float)ny; k->cull_planes[np][1] = (float)nz; k->cull_planes[np][2] = (float)(hmax + 1e-6); ++np;
+      planes[3 * np] = (float)ny; planes[3 * np + 1] = (float)nz; planes[3 * np + 2] = (float)(hmax + 1e-6); ++np;
     }
     bool used[TB_MAX_HULL] = {false};
     for (int pick = 0; pick < TB_N_CULL - 8; ++pick) {
@@ -730,7 +733,7 @@ void to_kparams(const TbParams* p, KParams* k) {
       double il = 1.0 / sqrt(bl), ny = p->hull_edges[best][3] * il, nz = -p->hull_edges[best][2] * il;  // outward normal of a CCW edge
       double hmax = -1e30;
       for (int i = 0; i < p->n_hull; ++i) { double v = ny * p->hull_edges[i][0] + nz * p->hull_edges[i][1]; hmax = v > hmax ? v : hmax; }
-      k->cull_planes[np][0] = (float)ny; k->cull_planes[np][1] = (float)nz; k->cull_planes[np][2] = (float)(hmax + 1e-6); ++np;
+      planes[3 * np] = (float)ny; planes[3 * np + 1] = (float)nz; planes[3 * np + 2] = (float)(hmax + 1e-6); ++np;
     }
   }
   // same float operations as the rows would do per contact (oracle setup_row): bit-identical
@@ -753,6 +756,7 @@ struct TbHandle {
   uint8_t* d_done;
   float4* d_hull;
   float4* h_hull;  // pinned staging copy of the outline table
+  float cull_planes[TB_N_CULL][3];  // derived from the outline (to_kparams); they travel behind it in the same table
   unsigned long long* d_counters;     // [TB_COUNTER_SHARDS][TB_N_COUNTERS]
   // pipelined fast-forward
   int pipeline;            // enabled by tb_set_pipeline
@@ -808,7 +812,8 @@ KArgs base_args(const TbHandle* h) {
 
 int upload_hull(TbHandle* h, hipStream_t s) {
   memcpy(h->h_hull, h->params.hull_edges, sizeof(float) * TB_HULL_REC * TB_MAX_HULL);
-  HIP_TRY(hipMemcpyAsync(h->d_hull, h->h_hull, sizeof(float) * TB_HULL_REC * TB_MAX_HULL, hipMemcpyHostToDevice, s));
+  memcpy(reinterpret_cast<float*>(h->h_hull + TB_HULL_PLANES), h->cull_planes, sizeof h->cull_planes);
+  HIP_TRY(hipMemcpyAsync(h->d_hull, h->h_hull, sizeof(float4) * TB_HULL_LDS, hipMemcpyHostToDevice, s));
   return TB_OK;
 }
 
@@ -1007,7 +1012,7 @@ int tb_create(const TbParams* params, int env_kind, int n_envs, int device, uint
   TbHandle* h = (TbHandle*)calloc(1, sizeof(TbHandle));
   if (!h) return fail(TB_E_INVAL, "tb_create: out of host memory");
   h->device = device; h->kind = env_kind; h->n = n_envs; h->seed = seed; h->env_id_base = env_id_base;
-  h->params = *params; to_kparams(params, &h->kp); h->block = pick_block(n_envs);
+  h->params = *params; to_kparams(params, &h->kp, &h->cull_planes[0][0]); h->block = pick_block(n_envs);
   {  // Tennisbot, measured in the steady state (envs past their first, synchronised episodes): +28 % at 4096 envs,
      // +8 % at 256 K, +16 % at 1 M, +12 % at 4 M; only the contact-free first episode after a common reset, where the
      // kernel runs at 70 % of HBM peak and occupancy counts, loses 3 % at 1 M envs
@@ -1021,8 +1026,8 @@ int tb_create(const TbParams* params, int env_kind, int n_envs, int device, uint
 #define CREATE_TRY(expr) if ((err = (expr)) != hipSuccess) { int rc = fail((int)err, #expr); tb_destroy(h); return rc; }
   CREATE_TRY(hipMalloc((void**)&h->d_words, sizeof(uint32_t) * (size_t)nw * n_envs));
   CREATE_TRY(hipMalloc((void**)&h->d_done, (size_t)n_envs));
-  CREATE_TRY(hipMalloc((void**)&h->d_hull, sizeof(float) * TB_HULL_REC * TB_MAX_HULL));
-  CREATE_TRY(hipHostMalloc((void**)&h->h_hull, sizeof(float) * TB_HULL_REC * TB_MAX_HULL, hipHostMallocDefault));
+  CREATE_TRY(hipMalloc((void**)&h->d_hull, sizeof(float4) * TB_HULL_LDS));
+  CREATE_TRY(hipHostMalloc((void**)&h->h_hull, sizeof(float4) * TB_HULL_LDS, hipHostMallocDefault));
   CREATE_TRY(hipMalloc((void**)&h->d_counters, sizeof(unsigned long long) * TB_N_COUNTERS * TB_COUNTER_SHARDS));
   CREATE_TRY(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * TB_N_COUNTERS * TB_COUNTER_SHARDS, 0));
   hipLaunchKernelGGL(tb_init_kernel, dim3((unsigned)((n_envs + 255) / 256)), dim3(256), 0, 0, h->d_words, h->d_done, n_envs, nw);
@@ -1208,7 +1213,7 @@ int tb_set_params(TbHandle* h, const TbParams* params, void* stream) {
   HIP_TRY(hipStreamSynchronize(s));
   if ((params->flags ^ h->params.flags) & TB_F_AUTO_RESET) h->phase_valid = 0;  // episodes may stop / start restarting
   h->params = *params;
-  to_kparams(params, &h->kp);
+  to_kparams(params, &h->kp, &h->cull_planes[0][0]);
   if (int rc = upload_hull(h, s)) return rc;
   HIP_TRY(hipStreamSynchronize(s));
   return TB_OK;
