@@ -28,7 +28,10 @@
 // the outline table in LDS / device memory: 2 float4 per edge, then the cull planes (TB_N_CULL x 3 floats) in 9 float4.
 // The planes used to be kernel arguments: 36 SGPRs the loop-free step kernels had to spill at their very start.
 #define TB_HULL_PLANES (2 * TB_MAX_HULL)
-#define TB_HULL_LDS (2 * TB_MAX_HULL + 9)
+#define TB_HULL_KP (2 * TB_MAX_HULL + 9)
+// ... and behind the planes a copy of the whole KParams block (TB_KP_ROWS float4) for the COLD instantiations of substep
+#define TB_KP_ROWS 18
+#define TB_HULL_LDS (TB_HULL_KP + TB_KP_ROWS)
 #define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 
 namespace tb {
@@ -756,7 +759,10 @@ TB_DEV void integrate_pose(const KParams& P, Racket& rk, Ball& b) {
 // the narrowphase is arranged as cheap per-lane culls + wave votes: a wave runs the outline
 // sweep / the static tests / the impulse solver only if __any lane needs them, and those
 // branches are wave-uniform (s_cbranch on the ballot), never if-converted into the hot path.
-template <int KIND, bool RG, bool REGROWS = false>
+// COLD: the contact path reads its constants from the LDS copy of the parameter block instead of holding them in SGPRs all the
+// time. Pays where SGPRs are scarce and contacts rare (the policy rollout kernel: 97 -> 70 spill writes, collect +10 %); costs VGPRs and
+// LDS reads where throughput counts (SwingRacket at 1 M envs -15 %, Tennisbot -4 %), so only that kernel asks for it.
+template <int KIND, bool RG, bool REGROWS = false, bool COLD = false>
 TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, vec3 Fr, vec3 Tr, vec3 Fb, float goal_x, float goal_y, float scale TB_STAMP_ARG) {
   int bits = 0;
   TB_STAMP(st, 0);  // everything between two substeps (loop control, env logic)
@@ -809,26 +815,27 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, ve
 
   if (__any(bits != 0)) {
     if (bits) {  // only lanes that touch something enter the solver
+      const KParams& PC = COLD ? *reinterpret_cast<const KParams*>(hull + TB_HULL_KP) : P;
       Rows<RG> R;
       if constexpr (RG) {
         R.nrg = (rg_picks[0] >= 0) + (rg_picks[1] >= 0) + (rg_picks[2] >= 0) + (rg_picks[3] >= 0);
         // picks are found in order 0..3 and a later one exists only if the earlier ones do: compact already
 #pragma unroll
         for (int j = 0; j < TB_MAX_RG; ++j)
-          if (rg_picks[j] >= 0) setup_ground_row<KIND == TB_ENV_TENNIS>(P, hull, R.rg[j], rg_picks[j], scale, rg_zr, rk);
+          if (rg_picks[j] >= 0) setup_ground_row<KIND == TB_ENV_TENNIS>(PC, hull, R.rg[j], rg_picks[j], scale, rg_zr, rk);
       }
       R.on[0] = bits & CT_RACKET; R.on[1] = bits & CT_GROUND; R.on[2] = bits & CT_NET; R.on[3] = bits & CT_GOAL;
-      if (R.on[0]) setup_racket<KIND == TB_ENV_TENNIS>(P, R.rk, hr, rk, b, scale);
-      if (R.on[1]) setup_static(P, R.st[0], hg, P.rest_court, P.fric_court, b);
-      if (R.on[2]) setup_static(P, R.st[1], hn, P.rest_court, P.fric_court, b);
-      if (R.on[3]) setup_static(P, R.st[2], hc, P.rest_goal, P.fric_goal, b);
+      if (R.on[0]) setup_racket<KIND == TB_ENV_TENNIS>(PC, R.rk, hr, rk, b, scale);
+      if (R.on[1]) setup_static(PC, R.st[0], hg, PC.rest_court, PC.fric_court, b);
+      if (R.on[2]) setup_static(PC, R.st[1], hn, PC.rest_court, PC.fric_court, b);
+      if (R.on[3]) setup_static(PC, R.st[2], hc, PC.rest_goal, PC.fric_goal, b);
       if constexpr (RG) {
-        if (R.on[0]) setup_roll_racket<KIND == TB_ENV_TENNIS>(P, R.qrk, R.rk, rk, scale);
-        if (R.on[1]) setup_roll_static(P, R.qst[0], P.roll_court);
-        if (R.on[2]) setup_roll_static(P, R.qst[1], P.roll_court);
-        if (R.on[3]) setup_roll_static(P, R.qst[2], P.roll_goal);
+        if (R.on[0]) setup_roll_racket<KIND == TB_ENV_TENNIS>(PC, R.qrk, R.rk, rk, scale);
+        if (R.on[1]) setup_roll_static(PC, R.qst[0], PC.roll_court);
+        if (R.on[2]) setup_roll_static(PC, R.qst[1], PC.roll_court);
+        if (R.on[3]) setup_roll_static(PC, R.qst[2], PC.roll_goal);
       }
-      solve_contacts<RG, REGROWS>(P, R, rk, b);
+      solve_contacts<RG, REGROWS>(PC, R, rk, b);
     }
   }
   TB_STAMP(st, 4);  // contact solve

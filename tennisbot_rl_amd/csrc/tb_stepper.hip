@@ -215,13 +215,13 @@ TB_DEV vec3 restoring_force(const EnvRegs& e) {  // swingracket_env.py:135-141
 //                    later ones with the restoring force of :135-141.
 // `in_ff` = start inside the fast-forward (tb_ff_kernel resuming a parked env).
 // `defer`  = leave the fast-forward to tb_ff_kernel: sets `parked` instead of looping.
-template <bool RG, bool REGROWS = false>
+template <bool RG, bool REGROWS = false, bool COLD = false>
 TB_DEV float swing_loop(const KParams& P, const float4* hull, EnvRegs& e, vec3 F, vec3 T, bool in_ff, bool defer, bool& parked,
                         int& ns, uint32_t* cnt TB_STAMP_ARG) {
   const vec3 zero = mk(0.0f, 0.0f, 0.0f);
   float reward = 0.0f;
   for (;;) {
-    int bits = substep<TB_ENV_SWING, RG, REGROWS>(P, hull, e.r, e.b, F, T, zero, e.aux[0], e.aux[1], 1.0f TB_STAMP_PASS);  // :82 / :107
+    int bits = substep<TB_ENV_SWING, RG, REGROWS, COLD>(P, hull, e.r, e.b, F, T, zero, e.aux[0], e.aux[1], 1.0f TB_STAMP_PASS);  // :82 / :107
     e.step_count += 1; ns++;                                                                                   // :83 / :108
     if (bits & CT_RACKET) cnt[0]++;
     if (!in_ff) {
@@ -240,7 +240,7 @@ TB_DEV float swing_loop(const KParams& P, const float4* hull, EnvRegs& e, vec3 F
   return reward;
 }
 
-template <bool RG, bool REGROWS = false>
+template <bool RG, bool REGROWS = false, bool COLD = false>
 TB_DEV float swing_step(const KParams& P, const float4* hull, EnvRegs& e, const float* a, int& ns, uint32_t* cnt, bool defer, bool& parked TB_STAMP_ARG) {
   vec3 F = mk(a[0] * 400.0f, a[1] * 400.0f, FMA(a[2], 400.0f, 4.0f * 9.81f));  // :76-77
   vec3 T = mk(a[3] * 5.0f, a[4] * 5.0f, a[5] * 5.0f);                          // :78
@@ -249,7 +249,7 @@ TB_DEV float swing_step(const KParams& P, const float4* hull, EnvRegs& e, const 
     e.done = TB_DONE_YES;
   }
   ns = 0;
-  return swing_loop<RG, REGROWS>(P, hull, e, F, T, false, defer, parked, ns, cnt TB_STAMP_PASS);
+  return swing_loop<RG, REGROWS, COLD>(P, hull, e, F, T, false, defer, parked, ns, cnt TB_STAMP_PASS);
 }
 
 // tennisbot_env.py:90-102
@@ -258,13 +258,13 @@ TB_DEV float dist_to_reward(float d) {
 }
 
 // tennisbot_env.py:104-207 (the DELAY_MODE sleep at :124-126 is dropped on purpose)
-template <bool RG, bool REGROWS = false>
+template <bool RG, bool REGROWS = false, bool COLD = false>
 TB_DEV float tennis_step(const KParams& P, const float4* hull, EnvRegs& e, const float* a, float* obs, bool& ret_done, uint32_t* cnt TB_STAMP_ARG) {
   const vec3 zero = mk(0.0f, 0.0f, 0.0f);
   vec3 F = mk(a[0] * 10.0f, a[1] * 10.0f, 4.0f * 9.81f);  // :112-115
   vec3 Fb = zero;
   if (e.step_count < 5) Fb = mk(e.aux[0], e.aux[1], e.aux[2]);  // :118-119
-  int bits = substep<TB_ENV_TENNIS, RG, REGROWS>(P, hull, e.r, e.b, F, zero, Fb, 0.0f, 0.0f, e.aux[3] TB_STAMP_PASS);  // :121
+  int bits = substep<TB_ENV_TENNIS, RG, REGROWS, COLD>(P, hull, e.r, e.b, F, zero, Fb, 0.0f, 0.0f, e.aux[3] TB_STAMP_PASS);  // :121
   e.step_count += 1;                                                                // :122
   if (bits & CT_RACKET) cnt[0]++;
   make_obs<TB_ENV_TENNIS>(e, obs);  // :134-136
@@ -308,6 +308,7 @@ TB_DEV void stage_hull(float4* s_hull, const KArgs& A) {
   for (int k = TB_HULL_PLANES + threadIdx.x; k < TB_HULL_LDS; k += blockDim.x) s_hull[k] = A.hull[k];
   __syncthreads();
 }
+static_assert(sizeof(KParams) <= sizeof(float4) * TB_KP_ROWS, "the LDS copy of the parameter block needs more rows");
 
 // ------------------------------------------------------------------------------------------
 // step / rollout kernel: T agent steps of every env, state in registers throughout
@@ -536,7 +537,7 @@ __global__ void __launch_bounds__(320) tb_policy_rollout_kernel(KArgs A) {
       bool d, parked = false;
       float rew;
       if (KIND == TB_ENV_SWING) {
-        rew = swing_step<false>(A.P, s_hull, e, a, ns, cnt, true, parked TB_STAMP_PASS);  // never loops in here: see tb_step_kernel<LEAN>
+        rew = swing_step<false, false, true>(A.P, s_hull, e, a, ns, cnt, true, parked TB_STAMP_PASS);  // never loops in here: see tb_step_kernel<LEAN>; COLD
         make_obs<TB_ENV_SWING>(e, o);
         d = e.done != TB_DONE_NO;
         if (parked) {
@@ -549,7 +550,7 @@ __global__ void __launch_bounds__(320) tb_policy_rollout_kernel(KArgs A) {
           d = true;
         }
       } else {
-        rew = tennis_step<false, true>(A.P, s_hull, e, a, o, d, cnt TB_STAMP_PASS);
+        rew = tennis_step<false, true, true>(A.P, s_hull, e, a, o, d, cnt TB_STAMP_PASS);
       }
       cnt[6] += (uint32_t)(ns - 1);
       if (!(finite3(e.r.p) && finite3(e.r.v) && finite3(e.r.w) && finite3(e.b.p) && finite3(e.b.v) && finite3(e.b.w) &&
@@ -813,6 +814,8 @@ KArgs base_args(const TbHandle* h) {
 int upload_hull(TbHandle* h, hipStream_t s) {
   memcpy(h->h_hull, h->params.hull_edges, sizeof(float) * TB_HULL_REC * TB_MAX_HULL);
   memcpy(reinterpret_cast<float*>(h->h_hull + TB_HULL_PLANES), h->cull_planes, sizeof h->cull_planes);
+  memset(h->h_hull + TB_HULL_KP, 0, sizeof(float4) * TB_KP_ROWS);
+  memcpy(h->h_hull + TB_HULL_KP, &h->kp, sizeof h->kp);
   HIP_TRY(hipMemcpyAsync(h->d_hull, h->h_hull, sizeof(float4) * TB_HULL_LDS, hipMemcpyHostToDevice, s));
   return TB_OK;
 }
