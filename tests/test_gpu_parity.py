@@ -481,6 +481,55 @@ def test_randomised_engine_parameters_stay_bit_exact(torch, kind):
         env.close()
 
 
+def test_maximum_size_outline_stays_bit_exact(torch):
+    """an outline with TB_MAX_HULL = 64 edges fills the table the kernels stage into LDS to the last row (the racket cull
+    planes travel right behind it): an egg-shaped 64-gon, balls all around it and on its rim, Tennisbot with random scales"""
+    import copy
+    from tennisbot_rl_amd.params import load_scene
+    sc = copy.deepcopy(load_scene())
+    ang = np.linspace(0.0, 2.0 * np.pi, 64, endpoint=False)
+    y = 0.16 * np.cos(ang) * (1.0 + 0.15 * np.cos(2 * ang))
+    z = 0.5 + 0.3 * np.sin(ang) - 0.12 * np.sin(ang) ** 2   # link frame; the COM (inertial origin) is at z = 0.5
+    sc["racket"]["hull_yz_ccw"] = [[float(a), float(b)] for a, b in zip(y, z)]
+    n = 4096
+    rng = np.random.default_rng(404)
+    p = default_params(scene=sc)
+    assert p.n_hull == 64
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    env = BatchedEnv(ENV_TENNIS, n, device="cuda:0", seed=5, params=p, auto_reset=False)
+    pf = p.copy(); pf.flags &= ~F_AUTO_RESET
+    ref = OracleBatch(pf, ENV_TENNIS, n, seed=5, precision="f32")
+    ref.L.tbo_set_threads(ref.h, 8)
+    scale = rng.uniform(1.0, 3.0, n)
+    q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    rp = np.stack([rng.uniform(8, 12, n), rng.uniform(-4, 4, n), rng.uniform(0.6, 1.5, n) * scale], 1)
+    r = float(p.ball_radius)
+    th = rng.uniform(0, 2 * np.pi, n)
+    rad = rng.uniform(0.0, 1.15, n)  # inside, on the rim, just outside
+    loc = np.stack([rng.uniform(-1, 1, n) * (float(p.racket_half_thick) * scale + r + 0.003),
+                    0.17 * np.cos(th) * rad * scale, (0.3 * np.sin(th) * rad) * scale], 1)
+
+    def rot(q, v):
+        u, w = q[:, :3], q[:, 3:4]
+        t = 2 * np.cross(u, v)
+        return v + w * t + np.cross(u, t)
+    fields = dict(racket_pos=rp, racket_quat=q, racket_vel=rng.uniform(-3, 3, (n, 3)), racket_angvel=rng.uniform(-5, 5, (n, 3)),
+                  ball_pos=rp + rot(q, loc), ball_vel=rng.uniform(-12, 12, (n, 3)), ball_angvel=rng.uniform(-40, 40, (n, 3)),
+                  shoot_force=(30, 0, 20), step_count=50, racket_scale=scale)
+    w, d = make_words(ENV_TENNIS, n, **fields)
+    env.set_state_words(w.view(np.int32), d); ref.set_state_words(w, d)
+    for t in range(8):
+        a = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+        obs, rew, done = env.step(torch.from_numpy(a).cuda())
+        o2, r2, d2, s2 = ref.step(a)
+        same(obs.cpu().numpy(), o2, "64-gon obs %d" % t)
+        same(rew.cpu().numpy(), r2, "64-gon reward %d" % t)
+        same(done.cpu().numpy(), d2, "64-gon done %d" % t)
+        compare_state(env, ref, "64-gon %d" % t)
+    assert env.counters()["racket_ball_contact_substeps"] > n // 8
+    env.close()
+
+
 def test_float32_drift_vs_float64_truth(torch):
     """stated float32 tolerance: over one Swing episode without contacts the float32 state stays
     within 2e-4 (abs, metres / m/s) of the float64 oracle; done and step counters agree wherever
