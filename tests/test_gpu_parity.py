@@ -481,6 +481,42 @@ def test_randomised_engine_parameters_stay_bit_exact(torch, kind):
         env.close()
 
 
+@pytest.mark.parametrize("kind,steps,piped", [(ENV_SWING, 30, False), (ENV_SWING, 30, True), (ENV_TENNIS, 120, False)])
+def test_large_batch_instantiations_in_lockstep_with_the_oracle(torch, kind, steps, piped):
+    """above 131 072 envs tb_create picks other launch shapes and kernel variants (256-thread workgroups, SwingRacket's
+    contact rows back in scratch): 200 003 envs -- ragged against every workgroup size -- against the oracle, through a
+    whole SwingRacket episode end (in-kernel and side-stream fast-forward) and Tennisbot's first arrivals at the racket"""
+    from tennisbot_rl_amd.rollout import RolloutBuffer
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    n = 200003
+    p = default_params()
+    env = BatchedEnv(kind, n, device="cuda:0", seed=21, params=p, pipeline=piped, track_terminal_obs=False)
+    pf = p.copy(); pf.flags |= F_AUTO_RESET
+    ref = OracleBatch(pf, kind, n, seed=21, precision="f32")
+    ref.L.tbo_set_threads(ref.h, 16)
+    rng = np.random.default_rng(9)
+    same(env.reset().cpu().numpy(), ref.reset(), "large reset obs")
+    outs = []
+    for t in range(steps):
+        a = rng.uniform(-1, 1, (n, env.act_dim)).astype(np.float32)
+        obs, rew, done = env.step(torch.from_numpy(a).cuda())
+        o2, r2, d2, s2 = ref.step(a)
+        same(obs.cpu().numpy(), o2, "large obs %d" % t)
+        same(done.cpu().numpy(), d2, "large done %d" % t)
+        if piped:
+            outs.append((rew, r2))  # terminal rewards arrive late from the side streams
+        else:
+            same(rew.cpu().numpy(), r2, "large reward %d" % t)
+    env.flush()
+    for t, (rew, r2) in enumerate(outs):
+        same(rew.cpu().numpy(), r2, "large reward %d" % t)
+    compare_state(env, ref, "large final state")
+    got, want = env.counters(), ref.counters()
+    assert list(got.values()) == [int(x) for x in want], (got, want)
+    assert got["nonfinite_states"] == 0 and got["substeps"] >= n * steps
+    env.close()
+
+
 def test_maximum_size_outline_stays_bit_exact(torch):
     """an outline with TB_MAX_HULL = 64 edges fills the table the kernels stage into LDS to the last row (the racket cull
     planes travel right behind it): an egg-shaped 64-gon, balls all around it and on its rim, Tennisbot with random scales"""
