@@ -4,25 +4,35 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one agent-level env.step() of every env of the batch (BASELINE.json metric;
-SURVEY.md 8d): one launch of the HIP step kernel over N envs, i.e. 1 physics substep for
-agent steps 1-25 of an episode and 1 + (up to 775) substeps on the 26th (the fast-forward
-of swingracket_env.py:105-141), plus the in-kernel auto-reset. Inputs (state, synthetic
-U(-1,1) actions from PCG64) are resident in HBM before the timed region; every step writes
-obs / reward / done straight into the rank's rollout buffer, and with N > 1 the timed
-region contains the exchange of the rollout shards (RCCL all-gather over xGMI) that the PPO
-collect boundary needs: ONE collective after the K steps, or the same bytes in 8 step-chunks
-overlapped with the steps -- whichever was faster on this node in untimed trials before the
-clock started (--gather-chunks pins a form; the line says which ran). Rank 0 prints ONE JSON line.
+A "step" is one agent-level env.step() of every env of the batch (BASELINE.json metric):
+one launch of the HIP step kernel over N envs, i.e. 1 physics substep for agent steps 1-25 of an
+episode and 1 + (up to 775) substeps on the 26th (the fast-forward of swingracket_env.py:105-141,
+~80 % of the workload's substeps), plus the in-kernel auto-reset.
+
+WHAT IS TIMED. The cost of a SwingRacket step is only defined over whole 26-step episodes, and the
+fast-forward of a rollout's last episode (its "tail") is part of the rollout. The unit of work is
+therefore one ROLLOUT: --rollout-steps agent steps (default 1040 = 40 episodes; the reference collects
+n_steps = 1100, train_swing.py:49-50) written in place into the rank's rollout buffer, ended by the join
+of every outstanding fast-forward, and -- with N > 1 -- the exchange of the rollout shards that the PPO
+collect boundary needs (RCCL all-gather over xGMI). `--steps K` is rounded UP to whole rollouts:
+steps_timed = rollout_steps * ceil(K / rollout_steps) (so K = 20 times 1040 steps, not 20 one-substep
+steps between two episode ends); `steps` echoes K. The episode phase is aligned (warm-up rounded up to
+whole episodes) and the line carries substeps_per_agent_step; a value whose substeps per step are not
+the workload's (within 5 %) is refused (value = null, "invalid" says why).
+Inputs (state, synthetic U(-1,1) actions from PCG64) are resident in HBM before the timed region.
 
 Also in that line:
-  roofline     -- HBM roofline of the step kernel: algorithmic bytes per launch (267 B/env
-                  Swing, 263 B/env Tennisbot: DESIGN.md) / average launch duration from HIP
-                  events on the launch stream. This path is launch- and ALU-latency-bound at
-                  4096 envs, and the number says so; `sweep` shows the
-                  asymptote at large N.
-  cpu_baseline -- the float32 CPU oracle (a port, not PyBullet, which is not installable
-                  here) timed on this host's cores on a bounded sample of the same workload.
+  roofline     -- HBM roofline of the step kernel: algorithmic bytes per launch (267 B/env Swing,
+                  263 B/env Tennisbot: DESIGN.md) / average launch duration from HIP events on the
+                  launch stream; `read_only` prices the same launch with the 145 / 117 B a step READS.
+                  Launch- and ALU-latency-bound at 4096 envs; `sweep` shows 4096 and
+                  1 M envs for both envs (--sweep: the whole 4096 .. 4 M ladder).
+  cpu_baseline -- the float32 CPU oracle (a port, not PyBullet, which is not installable here) timed on
+                  this host's cores on a bounded sample of the same workload (whole episodes: the same
+                  substeps per step), and `reference_record`: the wall-clock the reference's own PyBullet
+                  training run recorded (tests/golden/ppo_swing_reference_episodes.json).
+  exchange     -- N > 1: ranks_seen, bytes per rank, rollout_ms / exchange_ms measured apart, and what
+                  of the exchange stayed exposed in the timed region.
 """
 import argparse
 import json
@@ -36,6 +46,10 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 ALGO_BYTES = {"swing": {"read": 145, "write": 122}, "tennis": {"read": 117, "write": 146}}  # SURVEY.md 8d / DESIGN.md
+# physics substeps per agent step of the random-action workload (whole episodes): what a valid SwingRacket
+# measurement must show within 5 %; Tennisbot is 1 by construction. Measured over >= 4096 x 1040 steps
+# (profiles/r02*), the same on the CPU oracle; keyed by racket<->court contact on/off.
+EXPECTED_SUBSTEPS = {("swing", True): None, ("swing", False): 5.09, ("tennis", True): 1.0, ("tennis", False): 1.0}
 
 
 def pmc_traffic(env_name, n_envs):
@@ -59,21 +73,23 @@ def pmc_traffic(env_name, n_envs):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1040, help="timed agent steps (default 40 Swing episodes of 26)")
-    ap.add_argument("--warmup", type=int, default=None, help="untimed steps after reset (default 52 SwingRacket / 1040 Tennisbot: its envs are reset together and their first episode -- every ball still in flight -- steps 12 %% faster than the steady state; with a graph, its K steps are also replayed once before the clock starts)")
+    ap.add_argument("--steps", type=int, default=1040, help="agent steps to time; rounded UP to whole rollouts (see --rollout-steps)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps after reset (default 52 SwingRacket / 1040 Tennisbot: its envs are reset together and their first episode -- every ball still in flight -- steps 12 %% faster than the steady state); rounded up to whole episodes; the captured rollout is also replayed once before the clock starts")
+    ap.add_argument("--rollout-steps", type=int, default=1040, help="agent steps per rollout = per hipGraph replay, ended by the join of the fast-forwards (and the exchange); SwingRacket: a multiple of 26")
     ap.add_argument("--env", choices=["swing", "tennis"], default="swing")
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--contact-off", action="store_true", help="BASELINE configs[1] bench mode: racket<->ball pair disabled")
-    ap.add_argument("--racket-ground", action="store_true", help="also simulate racket<->court contact (TB_F_RACKET_GROUND, row f3; opt-in)")
+    ap.add_argument("--racket-ground", action="store_true", help="also simulate racket<->court contact (TB_F_RACKET_GROUND, row f3)")
     ap.add_argument("--rolling-friction", action="store_true", help="also solve the rolling-friction rows of every ball contact (TbParams.roll_*, row f3; opt-in)")
     ap.add_argument("--magnus", type=float, default=0.0, help="BASELINE configs[4] extension: Magnus coefficient k_M in F = k_M w x v (0 = the reference)")
     ap.add_argument("--spin-max", type=float, default=0.0, help="BASELINE configs[4] extension: initial ball spin ~ U(-w, w)^3 rad/s at reset (0 = the reference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work per baseline leg (1 core, all cores)")
-    ap.add_argument("--sweep", action="store_true", help="also time N = 4096 .. 4M envs on one GPU (extra JSON key)")
+    ap.add_argument("--sweep", action="store_true", help="the whole N ladder (4096 .. 4 M envs) for this env instead of the default 4096 + 1 M of both envs")
+    ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--gather-chunks", type=int, default=0, help="multi-rank exchange of the rollout: 1 = ONE all-gather at the collect boundary; C > 1 = C step-chunks, each all-gather overlapped with later chunks' steps; 0 (default) = measure both on the node, untimed, and time the faster")
-    ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of replaying one captured hipGraph")
+    ap.add_argument("--gather-chunks", type=int, default=8, help="multi-rank exchange of the rollout: C > 1 (default 8) = C step-chunks, each chunk's all-gather issued on a high-priority side stream as soon as the chunk is final, overlapped with the later chunks' steps; 1 = ONE all-gather after the rollout")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step from the host instead of replaying one captured hipGraph per rollout")
     ap.add_argument("--no-pipeline", action="store_true", help="run the SwingRacket fast-forward inside the step kernel instead of a side stream")
     args = ap.parse_args()
     if args.warmup is None:
@@ -94,131 +110,143 @@ def fill_actions(buf_actions, seed, torch):
         buf_actions[t0:t0 + n].copy_(a[:n])
 
 
-GRAPH_STATE = {"used": True, "chunks": 1, "priority": 0, "gather_ok": None, "tuning": None}
+class Rollouts:
+    """One rank's measured object: an env batch, its rollout buffer, and ONE way to run a rollout
+    (hipGraph replay or host-issued steps) and ONE way to exchange it (chunked + overlapped, or a single
+    all-gather)."""
 
+    def __init__(self, env, buf, torch, dist_on, use_graph, chunks, force_collective=False):
+        self.env, self.buf, self.torch, self.dist_on = env, buf, torch, dist_on
+        self.force = force_collective
+        self.collective = dist_on or force_collective
+        self.T = buf.T
+        self.chunks = chunks if (self.collective and chunks > 1 and self.T % chunks == 0) else 1
+        self.graph = None
+        self.use_graph = use_graph
+        self.note = ""
 
-def time_steps(env, buf, steps, warmup, torch, dist_on, tail_gather=True, graph=False, gather_chunks=0, force_collective=False):
-    """W untimed + K timed steps; returns (wall seconds, HIP-event seconds of the K launches).
-    graph=True: the K timed steps are captured once into a hipGraph (outside the timed region) and
-    the timed region replays it -- same kernels, same buffers, no per-step host work.
-    The exchange at the collect boundary (multi-rank only) has two forms: ONE all-gather after the K
-    steps, or C step-chunks whose all-gathers run on a side stream while the main stream goes on
-    stepping (the K steps stay ONE hipGraph with a progress mark behind every chunk,
-    RolloutBuffer.capture_marked; the host watches the marks and issues each chunk's collective as
-    soon as its records are final; only this library's kernels are captured, the collectives are
-    plain asynchronous RCCL calls). gather_chunks = 1 / C > 1 picks a form; 0 = try ONE, and 8
-    chunks at both stream priorities, untimed, on the node itself, and time the fastest (all ranks
-    agree through an all-reduce): which one overlaps best depends on how the runtime maps streams to
-    hardware queues, and is measured rather than assumed."""
-    dev = env.device
-    T = buf.T
-    for t in range(warmup):
-        buf.step_into(env, t % T)
-    collective = (dist_on or force_collective) and tail_gather
-    chunkable = collective and steps == T
+    def prepare(self):
+        """capture the rollout (nothing runs), then run it once untimed: RCCL's first use of each collective
+        shape (channels, buffers) and the allocator's first touches stay outside the timed region"""
+        env, buf, torch = self.env, self.buf, self.torch
+        if self.use_graph:
+            try:
+                self.graph = buf.capture_marked(env, self.chunks) if self.chunks > 1 else env.capture(lambda: buf.step_range(env, 0, self.T))
+            except Exception as exc:  # fall back to host-issued launches and say so
+                print("hipGraph capture failed (%s: %s); issuing the steps from the host" % (type(exc).__name__, exc), file=sys.stderr)
+                self.graph, self.use_graph = None, False
+        if self.chunks > 1:
+            try:
+                self.run_once()
+            except Exception as exc:  # a chunked exchange that does not complete must not cost the run
+                print("chunked exchange failed (%s: %s); falling back to ONE all-gather per rollout" % (type(exc).__name__, exc), file=sys.stderr)
+                self.note = "chunked exchange failed on this node (%s): ONE all-gather per rollout was timed instead" % type(exc).__name__
+                torch.cuda.synchronize(env.device)
+                self.chunks = 1
+                self.graph = env.capture(lambda: buf.step_range(env, 0, self.T)) if self.use_graph else None
+                self.run_once()
+        else:
+            self.run_once()
+        torch.cuda.synchronize(env.device)
 
-    def usable(c):
-        return c > 1 and chunkable and steps % c == 0
-    # A pipelined SwingRacket graph bakes in which of its steps end an episode (and fork a fast-forward): it can be
-    # replayed again and again only if K is a whole number of 26-step episodes. Otherwise it runs exactly once --
-    # the timed run -- and nothing is tuned.
-    repeatable = not getattr(env, "pipeline", False) or steps % 26 == 0
-    if gather_chunks == 0:
-        modes = [(1, 0)] + ([(8, -1), (8, 0)] if (usable(8) and repeatable) else [])
-    elif usable(gather_chunks):
-        modes = [(gather_chunks, -1 if getattr(env, "pipeline", False) else 0)]
-    else:
-        modes = [(1, 0)]
+    def steps_only(self):
+        env, buf = self.env, self.buf
+        if self.graph is not None and self.chunks > 1:
+            buf.replay_marked(self.graph, env, self.chunks, gather=False)
+        elif self.graph is not None:
+            self.graph.replay()
+        else:
+            buf.step_range(env, 0, self.T)
+            env.flush()  # pipelined fast-forwards: every step's outputs are complete from here on
 
-    plain, marked = None, {}
-    if graph:
-        try:
-            def body():
-                for t in range(steps):
-                    buf.step_into(env, t % T)
-            # a capture advances the library's episode-phase hint by K steps without running them: replay each
-            # graph once before anything else is captured or stepped
-            if any(c == 1 for c, _ in modes):
-                plain = env.capture(body)
-                if repeatable:
-                    plain.replay()
-                    torch.cuda.synchronize(dev)
-            for c in sorted({c for c, _ in modes if c > 1}):
-                marked[c] = buf.capture_marked(env, c)
-                if repeatable:
-                    marked[c].replay()
-                    torch.cuda.synchronize(dev)
-        except Exception as exc:  # fall back to host-issued launches and say so
-            print("hipGraph capture failed (%s: %s); issuing the steps from the host" % (type(exc).__name__, exc), file=sys.stderr)
-            plain, marked, graph = None, {}, False
-    GRAPH_STATE["used"] = bool(graph)
+    def exchange_only(self):
+        buf = self.buf
+        if not self.collective:
+            return
+        if self.chunks > 1:
+            buf.begin_gather(self.chunks, force=self.force, priority=-1)
+            for c in range(self.chunks):
+                buf.gather_chunk(c, force=self.force, after_mark=True)
+            buf.finish_gather()
+        else:
+            buf.all_gather(force=self.force)
 
-    def run(mode):
-        chunks, prio = mode
-        seg = steps // chunks
-        if chunks > 1:
-            buf.begin_gather(chunks, force=force_collective, priority=prio)
-        if dist_on:
+    def run_once(self):
+        """one rollout + its exchange, as the timed region runs it"""
+        env, buf = self.env, self.buf
+        if self.chunks > 1:
+            buf.begin_gather(self.chunks, force=self.force, priority=-1)
+            if self.graph is not None:
+                buf.replay_marked(self.graph, env, self.chunks, gather=True, force=self.force)
+            else:  # host-issued variant (--no-graph, or capture failed): the side stream waits by event
+                seg = self.T // self.chunks
+                for c in range(self.chunks):
+                    buf.step_range(env, c * seg, (c + 1) * seg)
+                    buf.gather_chunk(c, env=env, force=self.force)
+                env.flush()
+            buf.finish_gather()
+        else:
+            self.steps_only()
+            if self.collective:
+                buf.all_gather(force=self.force)  # collect boundary: one collective
+
+    def timed(self, fn, reps):
+        """reps x fn() bracketed by barrier + synchronize on both sides; (wall seconds, HIP-event seconds)"""
+        torch, dev = self.torch, self.env.device
+        if self.dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        ev0.record(torch.cuda.current_stream(dev))  # the stream the step kernel is launched on
-        if chunks > 1 and graph:
-            buf.replay_marked(marked[chunks], env, chunks, gather=True, force=force_collective)
-        elif chunks > 1:  # host-issued variant (--no-graph, or capture failed): the side stream waits by event
-            for c in range(chunks):
-                buf.step_range(env, c * seg, (c + 1) * seg)
-                buf.gather_chunk(c, env=env, force=force_collective)
-            env.flush()
-        elif graph:
-            plain.replay()
-        else:
-            for t0_ in range(0, steps, T):
-                buf.step_range(env, 0, min(T, steps - t0_))
-            env.flush()  # pipelined fast-forwards: every step's outputs are complete from here on
+        ev0.record(torch.cuda.current_stream(dev))  # the stream the step kernels are launched on
+        for _ in range(reps):
+            fn()
         ev1.record(torch.cuda.current_stream(dev))
-        if chunks > 1:
-            buf.finish_gather()
-        elif tail_gather:
-            buf.all_gather(force=force_collective)  # collect boundary: one collective (no-op for a single rank)
-        if dist_on:
+        if self.dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
         return time.perf_counter() - t0, ev0.elapsed_time(ev1) * 1e-3
 
-    if collective and not (repeatable or not graph):  # the graph runs once: warm the collective up without it
-        chunks, prio = modes[0]
-        if chunks > 1:
-            buf.begin_gather(chunks, force=force_collective, priority=prio)
-            for c in range(chunks):
-                buf.gather_chunk(c, env=env, force=force_collective)
-            buf.finish_gather()
-        else:
-            buf.all_gather(force=force_collective)
-        torch.cuda.synchronize(dev)
-    elif collective:  # RCCL's first use of each collective shape (channels, buffers) stays outside the timed region; so does the tuning
-        trial = []
-        for mode in modes:
-            run(mode)
-            best = min(run(mode)[0] for _ in range(2)) if len(modes) > 1 else 0.0
-            trial.append(best)
-        if len(modes) > 1:
-            tt = torch.tensor(trial, dtype=torch.float64, device=dev)
-            if dist_on:
-                torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-            trial = [float(x) for x in tt.tolist()]
-            GRAPH_STATE["tuning"] = {"%d chunk%s, stream priority %d" % (c, "" if c == 1 else "s", p): round(x * 1e3, 3) for (c, p), x in zip(modes, trial)}
-            modes = [modes[trial.index(min(trial))]]
-    env.counters_reset()  # from here on the counters hold the timed steps only
-    wall, ev_s = run(modes[0])
-    GRAPH_STATE["chunks"], GRAPH_STATE["priority"] = modes[0]
-    if collective:  # after the clock: every rank must hold every shard, starting with its own
-        ok = torch.tensor([1.0 if buf.check_gathered() else 0.0], device=dev)
-        if dist_on:  # one verdict for all ranks: whatever follows, they do it together
-            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
-        GRAPH_STATE["gather_ok"] = bool(ok.item() > 0.5)
-    return wall, ev_s
+
+def warm_up(env, buf, warmup, period):
+    """W untimed steps, rounded up to whole episodes so that the rollout starts at an episode start"""
+    w = -(-warmup // period) * period
+    for t in range(w):
+        buf.step_into(env, t % buf.T)
+    env.flush()
+    return w
+
+
+def sweep_entry(kind, env_name, n, flags, pipeline, dev, seed, use_graph, torch):
+    """one N of the ladder: rollouts of 52 steps (26 from 1 M envs: memory), replayed until >= ~5 ms are timed"""
+    from tennisbot_rl_amd.params import ENV_SWING, default_params
+    from tennisbot_rl_amd.rollout import RolloutBuffer
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    T = 26 if n >= 1048576 else 52
+    e2 = BatchedEnv(kind, n, device=dev, seed=seed, params=default_params(flags=flags), track_terminal_obs=False, pipeline=pipeline)
+    b2 = RolloutBuffer(kind, T, n, dev)
+    b2.actions.uniform_(-1.0, 1.0)  # device RNG: a host PCG64 draw for 1 M envs would dominate the set-up
+    b2.bind(e2)
+    e2.reset()
+    warm_up(e2, b2, 26 if kind == ENV_SWING else 1040, 26 if kind == ENV_SWING else 1)  # Tennisbot: steady state, past the first episodes
+    r = Rollouts(e2, b2, torch, False, use_graph, 1)
+    r.prepare()
+    _, one = r.timed(r.run_once, 1)
+    reps = max(1, min(64, int(5e-3 / max(one, 1e-6)) + 1))
+    e2.counters_reset()
+    w, evs = r.timed(r.run_once, reps)
+    c = e2.counters()
+    ab = ALGO_BYTES[env_name]
+    k = T * reps
+    out = {"env": env_name, "envs": n, "steps_per_s": n * k / w, "launch_us": evs / k * 1e6, "rollout_steps": T, "rollouts_timed": reps,
+           "substeps_per_agent_step": c["substeps"] / (n * k),
+           "achieved_GBs": (ab["read"] + ab["write"]) * n / (evs / k) / 1e9, "read_GBs": ab["read"] * n / (evs / k) / 1e9}
+    out["frac"] = out["achieved_GBs"] / HBM_PEAK_GBS
+    out["read_frac"] = out["read_GBs"] / HBM_PEAK_GBS
+    e2.close()
+    del b2, r
+    torch.cuda.empty_cache()
+    return out
 
 
 def open_loop_rate(kind, N, flags, pipeline, dev, seed, torch):
@@ -234,6 +262,7 @@ def open_loop_rate(kind, N, flags, pipeline, dev, seed, torch):
     env.rollout(acts[:52] if pipeline else acts)  # Tennisbot: past the first (synchronised, cheaper) episodes
     env.flush()
     g = env.capture(lambda: env.rollout(acts))
+    g.replay()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     g.replay()
@@ -244,11 +273,32 @@ def open_loop_rate(kind, N, flags, pipeline, dev, seed, torch):
             "note": "tb_rollout: up to 26 agent steps per launch, actions known up front (not an RL loop; shows the cost of the per-step launch boundary)"}
 
 
-def cpu_baseline(kind_name, n_envs, seconds, seed):
+def reference_record():
+    """what the reference itself recorded: wall-clock of the last 100 PyBullet training episodes inside its shipped
+    ppo_swing.zip (exported as data by tools/export_reference_episode_stats.py). Not this host, not this workload shape
+    (1 env, SB3 policy inference + Monitor + numpy between steps): quoted for scale, never as the target."""
+    import numpy as np
+    try:
+        rec = json.load(open(os.path.join(ROOT, "tests", "golden", "ppo_swing_reference_episodes.json")))
+    except Exception:
+        return None
+    t = np.asarray(rec["episode_wallclock_s"], np.float64)
+    n = np.asarray(rec["episode_lengths"], np.float64)
+    dt = np.diff(t)
+    plain = (n[1:] == 26) & (dt < 3 * np.median(dt))  # episodes not interrupted by a PPO update or an evaluation
+    return {"agent_steps_per_s_collect": float(26.0 / np.median(dt[plain])), "agent_steps_per_s_overall": float(n[1:].sum() / (t[-1] - t[0])),
+            "episodes": int(t.size), "envs": 1,
+            "caveat": "the reference's own PyBullet run (SwingRacket-v0, DIRECT mode, 1 env, SB3 1.8.0 PPO on unnamed hardware): "
+                      "collect = 26 / median wall-clock per uninterrupted episode, includes SB3's per-step policy inference, Monitor and the "
+                      "per-episode world rebuild (4 loadURDF); overall also includes the PPO updates and EvalCallback episodes in between",
+            "source": "backup_models/ppo_swing.zip ep_info_buffer['t'] -> tests/golden/ppo_swing_reference_episodes.json"}
+
+
+def cpu_baseline(kind_name, n_envs, seconds, seed, flags):
     """the oracle (kind "port") on this host, same workload shape, bounded time"""
     import numpy as np
     from oracle import OracleBatch
-    from tennisbot_rl_amd.params import ENV_SWING, ENV_TENNIS, F_AUTO_RESET, F_DEFAULT, default_params
+    from tennisbot_rl_amd.params import ENV_SWING, ENV_TENNIS, F_AUTO_RESET, default_params
     kind = ENV_SWING if kind_name == "swing" else ENV_TENNIS
     A = 6 if kind_name == "swing" else 2
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -259,7 +309,7 @@ def cpu_baseline(kind_name, n_envs, seconds, seed):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("TB_CPU_THREADS", "16"))))
+    cores = max(1, min(cores, 16))
     out = {}
     try:  # the PyBullet path is the preferred baseline where it exists
         import pybullet  # noqa: F401
@@ -267,7 +317,7 @@ def cpu_baseline(kind_name, n_envs, seconds, seed):
     except ImportError:
         out["pybullet"] = "not importable on this host: CPU baseline is the float32 restatement (kind \"port\")"
     for label, threads in (("1core", 1), ("allcores", cores)):
-        b = OracleBatch(default_params(flags=F_DEFAULT | F_AUTO_RESET), kind, n_envs, seed=seed, precision="f32", threads=threads)
+        b = OracleBatch(default_params(flags=flags | F_AUTO_RESET), kind, n_envs, seed=seed, precision="f32", threads=threads)
         b.reset()
         done_steps, t0 = 0, time.perf_counter()
         while True:
@@ -277,8 +327,9 @@ def cpu_baseline(kind_name, n_envs, seconds, seed):
             el = time.perf_counter() - t0
             if el > seconds:
                 break
+        sub = float(b.counters()[6])
         out[label] = {"steps_per_s": done_steps * n_envs / el, "agent_steps": done_steps, "seconds": el,
-                      "substeps_per_s": float(b.counters()[6]) / el, "threads": threads}
+                      "substeps_per_s": sub / el, "substeps_per_agent_step": sub / (done_steps * n_envs), "threads": threads}
         b.close()
     return out
 
@@ -286,7 +337,7 @@ def cpu_baseline(kind_name, n_envs, seconds, seed):
 def main():
     args = parse()
     import torch
-    from tennisbot_rl_amd.params import ENV_SWING, ENV_TENNIS, F_DEFAULT, F_NET, default_params
+    from tennisbot_rl_amd.params import ENV_SWING, ENV_TENNIS, F_DEFAULT, F_NET, F_RACKET_GROUND, default_params
     from tennisbot_rl_amd.rollout import RolloutBuffer
     from tennisbot_rl_amd.stepper import BatchedEnv
 
@@ -319,9 +370,9 @@ def main():
             torch.distributed.init_process_group(backend="nccl", device_id=dev)
 
     kind = ENV_SWING if args.env == "swing" else ENV_TENNIS
+    period = 26 if kind == ENV_SWING else 1
     flags = F_NET if args.contact_off else F_DEFAULT
     if args.racket_ground:
-        from tennisbot_rl_amd.params import F_RACKET_GROUND
         flags |= F_RACKET_GROUND
     N = args.envs_per_gpu
     pipeline = kind == ENV_SWING and not args.no_pipeline
@@ -331,14 +382,14 @@ def main():
         ext.update(reference_rolling_friction())
     env = BatchedEnv(kind, N, device=dev, seed=args.seed, env_id_base=rank * N, params=default_params(flags=flags, **ext),
                      track_terminal_obs=False, pipeline=pipeline)
-    T_buf = min(args.steps, 1100)  # rollout length of the reference: n_steps = 1100 (train_swing.py:49-50)
-    buf = RolloutBuffer(kind, T_buf, N, dev)
+    T_roll = -(-max(1, args.rollout_steps) // period) * period
+    rollouts = -(-max(1, args.steps) // T_roll)
+    steps_timed = rollouts * T_roll
+    buf = RolloutBuffer(kind, T_roll, N, dev)
     fill_actions(buf.actions, args.seed + rank, torch)
     buf.bind(env)
     env.reset()
-    env.counters_reset()
-    use_graph = not args.no_graph
-    chunks = max(0, args.gather_chunks)
+    warmup_run = warm_up(env, buf, args.warmup, period)
     fake_us = float(os.environ.get("TB_BENCH_FAKE_GATHER_US", "0"))
     if fake_us > 0 and force_collective:
         # one-GPU rehearsal of the overlap: every exchange of the whole rollout is preceded, on the stream that
@@ -348,96 +399,127 @@ def main():
         e0.record(); torch.cuda._sleep(10_000_000); e1.record(); torch.cuda.synchronize(dev)
         cycles_per_us = 10_000_000 / (e0.elapsed_time(e1) * 1e3)
         buf.rehearsal_total_cycles = int(fake_us * cycles_per_us)
-    wall, ev_s = time_steps(env, buf, args.steps, args.warmup, torch, dist_on, graph=use_graph, gather_chunks=chunks, force_collective=force_collective)
-    gather_note = ""
-    if GRAPH_STATE["gather_ok"] is False and GRAPH_STATE["chunks"] > 1:
-        # never seen, but an overlapped exchange that delivered stale bytes must not cost the run: say so, fall back to ONE exchange
-        print("chunked exchange: the gathered rollout does not match the local shard; timing ONE all-gather instead", file=sys.stderr)
-        wall, ev_s = time_steps(env, buf, args.steps, 0, torch, dist_on, graph=use_graph, gather_chunks=1, force_collective=force_collective)
-    if GRAPH_STATE["gather_ok"] is False:
-        sys.exit("the gathered rollout does not match the local shard: result discarded")
-    if dist_on or force_collective:
-        gather_note = (", 1 RCCL all-gather of rollouts at the collect boundary" if GRAPH_STATE["chunks"] == 1 else
-                       ", rollouts all-gathered (RCCL) in %d step-chunks, each overlapped with the next chunk's steps%s" % (
-                           GRAPH_STATE["chunks"], " (one hipGraph, progress marks watched by the host)" if GRAPH_STATE["used"] else " (steps enqueued by tb_step_sequence)"))
-        if GRAPH_STATE["tuning"]:
-            gather_note += "; exchange form chosen on this node before the clock started, ms per K steps + exchange: %s" % json.dumps(GRAPH_STATE["tuning"])
+    R = Rollouts(env, buf, torch, dist_on, not args.no_graph, max(1, args.gather_chunks), force_collective)
+    R.prepare()
+    exch = None
+    if R.collective:  # measured apart, untimed: what the rollout and the exchange cost on their own
+        seen = torch.ones(1, device=dev)
+        if dist_on:
+            torch.distributed.all_reduce(seen)
+        r_wall, _ = R.timed(R.steps_only, 1)
+        x_wall, _ = R.timed(R.exchange_only, 1)
+        exch = {"ranks_seen": int(seen.item()), "bytes_per_rank": int(buf.nbytes), "rollout_ms": r_wall * 1e3, "exchange_ms": x_wall * 1e3,
+                "form": "%d step-chunks, each all-gathered on a high-priority side stream while later chunks step" % R.chunks if R.chunks > 1
+                        else "ONE all-gather after the rollout"}
+    env.counters_reset()  # from here on the counters hold the timed steps only
+    wall, ev_s = R.timed(R.run_once, rollouts)
+    gather_ok = True
+    if R.collective:  # after the clock: every rank must hold every shard, starting with its own
+        ok = torch.tensor([1.0 if buf.check_gathered() else 0.0], device=dev)
+        if dist_on:  # one verdict for all ranks: whatever follows, they do it together
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+        gather_ok = bool(ok.item() > 0.5)
     c = env.counters()
-    if c["nonfinite_states"]:
-        sys.exit("%d env states went non-finite or left the lockstep the pipelined kernels rely on: result discarded" % c["nonfinite_states"])
 
     wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
-    sub_t = torch.tensor([float(c["substeps"])], dtype=torch.float64, device=dev)
+    sub_t = torch.tensor([float(c["substeps"]), float(c["nonfinite_states"] + c["lockstep_violations"])], dtype=torch.float64, device=dev)
     if dist_on:
         torch.distributed.all_reduce(wall_t, op=torch.distributed.ReduceOp.MAX)
         torch.distributed.all_reduce(sub_t, op=torch.distributed.ReduceOp.SUM)
     wall_max = float(wall_t.item())
-    timed_substeps = float(sub_t.item())  # time_steps resets the counters right before the timed steps
+    timed_substeps, bad_states = float(sub_t[0].item()), float(sub_t[1].item())
 
     result = None
     if rank == 0:
         ab = ALGO_BYTES[args.env]
         per_launch_bytes = (ab["read"] + ab["write"]) * N
-        launch_s = ev_s / args.steps
+        launch_s = ev_s / steps_timed
         achieved = per_launch_bytes / launch_s / 1e9
         traffic = None if args.contact_off else pmc_traffic(args.env, N)
+        sps = timed_substeps / (world * N * steps_timed)
+        if exch is not None:
+            exch["exposed_exchange_ms"] = max(0.0, wall_max / rollouts * 1e3 - exch["rollout_ms"])
+            exch["note"] = R.note
+        gather_note = ("" if not R.collective else ", rollouts all-gathered (RCCL) in %d step-chunks overlapped with the steps (one hipGraph, progress marks watched by the host)" % R.chunks
+                       if R.chunks > 1 else ", 1 RCCL all-gather of the rollout at the collect boundary")
         result = {
             "metric": "env steps/sec (whole node), SwingRacket-v0 @4096 envs/GPU" if args.env == "swing" and N == 4096
                       else "env steps/sec (whole node), %s @%d envs/GPU" % ("SwingRacket-v0" if args.env == "swing" else "Tennisbot-v0", N),
-            "value": world * N * args.steps / wall_max,
+            "value": world * N * steps_timed / wall_max,
             "unit": "env steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": wall_max / args.steps * 1e3,
+            "steps_timed": steps_timed, "rollout_steps": T_roll, "rollouts_timed": rollouts, "warmup_run": warmup_run,
+            "timed_region_ms": wall_max * 1e3,
+            "ms_per_step": wall_max / steps_timed * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s, %d envs/GPU, %s, auto-reset, U(-1,1) actions, rollout buffer %d steps%s%s%s" % (
+            "config": {"workload": "%s, %d envs/GPU, %s, auto-reset, U(-1,1) actions, whole rollouts of %d agent steps (%s) each ended by the join of its fast-forwards%s%s%s" % (
                 "SwingRacket-v0" if args.env == "swing" else "Tennisbot-v0", N,
                 ("racket<->ball contact off (configs[1] bench mode)" if args.contact_off else "full contact semantics") + (" + racket<->court contact" if args.racket_ground else "")
                 + (" + rolling-friction rows" if args.rolling_friction else "")
                 + (" + Magnus k=%g, spin<=%g rad/s (extension, not in the reference)" % (args.magnus, args.spin_max) if (args.magnus or args.spin_max) else ""),
-                T_buf, ", fast-forward pipelined on side streams" if pipeline else "", ", K steps replayed as one hipGraph" if (use_graph and GRAPH_STATE["used"]) else "",
+                T_roll, "%d episodes" % (T_roll // 26) if kind == ENV_SWING else "steady state",
+                ", fast-forward pipelined on side streams" if pipeline else "", ", one hipGraph replay per rollout" if R.graph is not None else ", steps issued from the host",
                 gather_note),
                 "envs_per_gpu": N, "global_envs": world * N, "parallelism": "env-sharded x%d" % world},
             "substeps_per_s": timed_substeps / wall_max,
-            "substeps_per_agent_step": timed_substeps / (world * N * args.steps),
+            "substeps_per_agent_step": sps,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
                          "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic[1] if traffic else None,
                          "algorithmic_bytes_per_launch": per_launch_bytes,
                          "kernel": "tb_step_kernel<%d>" % kind, "launch_us": launch_s * 1e6,
                          "algorithmic_bytes_per_env_step": ab["read"] + ab["write"],
+                         "read_only": {"achieved": ab["read"] * N / launch_s / 1e9, "frac": ab["read"] * N / launch_s / 1e9 / HBM_PEAK_GBS,
+                                       "algorithmic_bytes_per_env_step": ab["read"], "note": "the HBM-READ roofline north_star words its 40 % target on"},
                          "note": "latency-bound at this batch size, not bandwidth-bound (see sweep / DESIGN.md)"},
             "parity": "bit-exact vs the CPU restatement; PyBullet parity unpinned at trajectory level (the reference ships no tests or golden vectors, PyBullet is not available offline), pinned statistically by the 100 PyBullet episodes recorded in the reference's ppo_swing.zip (DESIGN.md section 2)",
         }
-    if args.sweep and not dist_on:
+        if exch is not None:
+            result["exchange"] = exch
+        invalid = []
+        want = EXPECTED_SUBSTEPS.get((args.env, bool(args.racket_ground)))
+        if args.contact_off or args.magnus or args.spin_max or args.rolling_friction:
+            want = None  # other workloads than the headline's: reported, not judged
+        if want is not None and abs(sps / want - 1.0) > 0.05:
+            invalid.append("substeps per agent step %.3f, the workload's is %.3f: the timed region did not hold whole episodes" % (sps, want))
+        if bad_states:
+            invalid.append("%d env states went non-finite or left the lockstep the pipelined kernels rely on" % bad_states)
+        if not gather_ok:
+            invalid.append("the gathered rollout does not match the local shard")
+        if kind == ENV_SWING and steps_timed % 26:
+            invalid.append("steps_timed is not a whole number of episodes")
+        if invalid:
+            result["invalid"] = "; ".join(invalid)
+            result["value_refused"] = result["value"]
+            result["value"] = None
+    if not dist_on and not args.no_sweep and not force_collective:
+        ladder = [(args.env, n) for n in (4096, 32768, 262144, 1048576, 4194304)] if args.sweep else \
+                 [("swing", 4096), ("swing", 1048576), ("tennis", 4096), ("tennis", 1048576)]
         sweep = []
-        for n in (4096, 32768, 262144, 1048576, 4194304):
-            e2 = BatchedEnv(kind, n, device=dev, seed=args.seed, params=default_params(flags=flags), track_terminal_obs=False, pipeline=pipeline)
-            b2 = RolloutBuffer(kind, 26, n, dev)
-            fill_actions(b2.actions, args.seed, torch)
-            b2.bind(e2)
-            e2.reset()
-            k = 52 if n >= 1048576 else 104
-            w, evs = time_steps(e2, b2, k, 26 if kind == ENV_SWING else 1040, torch, False, tail_gather=False, graph=use_graph)  # Tennisbot: steady state, past the first episodes
-            ab = ALGO_BYTES[args.env]
-            sweep.append({"envs": n, "steps_per_s": n * k / w, "launch_us": evs / k * 1e6,
-                          "achieved_GBs": (ab["read"] + ab["write"]) * n / (evs / k) / 1e9})
-            e2.close()
-            del b2
-            torch.cuda.empty_cache()
+        for name, n in ladder:
+            k2 = ENV_SWING if name == "swing" else ENV_TENNIS
+            sweep.append(sweep_entry(k2, name, n, flags, k2 == ENV_SWING and not args.no_pipeline, dev, args.seed, not args.no_graph, torch))
         if result is not None:
             result["sweep"] = sweep
-            result["open_loop"] = open_loop_rate(kind, N, flags, pipeline, dev, args.seed, torch)
+            if args.sweep:
+                result["open_loop"] = open_loop_rate(kind, N, flags, pipeline, dev, args.seed, torch)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # a reported baseline, timed once, next to the 1-GPU figure
-        cb = cpu_baseline(args.env, N, args.cpu_seconds, args.seed)
+        cb = cpu_baseline(args.env, N, args.cpu_seconds, args.seed, flags)
         best = cb["allcores"]
         result["cpu_baseline"] = {
             "value": best["steps_per_s"], "unit": "env steps/s", "cores": best["threads"], "kind": "port",
             "sample": "float32 CPU oracle (oracle/tb_oracle.c, OpenMP over envs), %d envs x %d agent steps (whole 26-step episodes incl. fast-forward), %.1f s"
                       % (N, best["agent_steps"], best["seconds"]),
+            "substeps_per_agent_step": best["substeps_per_agent_step"],
             "value_1core": cb["1core"]["steps_per_s"], "substeps_per_s": best["substeps_per_s"], "pybullet": cb["pybullet"],
             "substeps_per_s_1core": cb["1core"]["substeps_per_s"],
+            "reference_record": reference_record() if args.env == "swing" else None,
         }
+        sps = result["substeps_per_agent_step"]
+        if kind == ENV_SWING and abs(sps / best["substeps_per_agent_step"] - 1.0) > 0.05 and result["value"] is not None:
+            result["invalid"] = "GPU leg %.3f substeps per agent step, CPU leg %.3f: not the same workload" % (sps, best["substeps_per_agent_step"])
+            result["value_refused"], result["value"] = result["value"], None
     if dist_on or force_collective:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

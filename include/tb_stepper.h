@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TB_ABI_VERSION 2
+#define TB_ABI_VERSION 3
 
 /* library error codes (negative); positive return values are hipError_t */
 #define TB_OK 0
@@ -153,6 +153,22 @@ typedef struct TbParams {
 
 typedef struct TbHandle TbHandle;
 
+/*
+ * Kernel-selection options (ABI v3; they replace the TB_BLOCK / TB_TENNIS_REG_ROWS / TB_SWING_REG_ROWS
+ * environment variables of v2). Every field: 0 = let the library choose from the batch size. None of
+ * them changes any result -- the variants are bit-identical (tests/test_gpu_parity.py runs them all) --
+ * only which instantiation of the same arithmetic is launched.
+ */
+typedef struct TbOptions {
+  uint32_t struct_size;     /* sizeof(TbOptions): lets a newer library read an older caller's struct */
+  int32_t block;            /* threads per workgroup of the step kernels: 64, 128 or 256 (auto: 64 up to 131072 envs, 256 above) */
+  int32_t tennis_reg_rows;  /* Tennisbot static contact rows in registers: 1 on, -1 off (auto: on) */
+  int32_t swing_reg_rows;   /* the same for the pipelined SwingRacket step kernel: 1 on, -1 off (auto: on up to 131072 envs) */
+  int32_t ff_lanes_per_wave; /* parked envs per wave of the fast-forward kernel, 1..64 (auto: spread n envs over the chip's SIMDs) */
+  int32_t ff_sort;          /* order parked envs by predicted flight length before the fast-forward: 1 on, -1 off (auto: on from 32768 envs) */
+  int32_t reserved[2];
+} TbOptions;
+
 /* library identity / shape queries (host only, no device touched) */
 int tb_abi_version(void);
 int tb_obs_dim(int env_kind);
@@ -169,15 +185,25 @@ const char *tb_last_error(void);
  * (seed, env_id_base + i, episode_index), so results do not depend on how a
  * global batch is sharded over GPUs.
  */
-int tb_create(const TbParams *params, int env_kind, int n_envs, int device, uint64_t seed,
-              uint64_t env_id_base, TbHandle **out);
+int tb_create(const TbParams *params, const TbOptions *options_or_null, int env_kind, int n_envs, int device,
+              uint64_t seed, uint64_t env_id_base, TbHandle **out);
 
 /* Replaces p.disconnect (swingracket_env.py:189, tennisbot_env.py:291). Synchronous. */
 int tb_destroy(TbHandle *h);
 
-/* Replace the parameter block (e.g. after set_racket_scale, tennisbot_env.py:213-215).
- * Takes effect for launches enqueued after it on `stream`. */
+/* Replace the parameter block. Takes effect for launches ENQUEUED after it on `stream`. The scalar
+ * parameters travel in the kernel-argument block of each launch, so a hipGraph captured earlier keeps
+ * the values it was captured with: tb_params_generation() goes up by one on every tb_set_params, and a
+ * caller that replays captured steps compares it with the value at capture time and recaptures when it
+ * differs (tennisbot_rl_amd.stepper.StepGraph does; a stale replay is refused, never silent). */
 int tb_set_params(TbHandle *h, const TbParams *params, void *stream);
+int tb_params_generation(TbHandle *h);
+/* set_racket_scale (tennisbot_env.py:213-215; the curriculum callback train.py:164-176 calls it at every
+ * rollout start): the globalScaling an env's racket is rebuilt with at ITS next reset. Unlike the rest of
+ * TbParams this value is read by the reset code from the device-resident parameter block, not from the
+ * kernel arguments: the update is one asynchronous 4-byte copy on `stream`, it does not bump
+ * tb_params_generation, and REPLAYS OF GRAPHS CAPTURED EARLIER SEE IT (row f2 under hipGraph replay). */
+int tb_set_racket_scale(TbHandle *h, float scale, void *stream);
 
 /*
  * reset(): swingracket_env.py:151-186 / tennisbot_env.py:217-261 for every env i with
@@ -283,20 +309,6 @@ int tb_policy_rollout(TbHandle *h, int n_steps, const float *weights_dev, const 
 int tb_set_pipeline(TbHandle *h, int enable);
 int tb_flush(TbHandle *h, void *stream);
 /*
- * Deferred fast-forwards (for callers that cut a rollout into several hipGraphs). A graph has to join
- * everything it forks, so a graph that ends right after an episode end would stall on a fast-forward
- * it has just started. With tb_set_defer(h, 1) the following tb_step calls still park their finished
- * episodes (obs/done returned at once, as always) but do not launch tb_ff_kernel; the parked lanes are
- * finished by the next tb_ff_launch_pending(h, stream) -- typically the first call inside the NEXT
- * graph, where the fast-forward then has that whole graph to overlap with -- or by tb_flush, or as soon
- * as their slot is needed again. tb_pipeline_join makes `stream` wait for the fast-forwards already
- * launched only (what a capture must do before it ends); tb_flush = launch pending + join, i.e. after
- * it every result is in place. Results are bit-identical in every mode.
- */
-int tb_set_defer(TbHandle *h, int on);
-int tb_ff_launch_pending(TbHandle *h, void *stream);
-int tb_pipeline_join(TbHandle *h, void *stream);
-/*
  * Progress marks (for callers that ship a rollout in chunks while ONE hipGraph is still producing it). A mark
  * tells the HOST that everything tb_step was asked to do before it is final in the caller's buffers -- the steps
  * themselves AND the late fast-forward writes they are still owed -- without making any stream wait for
@@ -326,6 +338,16 @@ long long tb_mark_count(TbHandle *h, int k);
  * ... tb_step x K ... tb_flush on the capturing stream, end the capture, then call with
  * host_wait = 0 (forget the capture-local events). */
 int tb_pipeline_sync(TbHandle *h, int host_wait);
+/* The host-side episode phase of a SwingRacket handle: agent steps since the last common reset, modulo 26
+ * (every episode is exactly 26 steps, swingracket_env.py:105-129), or -1 when the envs are not known to be
+ * in lockstep (masked reset, injected state whose step counters differ). The pipelined kernels use it to
+ * know which launch ends the episodes. A capture advances it by the captured steps although nothing ran:
+ * tb_pipeline_sync(h, 0) therefore puts it back to the value of the matching tb_pipeline_sync(h, 1), and
+ * whoever replays the captured steps calls tb_phase_advance(h, K) per replay -- after checking that
+ * tb_phase(h) is the phase the steps were captured at (a graph bakes in WHICH of its steps end an episode).
+ * tb_set_state re-derives the phase from the step-count row when every env agrees. */
+int tb_phase(TbHandle *h);
+int tb_phase_advance(TbHandle *h, int n_steps);
 /* After a capture that contained tb_step calls was ABANDONED (it failed, e.g. because something else
  * in it was not capturable): the handle's side streams were forked into that capture and stay
  * invalidated, and the host's episode-phase hint ran ahead of the device. Replaces the side streams
@@ -344,8 +366,11 @@ int tb_set_state(TbHandle *h, const uint32_t *words, const uint8_t *done, int on
  * stand-in for the reference's per-step prints (swingracket_env.py:102,115,124,129;
  * tennisbot_env.py:172,191,202). out[0] racket-ball contact substeps, [1] ball-court
  * terminations, [2] goal hits, [3] timeouts, [4] pass-racket terminations, [5] episodes
- * finished, [6] substeps, [7] non-finite state detections. Synchronises the stream. */
-#define TB_N_COUNTERS 8
+ * finished, [6] substeps, [7] non-finite state detections, [8] lockstep violations: lanes that reached
+ * an episode end in a launch the host had not given a fast-forward slot (only possible when a captured
+ * graph is replayed at another phase than it was captured at; their terminal reward is lost). Synchronises
+ * the stream. */
+#define TB_N_COUNTERS 9
 int tb_counters(TbHandle *h, uint64_t *out, void *stream);
 int tb_counters_reset(TbHandle *h, void *stream);
 

@@ -148,8 +148,11 @@ TB_DEV void load_actions(const float* actions, size_t row, float* a) {
 
 // reset(): swingracket_env.py:151-186 / tennisbot_env.py:217-261. The world rebuild
 // (resetSimulation + 3-4 loadURDF + STL hull + texture) collapses to re-drawing the state.
+// `KP`: the device-resident copy of the parameter block (LDS in the step kernels, global memory in the reset
+// kernel). The racket scale is read from THERE, not from the kernel arguments: tb_set_racket_scale updates it
+// with a stream-ordered store, so replays of a hipGraph captured earlier see the curriculum (train.py:164-176).
 template <int KIND>
-TB_DEV void reset_env(const KArgs& A, int i, EnvRegs& e) {
+TB_DEV void reset_env(const KArgs& A, const float4* KP, int i, EnvRegs& e) {
   const KParams& P = A.P;
   unsigned long long id = A.env_id_base + (unsigned long long)i;
   uint32_t k0 = (uint32_t)A.seed, k1 = (uint32_t)(A.seed >> 32);
@@ -178,7 +181,7 @@ TB_DEV void reset_env(const KArgs& A, int i, EnvRegs& e) {
     float x = uniform(7.5f, 5.0f, u[0]), y = uniform(-5.0f, 10.0f, u[1]), z = uniform(0.2f, 0.21f - 0.2f, u[2]);
     quat q0; q0.x = 0.0f; q0.y = 0.0f; q0.z = 0.0f; q0.w = 1.0f;
     e.r.q = q0;
-    e.aux[3] = P.racket_scale;  // Racket(..., scale=self.racket_scale), tennisbot_env.py:230-234
+    e.aux[3] = reinterpret_cast<const KParams*>(KP)->racket_scale;  // Racket(..., scale=self.racket_scale), tennisbot_env.py:230-234
     e.r.p = mk(x, y, z) + e.aux[3] * com;
     e.aux[0] = uniform(25.0f, 12.5f, u[3]);
     e.aux[1] = uniform(-10.0f, 20.0f, w[0]);
@@ -413,7 +416,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
             store_env<TB_ENV_SWING>(A.ff_words, A.ff_flag, A.n, i, e, true);
             A.ff_flag[i] = 1;
           } else {
-            cnt[7]++;  // lockstep invariant broken (see launch_step): reported, never silent
+            cnt[8]++;  // lockstep invariant broken (see launch_step): reported, never silent
           }
           d = true;
         }
@@ -429,7 +432,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
         cnt[5]++;
         if (A.term_obs && !parked) write_obs<KIND>(A.term_obs, (size_t)i, o);
         e.episode += 1u;
-        reset_env<KIND>(A, i, e);
+        reset_env<KIND>(A, s_hull + TB_HULL_KP, i, e);
         make_obs<KIND>(e, o);
         any_reset = true;
       }
@@ -545,7 +548,7 @@ __global__ void __launch_bounds__(320) tb_policy_rollout_kernel(KArgs A) {
             store_env<TB_ENV_SWING>(A.ff_words, A.ff_flag, A.n, i, e, true);
             A.ff_flag[i] = 1;
           } else {
-            cnt[7]++;  // lockstep invariant broken (see launch_policy_rollout): reported, never silent
+            cnt[8]++;  // lockstep invariant broken (see launch_policy_rollout): reported, never silent
           }
           d = true;
         }
@@ -559,7 +562,7 @@ __global__ void __launch_bounds__(320) tb_policy_rollout_kernel(KArgs A) {
       if (d) {  // (rollouts require TB_F_AUTO_RESET)
         cnt[5]++;
         e.episode += 1u;
-        reset_env<KIND>(A, i, e);
+        reset_env<KIND>(A, s_hull + TB_HULL_KP, i, e);
         make_obs<KIND>(e, o);
         any_reset = true;
       }
@@ -582,6 +585,9 @@ __global__ void __launch_bounds__(320) tb_policy_rollout_kernel(KArgs A) {
 __global__ void tb_mark_kernel(unsigned long long* count) {
   __hip_atomic_fetch_add(count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+
+// tb_set_racket_scale: one stream-ordered 4-byte store into the device-resident parameter block
+__global__ void tb_poke_kernel(float* dst, float v) { *dst = v; }
 
 // finishes parked SwingRacket fast-forwards (side stream): same device code as the in-step loop
 template <bool RG>
@@ -628,7 +634,7 @@ __global__ void __launch_bounds__(256) tb_reset_kernel(KArgs A) {
   if (A.mask && !A.mask[i]) return;
   EnvRegs e;
   e.episode = A.words[(size_t)(Dims<KIND>::W - 1) * A.n + i] + 1u;
-  reset_env<KIND>(A, i, e);
+  reset_env<KIND>(A, A.hull + TB_HULL_KP, i, e);
   store_env<KIND>(A.words, A.done_state, A.n, i, e, true);
   if (A.obs) {
     float o[Dims<KIND>::O];
@@ -744,10 +750,11 @@ void to_kparams(const TbParams* p, KParams* k, float* planes) {
 
 }  // namespace
 
-#define TB_FF_SLOTS 8  // parked-state buffers + side streams: ~2.5 fast-forwards are in flight in steady state, up to 3 more are deferred across a graph boundary
+#define TB_FF_SLOTS 8  // parked-state buffers + side streams: ~2.5 fast-forwards are in flight in steady state
 
 struct TbHandle {
   int device, kind, n, block;
+  TbOptions opt;  // as given to tb_create (0 = auto)
   int reg_rows;  // Tennisbot step kernel with the static contact rows in registers
   int swing_reg_rows;  // the same for the pipelined SwingRacket step kernel (+2.7 % at 4096 envs; NOT for tb_ff_kernel)
   uint64_t seed, env_id_base;
@@ -762,10 +769,8 @@ struct TbHandle {
   // pipelined fast-forward
   int pipeline;            // enabled by tb_set_pipeline
   int phase, phase_valid;  // agent steps since the last full reset (SwingRacket episodes are exactly 26 steps)
-  int phase_at_capture, phase_valid_at_capture;  // snapshot taken by tb_pipeline_sync(h, 1), see tb_pipeline_recover
-  // deferred fast-forwards (tb_set_defer): parked, not yet launched
-  int defer, n_pending, n_pending_at_capture;
-  struct Pending { KArgs a; int slot; const void *term, *sub; } pending[TB_FF_SLOTS], pending_at_capture[TB_FF_SLOTS];
+  int phase_at_capture, phase_valid_at_capture;  // snapshot taken by tb_pipeline_sync(h, 1), restored by tb_pipeline_sync(h, 0) / tb_pipeline_recover
+  int params_generation;   // tb_set_params count: captured launches carry the parameter block they were captured with
   hipStream_t side[TB_FF_SLOTS];  // one stream per slot: consecutive fast-forwards overlap each other too
   const void *last_term, *last_sub;  // shared late-written buffers force ordering between fast-forwards
   int last_slot;
@@ -797,9 +802,8 @@ int ensure_marks(TbHandle* h) {
 
 // small batches: one wave per workgroup so the waves spread over as many CUs as possible
 // (4096 envs = 64 waves -> 64 CUs); large batches: 256-thread workgroups amortise the LDS staging
-int pick_block(int n) {
-  const char* env = getenv("TB_BLOCK");
-  if (env) { int b = atoi(env); if (b == 64 || b == 128 || b == 256) return b; }
+int pick_block(int n, const TbOptions& o) {
+  if (o.block == 64 || o.block == 128 || o.block == 256) return o.block;
   return n <= 131072 ? 64 : 256;
 }
 
@@ -855,21 +859,8 @@ int launch_ff(TbHandle* h, int slot, const KArgs& a, const void* term, const voi
   return TB_OK;
 }
 
-// launch every deferred fast-forward (oldest first), ordered after what `s` holds so far
-int launch_pending(TbHandle* h, hipStream_t s) {
-  for (int i = 0; i < h->n_pending; ++i) {
-    const TbHandle::Pending& p = h->pending[i];
-    if (int rc = launch_ff(h, p.slot, p.a, p.term, p.sub, s)) return rc;
-  }
-  h->n_pending = 0;
-  return TB_OK;
-}
-
-// every result of every fast-forward, parked or running, is in place once `s` gets past this point
-int flush_all(TbHandle* h, hipStream_t s) {
-  if (int rc = launch_pending(h, s)) return rc;
-  return wait_side(h, s);
-}
+// every result of every fast-forward is in place once `s` gets past this point
+int flush_all(TbHandle* h, hipStream_t s) { return wait_side(h, s); }
 
 struct PolicyIO {  // non-null weights = fused policy step
   const float* weights; const float* obs_in; float* actions; float* raw; float* logp; float* value;
@@ -900,8 +891,6 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
   if (may_park) {
     slot = h->next_slot;
     h->next_slot = (slot + 1) % TB_FF_SLOTS;
-    for (int i = 0; i < h->n_pending; ++i)  // the slot still holds lanes whose fast-forward was deferred: it cannot wait any longer
-      if (h->pending[i].slot == slot) { if (int rc = launch_pending(h, s)) return rc; break; }
     if (h->ff_busy[slot]) HIP_TRY(hipStreamWaitEvent(s, h->ev_ff[slot], 0));  // slot still in use by an older fast-forward
     a.defer = 1; a.ff_words = h->d_ff_words[slot]; a.ff_flag = h->d_ff_flag[slot];
   }
@@ -941,12 +930,7 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
   HIP_TRY(hipGetLastError());
   if (may_park) {
     if (T > 1) a.reward = reward + (size_t)(T - 1) * h->n;  // the fast-forward owes its reward to the step that parked: the last one
-    if (h->defer) {  // tb_set_defer: park now, finish when the caller says so (tb_ff_launch_pending / tb_flush)
-      TbHandle::Pending& p = h->pending[h->n_pending++];  // (a slot is never parked into twice: n_pending <= TB_FF_SLOTS)
-      p.a = a; p.slot = slot; p.term = term; p.sub = substeps;
-    } else if (int rc = launch_ff(h, slot, a, term, substeps, s)) {
-      return rc;
-    }
+    if (int rc = launch_ff(h, slot, a, term, substeps, s)) return rc;
   }
   if (h->phase_valid) h->phase = (h->phase + T) % 26;
   return TB_OK;
@@ -966,8 +950,6 @@ int launch_policy_rollout(TbHandle* h, int T, const PolicyIO& pol, float* obs, f
   if (may_park) {
     slot = h->next_slot;
     h->next_slot = (slot + 1) % TB_FF_SLOTS;
-    for (int i = 0; i < h->n_pending; ++i)
-      if (h->pending[i].slot == slot) { if (int rc = launch_pending(h, s)) return rc; break; }
     if (h->ff_busy[slot]) HIP_TRY(hipStreamWaitEvent(s, h->ev_ff[slot], 0));
     a.defer = 1; a.ff_words = h->d_ff_words[slot]; a.ff_flag = h->d_ff_flag[slot];
   }
@@ -978,12 +960,7 @@ int launch_policy_rollout(TbHandle* h, int T, const PolicyIO& pol, float* obs, f
   HIP_TRY(hipGetLastError());
   if (may_park) {
     a.reward = reward + (size_t)(T - 1) * st[5];  // the fast-forward owes its reward to the step that parked: the last one
-    if (h->defer) {
-      TbHandle::Pending& p = h->pending[h->n_pending++];
-      p.a = a; p.slot = slot; p.term = nullptr; p.sub = nullptr;
-    } else if (int rc = launch_ff(h, slot, a, nullptr, nullptr, s)) {
-      return rc;
-    }
+    if (int rc = launch_ff(h, slot, a, nullptr, nullptr, s)) return rc;
   }
   if (h->phase_valid) h->phase = (h->phase + T) % 26;
   return TB_OK;
@@ -999,12 +976,20 @@ int tb_act_dim(int k) { return k == TB_ENV_SWING ? TB_SWING_ACT_DIM : k == TB_EN
 int tb_state_words(int k) { return kind_ok(k) ? words_of(k) : TB_E_INVAL; }
 const char* tb_last_error(void) { return g_err; }
 
-int tb_create(const TbParams* params, int env_kind, int n_envs, int device, uint64_t seed, uint64_t env_id_base, TbHandle** out) {
+int tb_create(const TbParams* params, const TbOptions* options, int env_kind, int n_envs, int device, uint64_t seed, uint64_t env_id_base, TbHandle** out) {
   if (!params || !out) return fail(TB_E_INVAL, "tb_create: null argument");
   *out = nullptr;
   if (!kind_ok(env_kind)) return fail(TB_E_INVAL, "tb_create: unknown env kind");
   if (n_envs <= 0 || n_envs > (1 << 26)) return fail(TB_E_INVAL, "tb_create: n_envs must be in [1, 2^26]");
   if (int rc = validate_params(params)) return rc;
+  TbOptions opt;
+  memset(&opt, 0, sizeof opt);
+  if (options) {  // a caller built against an older (shorter) TbOptions leaves the newer fields at "auto"
+    if (options->struct_size < sizeof(uint32_t) || options->struct_size > 4096) return fail(TB_E_INVAL, "tb_create: TbOptions.struct_size is not set");
+    memcpy(&opt, options, options->struct_size < sizeof opt ? options->struct_size : sizeof opt);
+    if (opt.block != 0 && opt.block != 64 && opt.block != 128 && opt.block != 256) return fail(TB_E_INVAL, "tb_create: TbOptions.block must be 0, 64, 128 or 256");
+    if (opt.ff_lanes_per_wave < 0 || opt.ff_lanes_per_wave > 64) return fail(TB_E_INVAL, "tb_create: TbOptions.ff_lanes_per_wave must be in [0, 64]");
+  }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) return fail(TB_E_NODEVICE, "tb_create: no HIP device available (this library has no CPU fallback)");
@@ -1015,15 +1000,13 @@ int tb_create(const TbParams* params, int env_kind, int n_envs, int device, uint
   TbHandle* h = (TbHandle*)calloc(1, sizeof(TbHandle));
   if (!h) return fail(TB_E_INVAL, "tb_create: out of host memory");
   h->device = device; h->kind = env_kind; h->n = n_envs; h->seed = seed; h->env_id_base = env_id_base;
-  h->params = *params; to_kparams(params, &h->kp, &h->cull_planes[0][0]); h->block = pick_block(n_envs);
-  {  // Tennisbot, measured in the steady state (envs past their first, synchronised episodes): +28 % at 4096 envs,
-     // +8 % at 256 K, +16 % at 1 M, +12 % at 4 M; only the contact-free first episode after a common reset, where the
-     // kernel runs at 70 % of HBM peak and occupancy counts, loses 3 % at 1 M envs
-    const char* rr = getenv("TB_TENNIS_REG_ROWS");
-    h->reg_rows = env_kind == TB_ENV_TENNIS && (rr ? atoi(rr) != 0 : 1);
-    const char* sr = getenv("TB_SWING_REG_ROWS");
-    h->swing_reg_rows = env_kind == TB_ENV_SWING && (sr ? atoi(sr) != 0 : n_envs <= 131072);
-  }
+  h->params = *params; to_kparams(params, &h->kp, &h->cull_planes[0][0]); h->block = pick_block(n_envs, opt);
+  h->opt = opt;
+  // Tennisbot, measured in the steady state (envs past their first, synchronised episodes): +28 % at 4096 envs,
+  // +8 % at 256 K, +16 % at 1 M, +12 % at 4 M; only the contact-free first episode after a common reset, where the
+  // kernel runs at 70 % of HBM peak and occupancy counts, loses 3 % at 1 M envs
+  h->reg_rows = env_kind == TB_ENV_TENNIS && (opt.tennis_reg_rows ? opt.tennis_reg_rows > 0 : 1);
+  h->swing_reg_rows = env_kind == TB_ENV_SWING && (opt.swing_reg_rows ? opt.swing_reg_rows > 0 : n_envs <= 131072);
   const int nw = words_of(env_kind);
   hipError_t err;
 #define CREATE_TRY(expr) if ((err = (expr)) != hipSuccess) { int rc = fail((int)err, #expr); tb_destroy(h); return rc; }
@@ -1096,8 +1079,8 @@ int tb_pipeline_sync(TbHandle* h, int host_wait) {
   if (host_wait) {
     h->ff_cap = 0;
     h->phase_at_capture = h->phase; h->phase_valid_at_capture = h->phase_valid;
-    h->n_pending_at_capture = h->n_pending;
-    memcpy(h->pending_at_capture, h->pending, sizeof h->pending);
+  } else {  // the captured tb_step calls advanced the host's episode phase, but none of them ran: the replays will (tb_phase_advance)
+    h->phase = h->phase_at_capture; h->phase_valid = h->phase_valid_at_capture;
   }
   return TB_OK;
 }
@@ -1108,8 +1091,6 @@ int tb_pipeline_recover(TbHandle* h) {
   (void)hipGetLastError();  // the abandoned capture leaves a sticky hipErrorStreamCaptureInvalidated behind
   // the captured tb_step calls advanced the host's episode phase, but none of them ran
   h->phase = h->phase_at_capture; h->phase_valid = h->phase_valid_at_capture;
-  h->n_pending = h->n_pending_at_capture;  // parks deferred by the abandoned capture never happened; older ones did
-  memcpy(h->pending, h->pending_at_capture, sizeof h->pending);
   for (int k = 0; k < TB_FF_SLOTS; ++k) {
     h->ff_busy[k] = 0;
     if (!h->side[k]) continue;
@@ -1133,17 +1114,15 @@ int tb_flush(TbHandle* h, void* stream) {
   return flush_all(h, (hipStream_t)stream);
 }
 
-int tb_set_defer(TbHandle* h, int on) {
-  if (!h) return fail(TB_E_INVAL, "tb_set_defer: null handle");
-  if (on && !h->pipeline) return fail(TB_E_UNSUPPORTED, "tb_set_defer needs tb_set_pipeline(h, 1)");
-  h->defer = on ? 1 : 0;
-  return TB_OK;
+int tb_phase(TbHandle* h) {
+  if (!h) return fail(TB_E_INVAL, "tb_phase: null handle");
+  return h->phase_valid ? h->phase : -1;
 }
 
-int tb_ff_launch_pending(TbHandle* h, void* stream) {
-  if (!h) return fail(TB_E_INVAL, "tb_ff_launch_pending: null handle");
-  DeviceGuard g(h->device);
-  return launch_pending(h, (hipStream_t)stream);
+int tb_phase_advance(TbHandle* h, int n_steps) {
+  if (!h || n_steps < 0) return fail(TB_E_INVAL, "tb_phase_advance: bad argument");
+  if (h->phase_valid) h->phase = (h->phase + n_steps) % 26;
+  return TB_OK;
 }
 
 int tb_mark_record(TbHandle* h, int k, void* stream) {
@@ -1151,7 +1130,6 @@ int tb_mark_record(TbHandle* h, int k, void* stream) {
   DeviceGuard g(h->device);
   hipStream_t s = (hipStream_t)stream;
   if (!h->marks_on) return fail(TB_E_UNSUPPORTED, "tb_mark_record needs tb_mark_enable(h, 1) before the steps it covers (their fast-forwards must be counted)");
-  if (int rc = launch_pending(h, s)) return rc;  // parked lanes owe rewards to the steps this mark covers
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   HIP_TRY(hipStreamIsCapturing(s, &st));
   hipLaunchKernelGGL(tb_mark_kernel, dim3(1), dim3(1), 0, s, h->h_marks + k);
@@ -1200,12 +1178,6 @@ int tb_mark_host_wait(TbHandle* h, int k, int timeout_ms) {
   }
 }
 
-int tb_pipeline_join(TbHandle* h, void* stream) {
-  if (!h) return fail(TB_E_INVAL, "tb_pipeline_join: null handle");
-  DeviceGuard g(h->device);
-  return wait_side(h, (hipStream_t)stream);
-}
-
 int tb_set_params(TbHandle* h, const TbParams* params, void* stream) {
   if (!h || !params) return fail(TB_E_INVAL, "tb_set_params: null argument");
   if (int rc = validate_params(params)) return rc;
@@ -1219,6 +1191,23 @@ int tb_set_params(TbHandle* h, const TbParams* params, void* stream) {
   to_kparams(params, &h->kp, &h->cull_planes[0][0]);
   if (int rc = upload_hull(h, s)) return rc;
   HIP_TRY(hipStreamSynchronize(s));
+  h->params_generation++;
+  return TB_OK;
+}
+
+int tb_params_generation(TbHandle* h) {
+  if (!h) return fail(TB_E_INVAL, "tb_params_generation: null handle");
+  return h->params_generation;
+}
+
+int tb_set_racket_scale(TbHandle* h, float scale, void* stream) {
+  if (!h) return fail(TB_E_INVAL, "tb_set_racket_scale: null handle");
+  if (!(scale > 0.0f)) return fail(TB_E_PARAMS, "tb_set_racket_scale: scale must be positive");
+  DeviceGuard g(h->device);
+  h->params.racket_scale = scale; h->kp.racket_scale = scale;  // what a later tb_set_params re-uploads
+  float* dst = reinterpret_cast<float*>(h->d_hull + TB_HULL_KP) + offsetof(KParams, racket_scale) / sizeof(float);
+  hipLaunchKernelGGL(tb_poke_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dst, scale);
+  HIP_TRY(hipGetLastError());
   return TB_OK;
 }
 
@@ -1357,6 +1346,25 @@ int tb_set_state(TbHandle* h, const uint32_t* words, const uint8_t* done, int on
   HIP_TRY(hipMemcpyAsync(h->d_words, words, wb, k, s));
   if (done) HIP_TRY(hipMemcpyAsync(h->d_done, done, (size_t)h->n, k, s));
   else HIP_TRY(hipMemsetAsync(h->d_done, 0, (size_t)h->n, s));
+  if (h->kind == TB_ENV_SWING) {
+    // the pipelined kernels need to know which launch ends the episodes: the injected envs are in lockstep again
+    // when every one is running (done = 0) at the same step count s < 26 -- then the phase is s (e.g. a checkpoint
+    // of a training run restored into a fresh handle). Costs one small device-to-host copy; this call is rare.
+    const size_t n = (size_t)h->n;
+    uint32_t* steps = (uint32_t*)malloc(n * sizeof(uint32_t));
+    uint8_t* dn = (uint8_t*)malloc(n);
+    if (!steps || !dn) { free(steps); free(dn); return fail(TB_E_INVAL, "tb_set_state: out of host memory"); }
+    hipError_t e1 = hipMemcpyAsync(steps, h->d_words + (size_t)TB_W_SW_STEP * n, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    hipError_t e2 = e1 == hipSuccess ? hipMemcpyAsync(dn, h->d_done, n, hipMemcpyDeviceToHost, s) : e1;
+    hipError_t e3 = e2 == hipSuccess ? hipStreamSynchronize(s) : e2;
+    if (e3 == hipSuccess) {
+      bool same = (int32_t)steps[0] >= 0 && (int32_t)steps[0] < 26;
+      for (size_t i = 0; same && i < n; ++i) same = steps[i] == steps[0] && dn[i] == TB_DONE_NO;
+      if (same) { h->phase_valid = 1; h->phase = (int)steps[0]; }
+    }
+    free(steps); free(dn);
+    if (e3 != hipSuccess) return fail((int)e3, "tb_set_state: reading back the step counters");
+  }
   if (!on_device) HIP_TRY(hipStreamSynchronize(s));
   return TB_OK;
 }

@@ -26,9 +26,9 @@ F_DEFAULT = F_NET | F_RACKET_BALL
 
 DONE_NO, DONE_PENDING_FORCE, DONE_YES = 0, 1, 2
 
-N_COUNTERS = 8
+N_COUNTERS = 9
 COUNTER_NAMES = ("racket_ball_contact_substeps", "ball_court_terminations", "goal_hits", "timeouts",
-                 "pass_racket_terminations", "episodes_finished", "substeps", "nonfinite_states")
+                 "pass_racket_terminations", "episodes_finished", "substeps", "nonfinite_states", "lockstep_violations")
 
 OBS_DIM = {ENV_SWING: 6, ENV_TENNIS: 12}
 ACT_DIM = {ENV_SWING: 6, ENV_TENNIS: 2}
@@ -75,6 +75,25 @@ class TbParams(ctypes.Structure):
         """CCW (y, z) hull vertices in the COM frame at scale 1, as the kernels see them."""
         e = np.ctypeslib.as_array(self.hull_edges)[: self.n_hull]
         return e[:, :2].astype(np.float64)
+
+
+class TbOptions(ctypes.Structure):
+    """kernel-selection options of tb_create (include/tb_stepper.h, ABI v3): 0 = the library chooses.
+    They never change a result, only which bit-identical instantiation runs."""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("block", ctypes.c_int32), ("tennis_reg_rows", ctypes.c_int32),
+                ("swing_reg_rows", ctypes.c_int32), ("ff_lanes_per_wave", ctypes.c_int32), ("ff_sort", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 2)]
+
+
+def make_options(block=0, tennis_reg_rows=None, swing_reg_rows=None, ff_lanes_per_wave=0, ff_sort=None):
+    """None = auto; True / False force a variant on / off"""
+    def tri(x):
+        return 0 if x is None else (1 if x else -1)
+    o = TbOptions()
+    o.struct_size = ctypes.sizeof(TbOptions)
+    o.block, o.tennis_reg_rows, o.swing_reg_rows = int(block), tri(tennis_reg_rows), tri(swing_reg_rows)
+    o.ff_lanes_per_wave, o.ff_sort = int(ff_lanes_per_wave), tri(ff_sort)
+    return o
 
 
 def load_scene(path=_ASSETS):

@@ -17,7 +17,7 @@ import numpy as np
 
 from .params import ACT_DIM, ENV_SWING, OBS_DIM
 from .rollout import RolloutBuffer
-from .stepper import ENV_IDS, BatchedEnv
+from .stepper import ENV_IDS, BatchedEnv, StepperError
 
 # hyper-parameters of the reference scripts (and SB3 1.8.0 defaults where they are silent)
 SWING_DEFAULTS = dict(net_arch=(32, 64, 32), ent_coef=0.002, learning_rate=3e-4)   # train_swing.py:80-91
@@ -175,6 +175,12 @@ class PPOTrainer:
         self.last_value = torch.zeros(num_envs, device=self.device)
         self.obs_in = self.env.reset().clone()  # static input of the (captured) rollout
         self.use_graph, self._graph = bool(graph), None
+        if self.use_graph and self.env.pipeline and self.n_steps % 26:
+            # a pipelined SwingRacket graph bakes in which of its steps end an episode: it can only be replayed back
+            # to back when the rollout is a whole number of 26-step episodes. The reference's n_steps = 1100
+            # (train_swing.py:49-50) is not: such rollouts are issued eagerly -- with whole episodes per launch
+            # (tb_policy_rollout) that is 43 launches + 43 fast-forwards per 1100 steps, nothing a graph would save
+            self.use_graph = False
         self.num_timesteps = 0
         # fused=True: the policy runs inside the step kernel (tb_policy_step); the torch module is
         # then only the learner's view of the same weights, repacked once per rollout
@@ -197,12 +203,14 @@ class PPOTrainer:
         n, O, A = self.num_envs, env.obs_dim, env.act_dim
         wp, cur = self.packed.data_ptr(), self.obs_in.data_ptr()
         self.obs_seq[0].copy_(self.obs_in)
-        if self.rollout_launch:
+        # whole-episode launches need the library to know the episode phase (every env restored / reset in lockstep)
+        by_launch = self.rollout_launch and (not env.pipeline or env.phase() >= 0)
+        if by_launch:
             rec = buf.record
             env.policy_rollout_ptrs(self.n_steps, wp, cur, buf.actions[0].data_ptr(), self._raw_actions.data_ptr(), self.logps.data_ptr(),
                                     self.values.data_ptr(), buf.obs[0].data_ptr(), buf.rewards[0].data_ptr(), buf.dones[0].data_ptr(),
                                     (rec, 0, 0, 0, rec, rec, rec), self.noise_seed)
-        for k in range(0 if self.rollout_launch else self.n_steps):
+        for k in range(0 if by_launch else self.n_steps):
             obs_k = buf.obs[k]
             # exploration noise is keyed by (seed, env, episode, step) inside the kernel: replaying
             # the captured graph draws fresh noise because episodes / steps advance
@@ -244,21 +252,19 @@ class PPOTrainer:
         if self.fused:
             pack_policy(self.policy, out=self.packed)
         with t.no_grad():
-            if self.use_graph and self._graph is None:
-                try:
-                    self._collect_body()  # warm-up on the real stream (allocator, lazy inits)
-                    t.cuda.synchronize(self.device)
-                    self.num_timesteps += self.n_steps * self.num_envs * self.world
-                    self._graph = self.env.capture(self._collect_body)
-                    return self.last_value
-                except Exception as exc:  # noqa: BLE001 - any capture problem means: run eagerly
-                    print("hipGraph capture of the rollout failed (%s); collecting eagerly" % exc)
-                    self.use_graph = False
-                    return self.last_value
+            if self._graph is not None and not self._graph.valid():
+                self._graph = None  # the envs are at another episode phase (load(), evaluate()) or set_params() ran: capture again
             if self._graph is not None:
                 self._graph.replay()
             else:
-                self._collect_body()
+                self._collect_body()  # a real rollout on the real stream; its errors are the caller's to see
+                if self.use_graph:
+                    t.cuda.synchronize(self.device)
+                    try:
+                        self._graph = self.env.capture(self._collect_body)  # runs nothing; replayed from the next collect on
+                    except (StepperError, RuntimeError) as exc:  # the capture itself failed: the rollout above stands, go on eagerly
+                        print("hipGraph capture of the rollout failed (%s); collecting eagerly" % exc)
+                        self.use_graph = False
         self.num_timesteps += self.n_steps * self.num_envs * self.world
         return self.last_value
 
@@ -319,6 +325,10 @@ class PPOTrainer:
             stats = self.update(adv, returns)
             self.torch.cuda.synchronize(self.device)
             t2 = time.perf_counter()
+            c = self.env.counters()
+            if c["nonfinite_states"] or c["lockstep_violations"]:
+                raise StepperError("rollout %d: %d env states went non-finite, %d episode ends fell outside the pipelined launches' slots "
+                                   "(their terminal rewards are lost)" % (len(history), c["nonfinite_states"], c["lockstep_violations"]))
             ep = float(self.buf.dones.sum())
             stats.update(timesteps=self.num_timesteps, episodes=ep,
                          mean_episode_reward=float(self.buf.rewards.sum()) / max(ep, 1.0),

@@ -11,9 +11,8 @@ Packed layout per rank: T per-step records, each `obs f32 [N][O] | act f32 [N][A
 done u8 [N]` (every part padded to 16 B), so any range of steps is one contiguous byte range:
 the whole buffer goes out in ONE all-gather, and begin_gather / gather_chunk / finish_gather can
 instead ship it in a few step-chunks from a side stream while later steps are still being computed
-(capture_marked keeps the rollout ONE hipGraph and tells the host when each chunk is final; capture_chunks,
-the older form, cuts it into one hipGraph per chunk). n_steps defaults
-to the reference's 1100 (train_swing.py:49-50).
+(capture_marked keeps the rollout ONE hipGraph and tells the host when each chunk is final). n_steps
+defaults to the reference's 1100 (train_swing.py:49-50).
 """
 import numpy as np
 
@@ -83,42 +82,6 @@ class RolloutBuffer:
         rec = self.record
         env.step_sequence_ptrs(t1 - t0, a, o, r, d, (rec, rec, rec, rec))
 
-    def capture_chunks(self, env, n_chunks, defer_window=52):
-        """The T steps of this buffer as n_chunks hipGraphs (+ a tail graph), for exchanging the
-        rollout chunk by chunk while it is still being produced. A graph must join what it forks, so
-        a chunk that ended right after an episode end would stall on the fast-forward it just
-        started: episode ends within the last `defer_window` steps of a chunk (default 2 episodes;
-        measured best at 4096 envs: a wider window parks more fast-forwards, and three or more of
-        them starting together at the head of the next graph slow each other and the steps) are parked
-        (BatchedEnv.set_defer) and their fast-forwards launched as the first node of the NEXT graph,
-        which they then overlap with. Chunk c is therefore complete when graph c+1 is (the tail
-        graph completes the last one). Returns (graphs, tail); tail is None without a pipeline."""
-        if getattr(self, "_bound", None) is not env:
-            raise ValueError("capture_chunks needs bind(env) first")
-        if self.T % n_chunks:
-            raise ValueError("n_steps %d is not divisible into %d chunks" % (self.T, n_chunks))
-        seg, piped = self.T // n_chunks, bool(getattr(env, "pipeline", False))
-        graphs = []
-        for c in range(n_chunks):
-            def body(c=c):
-                lo, hi = c * seg, (c + 1) * seg
-                if not piped:
-                    self.step_range(env, lo, hi)
-                    return
-                env.launch_pending()
-                cut = max(lo, hi - int(defer_window))
-                if cut > lo:
-                    self.step_range(env, lo, cut)
-                if hi > cut:
-                    env.set_defer(True)
-                    try:
-                        self.step_range(env, cut, hi)
-                    finally:
-                        env.set_defer(False)
-            graphs.append(env.capture(body, join_only=piped))
-        tail = env.capture(lambda: None) if piped else None  # capture() ends with flush(): launch what is parked, join
-        return graphs, tail
-
     def capture_marked(self, env, n_chunks):
         """The T steps of this buffer as ONE hipGraph with a progress mark (BatchedEnv.mark) after each of
         n_chunks step-chunks: the graph keeps its shape and speed -- a mark is one tiny kernel in the step
@@ -151,19 +114,6 @@ class RolloutBuffer:
             for c in range(n_chunks):
                 env.mark_host_wait(c)
                 self.gather_chunk(c, force=force, after_mark=True)
-
-    def replay_chunks(self, graphs, tail, gather=False, force=False):
-        """replay capture_chunks' graphs in order; gather=True issues each chunk's all-gather
-        (begin_gather(len(graphs)) first) as soon as the graph that completes it is enqueued"""
-        lag = 1 if tail is not None else 0
-        for c, g in enumerate(graphs):
-            g.replay()
-            if gather and c >= lag:
-                self.gather_chunk(c - lag, force=force)
-        if tail is not None:
-            tail.replay()
-            if gather:
-                self.gather_chunk(len(graphs) - 1, force=force)
 
     def _world(self, group):
         dist = self.torch.distributed

@@ -15,11 +15,11 @@ import os
 import numpy as np
 
 from .params import (ACT_DIM, COUNTER_NAMES, ENV_SWING, ENV_TENNIS, F_AUTO_RESET, N_COUNTERS, OBS_DIM,
-                     STATE_ROWS, STATE_WORDS, TbParams, default_params)
+                     STATE_ROWS, STATE_WORDS, TbOptions, TbParams, default_params, make_options)
 
-# TB_STEPPER_LIB: another build of the same ABI (diagnostic builds, A/B timing); never a different implementation
-_LIB_PATH = os.environ.get("TB_STEPPER_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtb_stepper.so")
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtb_stepper.so")
 _LIB = None
+ABI_VERSION = 3
 
 ENV_IDS = {"SwingRacket-v0": ENV_SWING, "Tennisbot-v0": ENV_TENNIS}  # tennisbot/__init__.py:3-11
 
@@ -30,6 +30,16 @@ class StepperError(RuntimeError):
 
 def lib_path():
     return _LIB_PATH
+
+
+def use_library(path):
+    """Load another BUILD of the same sources instead of the in-tree one (the -DTB_DIAG_* diagnostic builds of
+    tools/diag_*.py). An explicit call before the first BatchedEnv, not an environment variable: nothing
+    outside the caller's own code can redirect the product path."""
+    global _LIB_PATH, _LIB
+    if _LIB is not None:
+        raise StepperError("use_library() must be called before the library is first loaded")
+    _LIB_PATH = os.path.abspath(path)
 
 
 def load_library():
@@ -48,7 +58,7 @@ def load_library():
     L.tb_act_dim.argtypes = [i32]
     L.tb_state_words.argtypes = [i32]
     L.tb_last_error.restype = ctypes.c_char_p
-    L.tb_create.argtypes = [ctypes.POINTER(TbParams), i32, i32, i32, u64, u64, ctypes.POINTER(vp)]
+    L.tb_create.argtypes = [ctypes.POINTER(TbParams), ctypes.POINTER(TbOptions), i32, i32, i32, u64, u64, ctypes.POINTER(vp)]
     L.tb_destroy.argtypes = [vp]
     L.tb_set_params.argtypes = [vp, ctypes.POINTER(TbParams), vp]
     L.tb_reset.argtypes = [vp, vp, vp, vp]
@@ -72,12 +82,14 @@ def load_library():
     L.tb_policy_floats.restype = i32
     L.tb_policy_step.argtypes = [vp] * 10 + [u64, i32, vp]
     L.tb_policy_step.restype = i32
-    L.tb_set_defer.argtypes = [vp, i32]
-    L.tb_set_defer.restype = i32
-    L.tb_ff_launch_pending.argtypes = [vp, vp]
-    L.tb_ff_launch_pending.restype = i32
-    L.tb_pipeline_join.argtypes = [vp, vp]
-    L.tb_pipeline_join.restype = i32
+    L.tb_phase.argtypes = [vp]
+    L.tb_phase.restype = i32
+    L.tb_phase_advance.argtypes = [vp, i32]
+    L.tb_phase_advance.restype = i32
+    L.tb_params_generation.argtypes = [vp]
+    L.tb_params_generation.restype = i32
+    L.tb_set_racket_scale.argtypes = [vp, ctypes.c_float, vp]
+    L.tb_set_racket_scale.restype = i32
     L.tb_pipeline_recover.argtypes = [vp]
     L.tb_pipeline_recover.restype = i32
     L.tb_mark_record.argtypes = [vp, i32, vp]
@@ -95,8 +107,8 @@ def load_library():
     for f in ("tb_create", "tb_destroy", "tb_set_params", "tb_reset", "tb_step", "tb_rollout", "tb_get_state",
               "tb_set_state", "tb_counters", "tb_counters_reset", "tb_obs_dim", "tb_act_dim", "tb_state_words"):
         getattr(L, f).restype = i32
-    if L.tb_abi_version() != 2:
-        raise StepperError("libtb_stepper.so ABI version %d, expected 2" % L.tb_abi_version())
+    if L.tb_abi_version() != ABI_VERSION:
+        raise StepperError("libtb_stepper.so ABI version %d, expected %d" % (L.tb_abi_version(), ABI_VERSION))
     for kind in (ENV_SWING, ENV_TENNIS):
         assert L.tb_obs_dim(kind) == OBS_DIM[kind] and L.tb_act_dim(kind) == ACT_DIM[kind]
         assert L.tb_state_words(kind) == STATE_WORDS[kind]
@@ -107,6 +119,42 @@ def load_library():
 def _check(L, rc, what):
     if rc != 0:
         raise StepperError("%s failed (%d): %s" % (what, rc, L.tb_last_error().decode()))
+
+
+class StepGraph:
+    """K captured agent steps of one BatchedEnv (BatchedEnv.capture). replay() runs them with one launch --
+    after checking what a captured launch cannot check for itself:
+      * the parameter block travels in the kernel arguments, so a graph captured before set_params() would
+        step with the old parameters: refused (recapture); set_racket_scale() is exempt, the kernels read
+        the scale from device memory;
+      * a pipelined SwingRacket graph bakes in WHICH of its steps end an episode (and fork a fast-forward):
+        it is only valid from the episode phase it was captured at. K % 26 != 0, or steps taken outside the
+        graph in between, move the phase: refused, instead of episode ends falling into launches that have
+        no fast-forward slot (their terminal rewards would be lost, counters()['lockstep_violations'])."""
+
+    def __init__(self, env, graph, n_steps, phase, generation):
+        self.env, self.graph, self.n_steps, self.phase, self.generation = env, graph, int(n_steps), phase, generation
+
+    @property
+    def repeatable(self):
+        return self.phase < 0 or self.n_steps % 26 == 0
+
+    def valid(self):
+        """may replay() run now? (same parameter block, same episode phase as at capture time)"""
+        env = self.env
+        return env.L.tb_params_generation(env._h) == self.generation and (self.phase < 0 or env.L.tb_phase(env._h) == self.phase)
+
+    def replay(self):
+        env = self.env
+        if env.L.tb_params_generation(env._h) != self.generation:
+            raise StepperError("this graph was captured before set_params(): its launches carry the old parameter block; capture it again")
+        if self.phase >= 0:
+            now = env.L.tb_phase(env._h)
+            if now != self.phase:
+                raise StepperError("this graph was captured at episode phase %d and can only be replayed from there; the envs are at phase %d "
+                                   "(captured steps %% 26 = %d; or steps were taken outside the graph)" % (self.phase, now, self.n_steps % 26))
+        self.graph.replay()
+        _check(env.L, env.L.tb_phase_advance(env._h, self.n_steps), "tb_phase_advance")
 
 
 class BatchedEnv:
@@ -120,7 +168,7 @@ class BatchedEnv:
     """
 
     def __init__(self, env_kind, num_envs, device=None, seed=0, env_id_base=0, params=None, auto_reset=True,
-                 reuse_buffers=False, track_terminal_obs=True, pipeline=False):
+                 reuse_buffers=False, track_terminal_obs=True, pipeline=False, options=None):
         import torch
         self.torch = torch
         if isinstance(env_kind, str):
@@ -145,8 +193,11 @@ class BatchedEnv:
         self.auto_reset = bool(auto_reset)
         self.reuse_buffers = bool(reuse_buffers)
         self._h = ctypes.c_void_p()
-        _check(self.L, self.L.tb_create(ctypes.byref(p), env_kind, self.num_envs, self.device.index, self.seed,
+        # options: a TbOptions, or a dict of make_options() keywords (kernel variants; results never depend on them)
+        self.options = options if isinstance(options, TbOptions) else make_options(**(options or {}))
+        _check(self.L, self.L.tb_create(ctypes.byref(p), ctypes.byref(self.options), env_kind, self.num_envs, self.device.index, self.seed,
                                         self.env_id_base, ctypes.byref(self._h)), "tb_create")
+        self._steps_issued = 0  # agent steps asked of the library so far (capture() measures its K with it)
         n, o = self.num_envs, self.obs_dim
         self._term = torch.zeros((n, o), dtype=torch.float32, device=self.device) if (auto_reset and track_terminal_obs) else None
         self._substeps = torch.zeros(n, dtype=torch.int32, device=self.device)
@@ -231,6 +282,7 @@ class BatchedEnv:
         _check(self.L, self.L.tb_step(self._h, a.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(),
                                       None if self._term is None else self._term.data_ptr(),
                                       None if self.pipeline else self._substeps.data_ptr(), self._stream()), "tb_step")
+        self._steps_issued += 1
         if self.pipeline and out is None:
             self._inflight.append(rew)  # keep the late-written buffer alive until flush()
             if len(self._inflight) > 4096:
@@ -244,6 +296,7 @@ class BatchedEnv:
                             self.torch.cuda.current_stream(self.device).cuda_stream)
         if rc:
             _check(self.L, rc, "tb_step")
+        self._steps_issued += 1
 
     def step_sequence_ptrs(self, n_steps, actions_ptr, obs_ptr, reward_ptr, done_ptr, strides):
         """n_steps consecutive steps from ONE host call (tb_step_sequence): step t uses the four
@@ -253,6 +306,7 @@ class BatchedEnv:
                                      strides[0], strides[1], strides[2], strides[3], self.torch.cuda.current_stream(self.device).cuda_stream)
         if rc:
             _check(self.L, rc, "tb_step_sequence")
+        self._steps_issued += int(n_steps)
 
     def policy_floats(self):
         """length of the packed MlpPolicy blob tb_policy_step expects for this env kind"""
@@ -292,11 +346,7 @@ class BatchedEnv:
                                    int(seed) & 0xFFFFFFFFFFFFFFFF, 1 if deterministic else 0, self.torch.cuda.current_stream(self.device).cuda_stream)
         if rc:
             _check(self.L, rc, "tb_policy_step")
-
-    def set_defer(self, on):
-        """pipelined mode: park finished episodes without launching their fast-forward until
-        launch_pending() / flush() (tb_set_defer; for rollouts cut into several graphs)"""
-        _check(self.L, self.L.tb_set_defer(self._h, 1 if on else 0), "tb_set_defer")
+        self._steps_issued += 1
 
     def mark(self, k):
         """progress mark k (tb_mark_record) at the current stream's position: a counter in pinned host memory goes
@@ -328,10 +378,6 @@ class BatchedEnv:
         enqueued before it have finished"""
         _check(self.L, self.L.tb_mark_host_wait(self._h, int(k), int(timeout_ms)), "tb_mark_host_wait")
 
-    def launch_pending(self):
-        """launch the deferred fast-forwards on the side streams, ordered after the current stream"""
-        _check(self.L, self.L.tb_ff_launch_pending(self._h, self._stream()), "tb_ff_launch_pending")
-
     def policy_rollout_ptrs(self, n_steps, weights_ptr, obs_in_ptr, act_ptr, raw_ptr, logp_ptr, value_ptr, obs_ptr, reward_ptr, done_ptr,
                             strides_bytes, seed, deterministic=False):
         """n_steps of policy_step_ptrs in as few launches as the episodes allow (tb_policy_rollout): the
@@ -343,6 +389,7 @@ class BatchedEnv:
                                       st, int(seed) & 0xFFFFFFFFFFFFFFFF, 1 if deterministic else 0, self.torch.cuda.current_stream(self.device).cuda_stream)
         if rc:
             _check(self.L, rc, "tb_policy_rollout")
+        self._steps_issued += int(n_steps)
 
     def policy_rollout(self, weights, obs_in, n_steps, seed=0, deterministic=False):
         """T = n_steps agent steps with the MlpPolicy inside the kernel, whole episodes per launch.
@@ -359,26 +406,26 @@ class BatchedEnv:
             self._inflight.append(rew)
         return (obs, rew, done), (act, raw, logp, value)
 
-    def capture(self, fn, join_only=False):
+    def capture(self, fn):
         """Capture `fn()` -- a fixed sequence of step()/step_ptrs()/RolloutBuffer.step_into calls on
-        fixed buffers -- into a HIP graph and return it; `graph.replay()` then runs the whole
-        sequence with one launch (no per-step host work). In pipelined mode the side-stream
-        fast-forwards are captured as forked branches and joined by the final flush().
-        join_only=True: the capture ends by joining the fast-forwards it launched but leaves the
-        deferred ones (set_defer) parked for the next graph."""
+        fixed buffers -- into a HIP graph and return it as a StepGraph; `graph.replay()` then runs the
+        whole sequence with one launch (no per-step host work). In pipelined mode the side-stream
+        fast-forwards are captured as forked branches and joined by the final flush(). Nothing runs
+        during the capture: the env (and the library's episode phase) are where they were, and the
+        first replay() is the first time the steps happen."""
         t = self.torch
         t.cuda.current_stream(self.device).synchronize()
         _check(self.L, self.L.tb_pipeline_sync(self._h, 1), "tb_pipeline_sync")
+        phase = self.L.tb_phase(self._h) if self.pipeline else -1
+        gen = self.L.tb_params_generation(self._h)
+        issued = self._steps_issued
         g = t.cuda.CUDAGraph()
         try:
             # thread_local: other threads (e.g. the RCCL watchdog of torch.distributed) may keep
             # issuing HIP calls while this thread captures
             with t.cuda.graph(g, capture_error_mode="thread_local"):
                 fn()
-                if join_only:
-                    _check(self.L, self.L.tb_pipeline_join(self._h, self._stream()), "tb_pipeline_join")
-                else:
-                    self.flush()
+                self.flush()
         except BaseException:
             # nothing captured ever ran; put the handle's streams and phase hint back (the env is intact)
             try:
@@ -386,9 +433,11 @@ class BatchedEnv:
             except Exception:  # the capture error may surface once more through torch
                 pass
             self.L.tb_pipeline_recover(self._h)
+            self._steps_issued = issued
             raise
-        _check(self.L, self.L.tb_pipeline_sync(self._h, 0), "tb_pipeline_sync")
-        return g
+        _check(self.L, self.L.tb_pipeline_sync(self._h, 0), "tb_pipeline_sync")  # also puts the phase back: nothing ran
+        n_steps, self._steps_issued = self._steps_issued - issued, issued
+        return StepGraph(self, g, n_steps, phase, gen)
 
     def flush(self):
         """Pipelined mode: make the current stream wait until every outstanding fast-forward has
@@ -406,6 +455,7 @@ class BatchedEnv:
         obs, rew, done = self._out(T)
         _check(self.L, self.L.tb_rollout(self._h, T, a.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(),
                                          None if self.pipeline else self._substeps.data_ptr(), self._stream()), "tb_rollout")
+        self._steps_issued += T
         if self.pipeline:
             self._inflight.append(rew)  # terminal rewards are written late, from the side streams: flush() before reading
         return obs, rew, done
@@ -444,10 +494,14 @@ class BatchedEnv:
     def set_racket_scale(self, scale):
         """tennisbot_env.py:213-215: takes effect at the next reset of each env (the reference
         rebuilds the racket with globalScaling=scale in reset(), :230-234); every env keeps the
-        scale of its current episode in its own state word."""
-        p = self.params.copy()
-        p.racket_scale = float(scale)
-        self.set_params(p)
+        scale of its current episode in its own state word. One stream-ordered store into the
+        device-resident parameter block (tb_set_racket_scale): graphs captured earlier see it."""
+        _check(self.L, self.L.tb_set_racket_scale(self._h, float(scale), self._stream()), "tb_set_racket_scale")
+        self.params.racket_scale = float(scale)
+
+    def phase(self):
+        """agent steps since the last common reset modulo 26, or -1 when the envs are not in lockstep"""
+        return int(self.L.tb_phase(self._h))
 
     # ------------------------------------------------------------------ state save / restore
     def get_state_words(self):

@@ -8,7 +8,7 @@ import subprocess
 
 import pytest
 
-from tennisbot_rl_amd.params import ACT_DIM, ENV_SWING, ENV_TENNIS, OBS_DIM, STATE_WORDS, TbParams, default_params
+from tennisbot_rl_amd.params import ACT_DIM, ENV_SWING, ENV_TENNIS, OBS_DIM, STATE_WORDS, TbOptions, TbParams, default_params, make_options
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "tb_stepper.h")
@@ -42,21 +42,23 @@ def test_shape_queries_match_python_mirror(lib):
     assert lib.tb_obs_dim(7) < 0 and lib.tb_state_words(-1) < 0
 
 
-def test_tbparams_layout_matches_header(tmp_path):
-    """sizeof / offsetof from the C compiler == the ctypes mirror"""
-    fields = [f[0] for f in TbParams._fields_]
+@pytest.mark.parametrize("struct", [TbParams, TbOptions])
+def test_struct_layouts_match_header(tmp_path, struct):
+    """sizeof / offsetof from the C compiler == the ctypes mirrors (TbParams, TbOptions)"""
+    name = struct.__name__
+    fields = [f[0] for f in struct._fields_]
     prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % HEADER, "int main(void){",
-            'printf("%zu\\n", sizeof(TbParams));']
-    prog += ['printf("%%zu\\n", offsetof(TbParams, %s));' % f for f in fields]
+            'printf("%%zu\\n", sizeof(%s));' % name]
+    prog += ['printf("%%zu\\n", offsetof(%s, %s));' % (name, f) for f in fields]
     prog += ["return 0;}"]
     c = tmp_path / "layout.c"
     c.write_text("\n".join(prog))
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-o", str(exe), str(c)])
     out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
-    assert out[0] == ctypes.sizeof(TbParams)
+    assert out[0] == ctypes.sizeof(struct)
     for f, off in zip(fields, out[1:]):
-        assert getattr(TbParams, f).offset == off, f
+        assert getattr(struct, f).offset == off, f
 
 
 def test_no_device_means_loud_failure_not_fallback(lib):
@@ -65,7 +67,7 @@ def test_no_device_means_loud_failure_not_fallback(lib):
         pytest.skip("a GPU is present")
     h = ctypes.c_void_p()
     p = default_params()
-    rc = lib.tb_create(ctypes.byref(p), ENV_SWING, 16, 0, 0, 0, ctypes.byref(h))
+    rc = lib.tb_create(ctypes.byref(p), None, ENV_SWING, 16, 0, 0, 0, ctypes.byref(h))
     assert rc == -2 and not h  # TB_E_NODEVICE
     assert b"no CPU fallback" in lib.tb_last_error()
     from tennisbot_rl_amd.stepper import BatchedEnv, StepperError
@@ -76,12 +78,20 @@ def test_no_device_means_loud_failure_not_fallback(lib):
 def test_bad_arguments_are_rejected(lib):
     h = ctypes.c_void_p()
     p = default_params()
-    assert lib.tb_create(ctypes.byref(p), 5, 16, 0, 0, 0, ctypes.byref(h)) == -1
-    assert lib.tb_create(ctypes.byref(p), ENV_SWING, 0, 0, 0, 0, ctypes.byref(h)) == -1
+    assert lib.tb_create(ctypes.byref(p), None, 5, 16, 0, 0, 0, ctypes.byref(h)) == -1
+    assert lib.tb_create(ctypes.byref(p), None, ENV_SWING, 0, 0, 0, 0, ctypes.byref(h)) == -1
     bad = default_params()
     bad.n_hull = 2
-    assert lib.tb_create(ctypes.byref(bad), ENV_SWING, 16, 0, 0, 0, ctypes.byref(h)) == -3
+    assert lib.tb_create(ctypes.byref(bad), None, ENV_SWING, 16, 0, 0, 0, ctypes.byref(h)) == -3
     assert b"n_hull" in lib.tb_last_error()
+    # kernel-selection options travel through the ABI (v3), not through environment variables
+    assert lib.tb_abi_version() == 3
+    o = make_options(block=96)
+    assert lib.tb_create(ctypes.byref(p), ctypes.byref(o), ENV_SWING, 16, 0, 0, 0, ctypes.byref(h)) == -1 and b"block" in lib.tb_last_error()
+    o = TbOptions()  # struct_size left at 0
+    assert lib.tb_create(ctypes.byref(p), ctypes.byref(o), ENV_SWING, 16, 0, 0, 0, ctypes.byref(h)) == -1 and b"struct_size" in lib.tb_last_error()
+    src = "".join(open(os.path.join(ROOT, "tennisbot_rl_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "tennisbot_rl_amd", "csrc")))
+    assert "getenv" not in src
     assert lib.tb_step(None, None, None, None, None, None, None, None) == -1
     assert lib.tb_destroy(None) == 0
 

@@ -12,8 +12,8 @@ REQUIRED = {"metric": str, "value": float, "unit": str, "n_gpus": int, "steps": 
 
 
 def run_bench(*extra):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "52", "--warmup", "26", *extra],
-                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "52", "--warmup", "20", *extra],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, "bench.py must print exactly one line on stdout, got %d" % len(lines)
@@ -21,37 +21,54 @@ def run_bench(*extra):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [("--cpu-seconds", "1"), ("--env", "tennis", "--no-cpu-baseline"), ("--no-graph", "--no-pipeline", "--no-cpu-baseline")])
+@pytest.mark.parametrize("extra", [("--cpu-seconds", "1"), ("--env", "tennis", "--no-cpu-baseline", "--no-sweep"),
+                                   ("--no-graph", "--no-pipeline", "--no-cpu-baseline", "--no-sweep", "--rollout-steps", "104")])
 def test_bench_json_contract(extra):
     d = run_bench(*extra)
     for k, t in REQUIRED.items():
         assert k in d, k
         assert isinstance(d[k], t) or (t is float and isinstance(d[k], int)), (k, type(d[k]))
-    assert d["n_gpus"] == 1 and d["steps"] == 52 and d["warmup"] == 26 and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and d["steps"] == 52 and d["warmup"] == 20 and d["vs_baseline"] is None
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "f32" and d["data"] == "synthetic"
-    assert "workload" in d["config"] and "model" not in d["config"]
-    assert abs(d["value"] - 4096 * 52 / (d["ms_per_step"] * 52e-3)) / d["value"] < 1e-6
+    assert "workload" in d["config"] and "model" not in d["config"] and "invalid" not in d
+    # K = 52 is rounded up to whole rollouts (whole episodes): what is timed is the headline workload whatever K says
+    T = d["rollout_steps"]
+    assert d["steps_timed"] == T * d["rollouts_timed"] >= 52 and T == (104 if "--rollout-steps" in extra else 1040)
+    assert abs(d["value"] - 4096 * d["steps_timed"] / (d["ms_per_step"] * d["steps_timed"] * 1e-3)) / d["value"] < 1e-6
+    swing = "tennis" not in extra
+    if swing:
+        assert d["steps_timed"] % 26 == 0 and d["warmup_run"] == 26 and abs(d["substeps_per_agent_step"] / 5.09 - 1) < 0.05
+        assert d["timed_region_ms"] >= 5.0 or T == 104
+    else:
+        assert d["substeps_per_agent_step"] == 1.0
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
+    assert 0 < r["read_only"]["frac"] < r["frac"]
     if "cpu_baseline" in d:
         c = d["cpu_baseline"]
         assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["unit"] == "env steps/s"
+        assert abs(c["substeps_per_agent_step"] / d["substeps_per_agent_step"] - 1) < 0.05   # GPU and CPU legs run the same workload
+        rr = c["reference_record"]
+        assert 100 < rr["agent_steps_per_s_collect"] < 400 and rr["agent_steps_per_s_overall"] < rr["agent_steps_per_s_collect"]
+    if "--no-sweep" not in extra:
+        sw = {(e["env"], e["envs"]): e for e in d["sweep"]}
+        assert set(sw) == {("swing", 4096), ("swing", 1048576), ("tennis", 4096), ("tennis", 1048576)}
+        assert all(0 < e["read_frac"] < e["frac"] < 1 for e in sw.values())
+        assert abs(sw[("swing", 1048576)]["substeps_per_agent_step"] / 5.09 - 1) < 0.05
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("steps,expect_tuning", [("208", True), ("200", False)])
-def test_bench_exchange_forms_with_one_rank(steps, expect_tuning):
+@pytest.mark.parametrize("chunks", ["8", "1"])
+def test_bench_exchange_forms_with_one_rank(chunks):
     """the multi-rank exchange path rehearsed with a single rank (TB_BENCH_FORCE_COLLECTIVE=1: RCCL is initialised and every
-    collective is issued): with K a whole number of episodes the three exchange forms are tried and one is timed; otherwise
-    the pipelined graph can run only once, nothing is tuned, and the single all-gather is timed"""
+    collective is issued): the chunked, overlapped form (default) and the single all-gather, with the diagnostics an N > 1 line carries"""
     env = dict(os.environ, TB_BENCH_FORCE_COLLECTIVE="1", TB_BENCH_FAKE_GATHER_US="1000")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", steps, "--warmup", "26", "--no-cpu-baseline"],
-                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "208", "--rollout-steps", "208", "--warmup", "26", "--no-cpu-baseline",
+                          "--gather-chunks", chunks], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
-    w = d["config"]["workload"]
-    assert d["value"] > 0 and "all-gather" in w
-    assert ("exchange form chosen on this node" in w) == expect_tuning
-    if not expect_tuning:
-        assert "1 RCCL all-gather of rollouts at the collect boundary" in w
+    w, x = d["config"]["workload"], d["exchange"]
+    assert d["value"] > 0 and "invalid" not in d and "all-gather" in w
+    assert x["ranks_seen"] == 1 and x["bytes_per_rank"] > 208 * 4096 * 53 and x["rollout_ms"] > 0 and x["exchange_ms"] > 0.9 and x["exposed_exchange_ms"] >= 0
+    assert ("step-chunks" in x["form"]) == (chunks == "8") and not x["note"]

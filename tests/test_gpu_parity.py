@@ -27,11 +27,11 @@ def torch():
     return torch
 
 
-def make_pair(torch, kind, n, seed=11, auto_reset=True, env_id_base=0, **over):
+def make_pair(torch, kind, n, seed=11, auto_reset=True, env_id_base=0, options=None, **over):
     from tennisbot_rl_amd.stepper import BatchedEnv
     flags = over.pop("flags", F_DEFAULT)
     p = default_params(flags=flags, **over)
-    env = BatchedEnv(kind, n, device="cuda:0", seed=seed, env_id_base=env_id_base, params=p, auto_reset=auto_reset)
+    env = BatchedEnv(kind, n, device="cuda:0", seed=seed, env_id_base=env_id_base, params=p, auto_reset=auto_reset, options=options)
     pf = p.copy()
     pf.flags = (pf.flags | F_AUTO_RESET) if auto_reset else (pf.flags & ~F_AUTO_RESET)
     ref = OracleBatch(pf, kind, n, seed=seed, env_id_base=env_id_base, precision="f32")
@@ -99,11 +99,10 @@ def test_swing_lockstep_ragged_sizes(torch, n):
     env.close()
 
 
-@pytest.mark.parametrize("n,reg_rows", [(1, "1"), (65, "1"), (4096, "1"), (65, "0"), (4096, "0")])
-def test_tennis_lockstep(torch, n, reg_rows, monkeypatch):
-    # both builds of the Tennisbot step kernel: static contact rows in registers (small batches) / in scratch
-    monkeypatch.setenv("TB_TENNIS_REG_ROWS", reg_rows)
-    env, ref = make_pair(torch, ENV_TENNIS, n)
+@pytest.mark.parametrize("n,reg_rows", [(1, True), (65, True), (4096, True), (65, False), (4096, False)])
+def test_tennis_lockstep(torch, n, reg_rows):
+    # both builds of the Tennisbot step kernel (TbOptions.tennis_reg_rows): static contact rows in registers / in scratch
+    env, ref = make_pair(torch, ENV_TENNIS, n, options=dict(tennis_reg_rows=reg_rows))
     # 1010 steps: past the 1000-step timeout (tennisbot_env.py:201-203), so every env finishes at least once
     run_lockstep(torch, env, ref, 1010, np.random.default_rng(100 + n), "tennis n=%d" % n, check_state_every=50)
     c = env.counters()
@@ -147,10 +146,11 @@ def test_tennis_without_auto_reset(torch):
     env.close()
 
 
-def test_contact_off_bench_mode(torch):
-    """BASELINE configs[1]: racket-only dynamics, racket<->ball pair disabled"""
-    env, ref = make_pair(torch, ENV_SWING, 1024, flags=F_NET)
-    run_lockstep(torch, env, ref, 27, np.random.default_rng(7), "swing contact-off")
+@pytest.mark.parametrize("n", [1024, 4096])
+def test_contact_off_bench_mode(torch, n):
+    """BASELINE configs[1]: racket-only dynamics, racket<->ball pair disabled -- at the config's own 4096 envs too"""
+    env, ref = make_pair(torch, ENV_SWING, n, flags=F_NET)
+    run_lockstep(torch, env, ref, 27, np.random.default_rng(7), "swing contact-off n=%d" % n)
     assert env.counters()["racket_ball_contact_substeps"] == 0
     env.close()
 
@@ -589,19 +589,18 @@ def test_float32_drift_vs_float64_truth(torch):
     assert np.array_equal(g["step_count"], c["step_count"])
 
 
-@pytest.mark.parametrize("n,reg_rows", [(4096, "1"), (1000, "1"), (1000, "0")])
-def test_pipelined_fast_forward_is_bit_identical(torch, n, reg_rows, monkeypatch):
+@pytest.mark.parametrize("n,reg_rows", [(4096, True), (1000, True), (1000, False)])
+def test_pipelined_fast_forward_is_bit_identical(torch, n, reg_rows):
     """tb_set_pipeline: the fast-forward runs on a side stream and writes the terminal step's
     reward late; after flush() every output equals the unpipelined path bit for bit (both builds
     of the pipelined step kernel: static contact rows in registers, as small batches run it, and in
     scratch)"""
     from tennisbot_rl_amd.rollout import RolloutBuffer
     from tennisbot_rl_amd.stepper import BatchedEnv
-    monkeypatch.setenv("TB_SWING_REG_ROWS", reg_rows)
     T = 26 * 4 + 7
     rng = np.random.default_rng(41)
     acts = torch.from_numpy(rng.uniform(-1, 1, (T, n, 6)).astype(np.float32)).cuda()
-    a = BatchedEnv(ENV_SWING, n, seed=6, pipeline=True)
+    a = BatchedEnv(ENV_SWING, n, seed=6, pipeline=True, options=dict(swing_reg_rows=reg_rows))
     b = BatchedEnv(ENV_SWING, n, seed=6)
     ba, bb = RolloutBuffer(ENV_SWING, T, n, "cuda:0"), RolloutBuffer(ENV_SWING, T, n, "cuda:0")
     ba.actions.copy_(acts); bb.actions.copy_(acts)
@@ -661,6 +660,111 @@ def test_hipgraph_replay_equals_eager(torch):
         wa, da = a.get_state_words(); wb, db = b.get_state_words()
         assert torch.equal(wa, wb) and torch.equal(da, db) and a.counters() == b.counters()
         a.close(); b.close()
+
+
+def test_graph_is_refused_at_another_phase_or_after_set_params(torch):
+    """a pipelined SwingRacket graph bakes in which of its steps end an episode; K % 26 != 0 moves the phase, and
+    a second replay would let episode ends fall into launches without a fast-forward slot (terminal rewards lost).
+    StepGraph refuses that instead (and a graph captured before set_params, whose launches carry the old block);
+    the first replay of a 30-step graph equals eager stepping, and nothing is counted as a lockstep violation"""
+    from tennisbot_rl_amd.rollout import RolloutBuffer
+    from tennisbot_rl_amd.stepper import BatchedEnv, StepperError
+    n, T = 1000, 30
+    rng = np.random.default_rng(44)
+    acts = torch.from_numpy(rng.uniform(-1, 1, (T, n, 6)).astype(np.float32)).cuda()
+    a = BatchedEnv(ENV_SWING, n, seed=9, pipeline=True, track_terminal_obs=False)
+    b = BatchedEnv(ENV_SWING, n, seed=9)
+    ba, bb = RolloutBuffer(ENV_SWING, T, n, "cuda:0").bind(a), RolloutBuffer(ENV_SWING, T, n, "cuda:0")
+    ba.actions.copy_(acts); bb.actions.copy_(acts)
+    a.reset(); b.reset()
+    g = a.capture(lambda: ba.step_range(a, 0, T))
+    assert g.n_steps == T and g.phase == 0 and not g.repeatable and a.phase() == 0  # the capture ran nothing
+    g.replay()
+    for t in range(T):
+        bb.step_into(b, t)
+    torch.cuda.synchronize()
+    assert torch.equal(ba.obs, bb.obs) and torch.equal(ba.rewards, bb.rewards) and torch.equal(ba.dones, bb.dones)
+    assert a.phase() == 4
+    with pytest.raises(StepperError, match="phase"):
+        g.replay()
+    # 22 eager steps bring the envs back to phase 0: the same graph is valid again
+    more = torch.from_numpy(rng.uniform(-1, 1, (22, n, 6)).astype(np.float32)).cuda()
+    for t in range(22):
+        a.step(more[t]); b.step(more[t])
+    a.flush()
+    g.replay()
+    for t in range(T):
+        bb.step_into(b, t)
+    torch.cuda.synchronize()
+    assert torch.equal(ba.obs, bb.obs) and torch.equal(ba.rewards, bb.rewards) and torch.equal(ba.dones, bb.dones)
+    ca, cb = a.counters(), b.counters()
+    assert ca == cb and ca["lockstep_violations"] == 0
+    a.set_params(default_params(lin_damp=0.05))
+    with pytest.raises(StepperError, match="set_params"):
+        g.replay()
+    a.close(); b.close()
+
+
+def test_curriculum_scale_reaches_replayed_graphs(torch):
+    """train.py:164-176 calls set_racket_scale at every rollout start, and the trainer REPLAYS one captured
+    rollout: the scale is read by the reset code from device memory (tb_set_racket_scale), not from the
+    captured kernel arguments, so a replay rebuilds rackets with the new scale -- in lockstep with the oracle"""
+    n, K = 512, 300
+    env, ref = make_pair(torch, ENV_TENNIS, n)
+    rng = np.random.default_rng(52)
+    same(env.reset().cpu().numpy(), ref.reset(), "reset")
+    acts = rng.uniform(-1, 1, (K, n, 2)).astype(np.float32)
+    a_dev = torch.from_numpy(acts).cuda()
+    out = {}
+
+    def body():
+        out["r"] = [env.step(a_dev[t]) for t in range(K)]
+    g = env.capture(body)
+    for rnd, scale in enumerate((3.0, 2.3, 1.3, 1.0)):
+        env.set_racket_scale(scale)
+        p = ref.params.copy(); p.racket_scale = scale; ref.set_params(p)
+        g.replay()
+        torch.cuda.synchronize()
+        for t in range(K):
+            o2, r2, d2, _ = ref.step(acts[t])
+            o, r, d = out["r"][t]
+            same(d.cpu().numpy(), d2, "replayed curriculum done %d/%d" % (rnd, t))
+            same(o.cpu().numpy(), o2, "replayed curriculum obs %d/%d" % (rnd, t))
+            same(r.cpu().numpy(), r2, "replayed curriculum reward %d/%d" % (rnd, t))
+        compare_state(env, ref, "replayed curriculum round %d" % rnd)
+    sc = env.get_state()["racket_scale"][:, 0]
+    assert len(np.unique(sc)) >= 2 and np.float32(1.0) in sc   # the last scales arrived, env by env
+    env.close()
+
+
+def test_restored_lockstep_state_rearms_the_pipeline(torch):
+    """tb_set_state re-derives the episode phase when every injected env is running at the same step count:
+    a checkpoint restored into a fresh handle can go on with whole-episode launches (tb_policy_rollout needs
+    the phase) -- and ragged step counts leave the phase unknown"""
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    n = 700
+    rng = np.random.default_rng(45)
+    acts = torch.from_numpy(rng.uniform(-1, 1, (60, n, 6)).astype(np.float32)).cuda()
+    a = BatchedEnv(ENV_SWING, n, seed=10, pipeline=True, track_terminal_obs=False)
+    b = BatchedEnv(ENV_SWING, n, seed=10, pipeline=True, track_terminal_obs=False)
+    twin = BatchedEnv(ENV_SWING, n, seed=10)
+    a.reset(); twin.reset()
+    for t in range(33):
+        a.step(acts[t]); twin.step(acts[t])
+    a.flush()
+    w, d = a.get_state_words()
+    b.set_state_words(w, d)
+    assert a.phase() == 7 and b.phase() == 7
+    ob, rb, db = b.rollout(acts[33:60])   # pipelined whole-episode launches from the restored phase
+    b.flush()
+    for t in range(33, 60):
+        o, r, dn = twin.step(acts[t])
+        assert torch.equal(o, ob[t - 33]) and torch.equal(r, rb[t - 33]) and torch.equal(dn, db[t - 33]), "step %d" % t
+    assert b.counters()["lockstep_violations"] == 0
+    w2 = w.clone(); w2[28, 0] += 1   # one env a step ahead: no common phase
+    b.set_state_words(w2, d)
+    assert b.phase() == -1
+    a.close(); b.close(); twin.close()
 
 
 def test_curriculum_scale_applies_at_each_envs_own_reset(torch):
@@ -764,41 +868,6 @@ def test_step_sequence_equals_per_step_calls_and_chunked_gather_views(torch):
     assert len(shards) == 1 and torch.equal(shards[0][0][0], buf.obs)
 
 
-@pytest.mark.parametrize("n_chunks,window", [(4, 52), (8, 10), (2, 104)])
-def test_chunk_graphs_with_deferred_fast_forwards_are_bit_identical(torch, n_chunks, window):
-    """a rollout cut into several hipGraphs, episode ends near a chunk's end parked and finished by
-    the next graph (tb_set_defer / tb_ff_launch_pending / tb_pipeline_join), replayed for two
-    rounds, against the same envs stepped call by call"""
-    from tennisbot_rl_amd.rollout import RolloutBuffer
-    from tennisbot_rl_amd.stepper import BatchedEnv
-    n, T = 1000, 208
-    rng = np.random.default_rng(12)
-    acts = torch.from_numpy(rng.uniform(-1, 1, (T, n, 6)).astype(np.float32)).cuda()
-    ref_env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=31, track_terminal_obs=False, pipeline=True)
-    ref = RolloutBuffer(ENV_SWING, T, n, "cuda:0").bind(ref_env)
-    env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=31, track_terminal_obs=False, pipeline=True)
-    buf = RolloutBuffer(ENV_SWING, T, n, "cuda:0").bind(env)
-    for b in (ref, buf):
-        b.actions.copy_(acts)
-    ref_env.reset(); env.reset()
-    for t in range(7):  # chunk boundaries off the episode grid
-        ref.step_into(ref_env, t); buf.step_into(env, t)
-    graphs, tail = buf.capture_chunks(env, n_chunks, defer_window=window)
-    assert tail is not None and len(graphs) == n_chunks
-    for rnd in range(2):
-        for t in range(T):
-            ref.step_into(ref_env, t)
-        ref_env.flush()
-        buf.replay_chunks(graphs, tail)
-        torch.cuda.synchronize()
-        assert torch.equal(ref.raw, buf.raw), "round %d" % rnd
-    c = env.counters()
-    assert c == ref_env.counters()
-    wa, da = env.get_state_words()
-    wb, db = ref_env.get_state_words()
-    assert torch.equal(wa, wb) and torch.equal(da, db)
-
-
 @pytest.mark.parametrize("kind,n_chunks", [(ENV_SWING, 4), (ENV_SWING, 13), (ENV_TENNIS, 8)])
 def test_progress_marks_release_each_chunk_of_one_graph(torch, kind, n_chunks):
     """RolloutBuffer.capture_marked: the whole rollout is ONE hipGraph; mark c (tb_mark_record: a counter in
@@ -852,27 +921,6 @@ def test_progress_marks_release_each_chunk_of_one_graph(torch, kind, n_chunks):
         with pytest.raises(StepperError):  # a mark that nobody fires: the wait gives up
             env.mark_host_wait(0, timeout_ms=20)
     env.close(); ref_env.close()
-
-
-def test_deferred_fast_forward_is_launched_by_flush_and_by_slot_reuse(torch):
-    """tb_set_defer without anyone calling tb_ff_launch_pending: flush() must deliver, and so must a
-    ninth parked episode end that needs the first one's slot back (the handle has 8 slots)"""
-    from tennisbot_rl_amd.stepper import BatchedEnv
-    n = 300
-    rng = np.random.default_rng(2)
-    T = 26 * 10 + 5
-    acts = torch.from_numpy(rng.uniform(-1, 1, (T, n, 6)).astype(np.float32)).cuda()
-    ref = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=6, track_terminal_obs=False, pipeline=True)
-    env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=6, track_terminal_obs=False, pipeline=True)
-    ref.reset(); env.reset()
-    env.set_defer(True)
-    a = [env.step(acts[t]) for t in range(T)]   # 10 episode ends, 8 slots
-    b = [ref.step(acts[t]) for t in range(T)]
-    env.flush(); ref.flush()
-    env.set_defer(False)
-    torch.cuda.synchronize()
-    for t in range(T):
-        assert all(torch.equal(x, y) for x, y in zip(a[t], b[t])), "step %d" % t
 
 
 _ABANDONED_CAPTURE_CASE = r"""

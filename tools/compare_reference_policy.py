@@ -51,6 +51,27 @@ def rollout_rewards(num_envs=4096, episodes=4, seed=0, **overrides):
     return np.concatenate(out)
 
 
+def reference_record(exclude_interrupted=True):
+    """(rewards, note) of the reference's PyBullet record. Two of its 100 episodes are 38 steps long although every
+    SwingRacket episode is exactly 26 (swingracket_env.py:105-129): train_swing.py:111 hands EvalCallback the TRAINING env
+    object, so every 1000 timesteps the evaluation resets that env in the middle of a training
+    episode -- 1000 = 38 * 26 + 12 -- runs its own episodes, and leaves a fresh world behind; the training Monitor's
+    episode then lasts its 12 steps before the interruption + a full 26 after it, acts once on a stale observation, and sums
+    the rewards of two different worlds (the record's wall-clock shows the evaluation's 0.87 s gap inside exactly those two).
+    They are not samples of the episode-return distribution and are left out of the distribution tests."""
+    rec = json.load(open(os.path.join(ROOT, "tests", "golden", "ppo_swing_reference_episodes.json")))
+    r, n = np.asarray(rec["episode_rewards"], np.float64), np.asarray(rec["episode_lengths"])
+    keep = (n == 26) if exclude_interrupted else np.ones(r.size, bool)
+    return r[keep], int((~keep).sum())
+
+
+def ks_two_sample(a, b):
+    """two-sample Kolmogorov-Smirnov statistic D and its asymptotic p-value (scipy.stats.ks_2samp)"""
+    from scipy.stats import ks_2samp
+    res = ks_2samp(np.asarray(a, np.float64), np.asarray(b, np.float64), alternative="two-sided", method="asymp")
+    return float(res.statistic), float(res.pvalue)
+
+
 def summarize(r):
     r = np.asarray(r, dtype=np.float64)
     goal = r >= 50.0  # only the goal bonus (+50) lifts an episode that high
@@ -85,8 +106,12 @@ def main():
                     "racket restitution 0.9 (not the product 0.81)": dict(rest_racket=0.9), "racket restitution 0.5": dict(rest_racket=0.5),
                     "racket friction 0.2 (not the product 0.04)": dict(fric_racket=0.2), "restitution threshold 1.0": dict(rest_vel_threshold=1.0),
                     "racket mass 2": dict(racket_mass=2.0), "ball mass 0.058": dict(ball_mass=0.058), "10 solver iterations": dict(solver_iters=10)}
+    ref98, dropped = reference_record()
+    print("distribution tests use the %d uninterrupted episodes (%d were cut by an evaluation on the training env)" % (ref98.size, dropped))
     for name, over in variants.items():
-        b = summarize(rollout_rewards(**over))
+        rew = rollout_rewards(**over)
+        b = summarize(rew)
+        b["ks_D"], b["ks_p"] = ks_two_sample(ref98, rew)
         print("HIP envs, %s %s:\n    %s" % (name, {k: (tuple(round(x, 5) for x in v) if isinstance(v, tuple) else v) for k, v in over.items()}, json.dumps(b)))
         rest = np.array([x for x in ref["episode_rewards"] if x < 50.0])
         se_med = 1.2533 * rest.std(ddof=1) / len(rest) ** 0.5

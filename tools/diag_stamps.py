@@ -18,7 +18,7 @@ from tennisbot_rl_amd.params import ENV_SWING  # noqa: E402
 
 out = "/tmp/libtb_stamps.so"
 subprocess.check_call([hipcc()] + HIPCC_FLAGS + ["-DTB_DIAG_STAMPS", "-o", out] + SOURCES)
-stepper._LIB_PATH = out
+stepper.use_library(out)
 L = stepper.load_library()
 L.tb_diag_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096

@@ -34,7 +34,8 @@ w, d = make_words(ENV_SWING, n, racket_pos=(8, 0, 1.0), racket_angvel=rng.unifor
 for name, flags in VARIANTS.items():
     out = "/tmp/libtb_%s.so" % name
     subprocess.check_call([hipcc()] + HIPCC_FLAGS + flags + ["-o", out] + SOURCES)
-    stepper._LIB, stepper._LIB_PATH = None, out
+    stepper._LIB = None
+    stepper.use_library(out)
     env = stepper.BatchedEnv(ENV_SWING, n, auto_reset=False)
     a = torch.zeros((n, 6), device="cuda")
     times = []
