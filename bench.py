@@ -218,11 +218,12 @@ def warm_up(env, buf, warmup, period):
 
 
 def sweep_entry(kind, env_name, n, flags, pipeline, dev, seed, use_graph, torch):
-    """one N of the ladder: rollouts of 52 steps (26 from 1 M envs: memory), replayed until >= ~5 ms are timed"""
+    """one N of the ladder: whole rollouts as in the headline line (1040 steps up to 32768 envs, 104 above: the rollout
+    buffer of 4 M envs x 104 steps is 24 of the 288 GB), replayed until >= ~5 ms are timed"""
     from tennisbot_rl_amd.params import ENV_SWING, default_params
     from tennisbot_rl_amd.rollout import RolloutBuffer
     from tennisbot_rl_amd.stepper import BatchedEnv
-    T = 26 if n >= 1048576 else 52
+    T = 1040 if n <= 32768 else 104
     e2 = BatchedEnv(kind, n, device=dev, seed=seed, params=default_params(flags=flags), track_terminal_obs=False, pipeline=pipeline)
     b2 = RolloutBuffer(kind, T, n, dev)
     b2.actions.uniform_(-1.0, 1.0)  # device RNG: a host PCG64 draw for 1 M envs would dominate the set-up

@@ -47,8 +47,8 @@ struct KArgs {
   int n, T;
   // pipelined fast-forward (tb_set_pipeline): a step that starts a SwingRacket fast-forward parks
   // the env's pre-loop state in a slot and resets the env; tb_ff_kernel finishes it on a side stream
-  uint32_t* ff_words;     // [W][n] slot
-  uint8_t* ff_flag;       // [n]: 1 = parked, waiting for tb_ff_kernel
+  float4* ff_rec;         // [n][TB_FF_REC] slot: one 128-byte record per env (park_env), word 30 = 1 while parked
+  int ff_lanes;           // tb_ff_kernel: parked envs per wave (sparse waves at small batch sizes), 64 when it sorts
   int defer;
   // fused policy inference (tb_policy_step): actions are computed in-kernel from pol_obs
   const float* pol_weights;  // packed SB3 MlpPolicy towers, see PolicyNet
@@ -197,6 +197,55 @@ TB_DEV void reset_env(const KArgs& A, const float4* KP, int i, EnvRegs& e) {
   }
   e.step_count = 0;
   e.done = TB_DONE_NO;
+}
+
+// Parked SwingRacket envs travel as ONE 128-byte record each (array of structures, unlike the SoA state): the
+// fast-forward kernel hands records to lanes in another order than the env index (sorted by predicted flight
+// length, or a few per wave), and a lane that fetches a whole 128-byte line wastes nothing, where a gather from
+// the SoA rows would pull a 32-byte sector per word.
+#define TB_FF_REC 8  // float4 per record
+TB_DEV void park_env(float4* rec, int i, const EnvRegs& e) {
+  float4* r = rec + (size_t)i * TB_FF_REC;
+  r[0] = make_float4(e.r.p.x, e.r.p.y, e.r.p.z, e.r.q.x);
+  r[1] = make_float4(e.r.q.y, e.r.q.z, e.r.q.w, e.r.v.x);
+  r[2] = make_float4(e.r.v.y, e.r.v.z, e.r.w.x, e.r.w.y);
+  r[3] = make_float4(e.r.w.z, e.b.p.x, e.b.p.y, e.b.p.z);
+  r[4] = make_float4(e.b.v.x, e.b.v.y, e.b.v.z, e.b.w.x);
+  r[5] = make_float4(e.b.w.y, e.b.w.z, e.aux[0], e.aux[1]);
+  r[6] = make_float4(e.aux[2], e.aux[3], e.aux[4], e.aux[5]);
+  r[7] = make_float4(__int_as_float(e.step_count), __uint_as_float(e.episode), __uint_as_float(1u), __int_as_float(i));
+}
+TB_DEV void unpark_env(const float4* r, EnvRegs& e, int& env_index) {
+  e.r.p = mk(r[0].x, r[0].y, r[0].z);
+  e.r.q.x = r[0].w; e.r.q.y = r[1].x; e.r.q.z = r[1].y; e.r.q.w = r[1].z;
+  e.r.v = mk(r[1].w, r[2].x, r[2].y);
+  e.r.w = mk(r[2].z, r[2].w, r[3].x);
+  e.b.p = mk(r[3].y, r[3].z, r[3].w);
+  e.b.v = mk(r[4].x, r[4].y, r[4].z);
+  e.b.w = mk(r[4].w, r[5].x, r[5].y);
+  e.aux[0] = r[5].z; e.aux[1] = r[5].w; e.aux[2] = r[6].x; e.aux[3] = r[6].y; e.aux[4] = r[6].z; e.aux[5] = r[6].w;
+  e.step_count = __float_as_int(r[7].x); e.episode = __float_as_uint(r[7].y);
+  env_index = __float_as_int(r[7].w);
+  e.done = TB_DONE_NO;  // a parked env was running
+}
+// How long will this parked env's fast-forward last? The ball's flight decides (the loop ends when it touches the court
+// or the goal): vertical motion under gravity and Bullet's v (k1 + k2 |v|) drag, integrated with 4 substeps per
+// iteration until the ball's lowest point reaches the court; the iteration count is the sort key. An ESTIMATE for
+// scheduling only -- which lane computes which env never changes a result -- so the hardware's approximate square
+// root is good enough, and a ball that is struck again, rolls onto the goal or the net first just lands in a
+// neighbouring bin.
+TB_DEV int predict_flight(const KParams& P, vec3 bp, vec3 bv) {
+  const float dt4 = 4.0f * P.dt, z_land = (P.ground_half[2] + P.ball_radius) + P.contact_threshold;
+  float z = bp.z, vz = bv.z, vh = __builtin_amdgcn_sqrtf(FMA(bv.x, bv.x, bv.y * bv.y));
+  int k = 0;
+  while (k < 200 && z > z_land) {
+    float kd = FMA(P.lin_damp, __builtin_amdgcn_sqrtf(FMA(vh, vh, vz * vz)), P.lin_damp);
+    vz = FMA(dt4, -P.gravity - vz * kd, vz);
+    vh = FMA(dt4, -(vh * kd), vh);
+    z = FMA(dt4, vz, z);
+    ++k;
+  }
+  return k;
 }
 
 // swingracket_env.py:63-73
@@ -412,9 +461,8 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
           // Every SwingRacket episode ends inside this step (the loop only exits through done), so
           // done = 1 is known now; reward, terminal obs and substep count of this step are written
           // later by tb_ff_kernel from the parked state. The env itself restarts immediately.
-          if (A.ff_words) {
-            store_env<TB_ENV_SWING>(A.ff_words, A.ff_flag, A.n, i, e, true);
-            A.ff_flag[i] = 1;
+          if (A.ff_rec) {
+            park_env(A.ff_rec, i, e);
           } else {
             cnt[8]++;  // lockstep invariant broken (see launch_step): reported, never silent
           }
@@ -544,9 +592,8 @@ __global__ void __launch_bounds__(320) tb_policy_rollout_kernel(KArgs A) {
         make_obs<TB_ENV_SWING>(e, o);
         d = e.done != TB_DONE_NO;
         if (parked) {
-          if (A.ff_words) {
-            store_env<TB_ENV_SWING>(A.ff_words, A.ff_flag, A.n, i, e, true);
-            A.ff_flag[i] = 1;
+          if (A.ff_rec) {
+            park_env(A.ff_rec, i, e);
           } else {
             cnt[8]++;  // lockstep invariant broken (see launch_policy_rollout): reported, never silent
           }
@@ -589,15 +636,72 @@ __global__ void tb_mark_kernel(unsigned long long* count) {
 // tb_set_racket_scale: one stream-ordered 4-byte store into the device-resident parameter block
 __global__ void tb_poke_kernel(float* dst, float v) { *dst = v; }
 
-// finishes parked SwingRacket fast-forwards (side stream): same device code as the in-step loop
-template <bool RG>
-__global__ void __launch_bounds__(256) tb_ff_kernel(KArgs A) {
+// Finishes parked SwingRacket fast-forwards (side stream): same device code as the in-step loop, lane by lane; what
+// this kernel decides is WHICH lane runs which parked env, because the loop's cost is set by the slowest lane of a
+// wave and by the contact paths ANY lane of the wave enters (wave votes):
+//   SORT = false: wave w takes the A.ff_lanes records [w L, (w+1) L): at small batch sizes (4096 envs = 64 full waves
+//     on a chip with 1024 SIMDs) a few envs per wave spread the work over the idle SIMDs, a wave seldom has a lane in
+//     a contact path, and its loop length is that of its few lanes, not the maximum of 64;
+//   SORT = true: a 512-thread workgroup loads its 512 records, orders them by predicted flight length (predict_flight;
+//     counting sort over 256 bins in LDS, the records move through LDS) and wave k runs the k-th 64 of them: lanes of
+//     a wave finish together instead of idling until the longest flight of 64 random envs has landed (mean 108
+//     substeps, maximum of 64: ~170), and they are in the same phase of the flight, which is what makes the wave
+//     votes effective.
+// Results do not depend on the assignment (one lane = one world); tests/test_gpu_parity.py runs every variant.
+#define TB_FF_SORT_BLOCK 512
+template <bool RG, bool SORT>
+__global__ void __launch_bounds__(SORT ? TB_FF_SORT_BLOCK : 64) tb_ff_kernel(KArgs A) {
   __shared__ float4 s_hull[TB_HULL_LDS];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < A.n && A.ff_flag[i] == 1;
-  EnvRegs e;
-  if (live) load_env<TB_ENV_SWING>(A.ff_words, A.ff_flag, A.n, i, e);
-  stage_hull(s_hull, A);
+  __shared__ float4 s_rec[SORT ? TB_FF_SORT_BLOCK * TB_FF_REC : 1];
+  __shared__ int s_hist[SORT ? 256 : 1];
+  const int lane = threadIdx.x & 63;
+  float4 r[TB_FF_REC];
+  bool live = false;
+  if (SORT) {
+    const int src = blockIdx.x * TB_FF_SORT_BLOCK + threadIdx.x;
+    if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
+    int key = 255;  // not parked / beyond the batch: behind every real flight
+#pragma unroll
+    for (int k = 0; k < TB_FF_REC; ++k) r[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (src < A.n) {
+      const float4* g = A.ff_rec + (size_t)src * TB_FF_REC;
+#pragma unroll
+      for (int k = 0; k < TB_FF_REC; ++k) r[k] = g[k];
+      if (__float_as_uint(r[7].z) == 1u) {
+        int it = predict_flight(A.P, mk(r[3].y, r[3].z, r[3].w), mk(r[4].x, r[4].y, r[4].z));
+        key = it < 254 ? it : 254;
+      }
+    }
+    stage_hull(s_hull, A);  // (its barrier also publishes the zeroed histogram)
+    const int rank = atomicAdd(&s_hist[key], 1);
+    __syncthreads();
+    if (threadIdx.x < 64) {  // exclusive scan of the 256 bins by one wave: 4 bins per lane
+      int c0 = s_hist[4 * lane], c1 = s_hist[4 * lane + 1], c2 = s_hist[4 * lane + 2], c3 = s_hist[4 * lane + 3];
+      int sum = c0 + c1 + c2 + c3, inc = sum;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { int o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
+      int base = inc - sum;
+      s_hist[4 * lane] = base; s_hist[4 * lane + 1] = base + c0; s_hist[4 * lane + 2] = base + c0 + c1; s_hist[4 * lane + 3] = base + c0 + c1 + c2;
+    }
+    __syncthreads();
+    const int pos = s_hist[key] + rank;
+#pragma unroll
+    for (int k = 0; k < TB_FF_REC; ++k) s_rec[pos * TB_FF_REC + k] = r[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TB_FF_REC; ++k) r[k] = s_rec[threadIdx.x * TB_FF_REC + k];
+    live = __float_as_uint(r[7].z) == 1u;
+  } else {
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int src = wave * A.ff_lanes + lane;
+    if (lane < A.ff_lanes && src < A.n) {
+      const float4* g = A.ff_rec + (size_t)src * TB_FF_REC;
+#pragma unroll
+      for (int k = 0; k < TB_FF_REC; ++k) r[k] = g[k];
+      live = __float_as_uint(r[7].z) == 1u;
+    }
+    stage_hull(s_hull, A);
+  }
   uint32_t cnt[TB_N_COUNTERS];
 #pragma unroll
   for (int k = 0; k < TB_N_COUNTERS; ++k) cnt[k] = 0u;
@@ -607,7 +711,9 @@ __global__ void __launch_bounds__(256) tb_ff_kernel(KArgs A) {
   st.t = stamp_now();
 #endif
   if (live) {
-    e.done = TB_DONE_NO;  // the slot's byte is the parking flag, the parked env was not done
+    EnvRegs e;
+    int i;
+    unpark_env(r, e, i);
     int ns = 1;           // the step kernel ran the first substep of this agent step
     bool parked = false;
     const vec3 zero = mk(0.0f, 0.0f, 0.0f);
@@ -621,7 +727,7 @@ __global__ void __launch_bounds__(256) tb_ff_kernel(KArgs A) {
     if (A.term_obs) write_obs<TB_ENV_SWING>(A.term_obs, (size_t)i, o);
     A.reward[i] = rew;
     if (A.substeps) A.substeps[i] = ns;
-    A.ff_flag[i] = 0;
+    reinterpret_cast<uint32_t*>(A.ff_rec + (size_t)i * TB_FF_REC + 7)[2] = 0u;  // the record is free again
   }
   flush_counters(A.counters, cnt);
 }

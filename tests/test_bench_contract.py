@@ -70,5 +70,5 @@ def test_bench_exchange_forms_with_one_rank(chunks):
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
     w, x = d["config"]["workload"], d["exchange"]
     assert d["value"] > 0 and "invalid" not in d and "all-gather" in w
-    assert x["ranks_seen"] == 1 and x["bytes_per_rank"] > 208 * 4096 * 53 and x["rollout_ms"] > 0 and x["exchange_ms"] > 0.9 and x["exposed_exchange_ms"] >= 0
+    assert x["ranks_seen"] == 1 and x["bytes_per_rank"] >= 208 * 4096 * 53 and x["rollout_ms"] > 0 and x["exchange_ms"] > 0.9 and x["exposed_exchange_ms"] >= 0
     assert ("step-chunks" in x["form"]) == (chunks == "8") and not x["note"]

@@ -87,7 +87,7 @@ def run_lockstep(torch, env, ref, steps, rng, what, check_state_every=1):
 def test_native_library_is_the_one_running(torch):
     from tennisbot_rl_amd import stepper
     L = stepper.load_library()
-    assert L.tb_abi_version() == 2
+    assert L.tb_abi_version() == 3
     with open("/proc/self/maps") as f:
         assert "libtb_stepper.so" in f.read()
 
