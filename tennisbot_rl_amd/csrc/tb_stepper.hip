@@ -880,8 +880,8 @@ struct TbHandle {
   hipStream_t side[TB_FF_SLOTS];  // one stream per slot: consecutive fast-forwards overlap each other too
   const void *last_term, *last_sub;  // shared late-written buffers force ordering between fast-forwards
   int last_slot;
-  uint32_t* d_ff_words[TB_FF_SLOTS];
-  uint8_t* d_ff_flag[TB_FF_SLOTS];
+  float4* d_ff_rec[TB_FF_SLOTS];  // [n][TB_FF_REC] parked records (park_env)
+  int ff_lanes, ff_sort;          // how tb_ff_kernel hands records to lanes (TbOptions.ff_lanes_per_wave / ff_sort, or chosen from n)
   hipEvent_t ev_step[TB_FF_SLOTS], ev_ff[TB_FF_SLOTS];
   int ff_busy[TB_FF_SLOTS], next_slot;
   // progress marks (tb_mark_record). h_marks: pinned host counters written by tb_mark_kernel -- [k] firings of mark k
@@ -943,15 +943,28 @@ bool extended_contacts(const KParams& kp) {
 }
 
 // finish the lanes parked in `slot` on that slot's side stream, ordered after everything issued to `s` so far
-int launch_ff(TbHandle* h, int slot, const KArgs& a, const void* term, const void* substeps, hipStream_t s) {
-  dim3 grid((unsigned)((h->n + h->block - 1) / h->block)), block((unsigned)h->block);
+int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const void* substeps, hipStream_t s) {
+  KArgs a = a_in;
+  // lockstep episodes (every env parks in the same launch): sorted, or a few envs per wave; without the host knowing the
+  // phase every step is followed by this kernel and nearly every record is idle: plain 64 per wave, one flag test each
+  const bool sort = h->ff_sort && h->phase_valid;
+  a.ff_lanes = sort || !h->phase_valid ? 64 : h->ff_lanes;
+  dim3 grid, block;
+  if (sort) { grid = dim3((unsigned)((h->n + TB_FF_SORT_BLOCK - 1) / TB_FF_SORT_BLOCK)); block = dim3(TB_FF_SORT_BLOCK); }
+  else { grid = dim3((unsigned)((h->n + a.ff_lanes - 1) / a.ff_lanes)); block = dim3(64); }
   HIP_TRY(hipEventRecord(h->ev_step[slot], s));
   HIP_TRY(hipStreamWaitEvent(h->side[slot], h->ev_step[slot], 0));
   // two fast-forwards that write the same terminal-obs / substeps buffer must finish in order
   if (h->last_slot >= 0 && h->last_slot != slot && ((term && term == h->last_term) || (substeps && substeps == h->last_sub)))
     HIP_TRY(hipStreamWaitEvent(h->side[slot], h->ev_ff[h->last_slot], 0));
-  if (extended_contacts(h->kp)) hipLaunchKernelGGL(tb_ff_kernel<true>, grid, block, 0, h->side[slot], a);
-  else hipLaunchKernelGGL(tb_ff_kernel<false>, grid, block, 0, h->side[slot], a);
+  const bool rg = extended_contacts(h->kp);
+  if (sort) {
+    if (rg) hipLaunchKernelGGL((tb_ff_kernel<true, true>), grid, block, 0, h->side[slot], a);
+    else hipLaunchKernelGGL((tb_ff_kernel<false, true>), grid, block, 0, h->side[slot], a);
+  } else {
+    if (rg) hipLaunchKernelGGL((tb_ff_kernel<true, false>), grid, block, 0, h->side[slot], a);
+    else hipLaunchKernelGGL((tb_ff_kernel<false, false>), grid, block, 0, h->side[slot], a);
+  }
   HIP_TRY(hipGetLastError());
   if (h->h_marks && h->marks_on) {  // progress marks: count this fast-forward as finished, in stream order behind it
     hipLaunchKernelGGL(tb_mark_kernel, dim3(1), dim3(1), 0, h->side[slot], h->h_marks + TB_MAX_MARKS);
@@ -998,7 +1011,7 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
     slot = h->next_slot;
     h->next_slot = (slot + 1) % TB_FF_SLOTS;
     if (h->ff_busy[slot]) HIP_TRY(hipStreamWaitEvent(s, h->ev_ff[slot], 0));  // slot still in use by an older fast-forward
-    a.defer = 1; a.ff_words = h->d_ff_words[slot]; a.ff_flag = h->d_ff_flag[slot];
+    a.defer = 1; a.ff_rec = h->d_ff_rec[slot];
   }
   const bool rg = extended_contacts(h->kp);  // selects the instantiation that contains racket<->court contact and rolling friction
   (void)hipGetLastError();  // the check below is about THIS launch, not about whatever another library left behind
@@ -1013,7 +1026,7 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
       if (h->reg_rows && !pol && !rg) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, true, false, false, true>), grid, block, 0, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);
       else TB_LAUNCH_STEP(TB_ENV_TENNIS, false, true);
     } else if (piped) {
-      if (!may_park) { a.ff_words = nullptr; a.ff_flag = nullptr; }
+      if (!may_park) a.ff_rec = nullptr;
       TB_LAUNCH_STEP(TB_ENV_SWING, true, true);
     } else TB_LAUNCH_STEP(TB_ENV_SWING, false, true);
   } else if (h->kind == TB_ENV_TENNIS) {
@@ -1021,7 +1034,7 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
     else if (h->reg_rows && !rg) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, false, false, false, true>), grid, block, 0, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);
     else TB_LAUNCH_STEP(TB_ENV_TENNIS, false, false);
   } else if (piped && h->swing_reg_rows && !pol && !rg) {
-    if (!may_park) { a.ff_words = nullptr; a.ff_flag = nullptr; }  // (see the comment of the next branch but one)
+    if (!may_park) a.ff_rec = nullptr;  // (see the comment of the next branch but one)
     hipLaunchKernelGGL((tb_step_kernel<TB_ENV_SWING, true, false, false, false, true>), grid, block, 0, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);
   } else if (may_park) TB_LAUNCH_STEP(TB_ENV_SWING, true, false);
   else if (piped) {
@@ -1029,7 +1042,7 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
     // together and every library call that could break lockstep clears phase_valid), so no lane
     // can start a fast-forward in this launch and the lean kernel needs no slot. Should the
     // invariant ever be broken, the lane is counted in counters[7] instead of being dropped silently.
-    a.ff_words = nullptr; a.ff_flag = nullptr;
+    a.ff_rec = nullptr;
     TB_LAUNCH_STEP(TB_ENV_SWING, true, false);
   } else TB_LAUNCH_STEP(TB_ENV_SWING, false, false);
 #undef TB_LAUNCH_STEP
@@ -1057,7 +1070,7 @@ int launch_policy_rollout(TbHandle* h, int T, const PolicyIO& pol, float* obs, f
     slot = h->next_slot;
     h->next_slot = (slot + 1) % TB_FF_SLOTS;
     if (h->ff_busy[slot]) HIP_TRY(hipStreamWaitEvent(s, h->ev_ff[slot], 0));
-    a.defer = 1; a.ff_words = h->d_ff_words[slot]; a.ff_flag = h->d_ff_flag[slot];
+    a.defer = 1; a.ff_rec = h->d_ff_rec[slot];
   }
   dim3 grid((unsigned)((h->n + 63) / 64)), block(320);
   (void)hipGetLastError();
@@ -1113,6 +1126,10 @@ int tb_create(const TbParams* params, const TbOptions* options, int env_kind, in
   // kernel runs at 70 % of HBM peak and occupancy counts, loses 3 % at 1 M envs
   h->reg_rows = env_kind == TB_ENV_TENNIS && (opt.tennis_reg_rows ? opt.tennis_reg_rows > 0 : 1);
   h->swing_reg_rows = env_kind == TB_ENV_SWING && (opt.swing_reg_rows ? opt.swing_reg_rows > 0 : n_envs <= 131072);
+  // fast-forward: spread small batches over the chip's 1024 SIMDs (>= 4 envs per wave), sort the lanes of large ones
+  h->ff_sort = opt.ff_sort ? opt.ff_sort > 0 : n_envs >= 32768;
+  h->ff_lanes = opt.ff_lanes_per_wave;
+  if (!h->ff_lanes) { h->ff_lanes = 4; while (h->ff_lanes < 64 && (long long)h->ff_lanes * 1024 < n_envs) h->ff_lanes <<= 1; }
   const int nw = words_of(env_kind);
   hipError_t err;
 #define CREATE_TRY(expr) if ((err = (expr)) != hipSuccess) { int rc = fail((int)err, #expr); tb_destroy(h); return rc; }
@@ -1141,8 +1158,7 @@ int tb_destroy(TbHandle* h) {
   if (h->h_hull) (void)hipHostFree(h->h_hull);
   if (h->d_counters) (void)hipFree(h->d_counters);
   for (int k = 0; k < TB_FF_SLOTS; ++k) {
-    if (h->d_ff_words[k]) (void)hipFree(h->d_ff_words[k]);
-    if (h->d_ff_flag[k]) (void)hipFree(h->d_ff_flag[k]);
+    if (h->d_ff_rec[k]) (void)hipFree(h->d_ff_rec[k]);
     if (h->ev_step[k]) (void)hipEventDestroy(h->ev_step[k]);
     if (h->ev_ff[k]) (void)hipEventDestroy(h->ev_ff[k]);
   }
@@ -1158,13 +1174,12 @@ int tb_set_pipeline(TbHandle* h, int enable) {
   DeviceGuard g(h->device);
   if (enable && !h->side[0]) {
     if (h->kind != TB_ENV_SWING) return fail(TB_E_UNSUPPORTED, "tb_set_pipeline: only SwingRacket-v0 has a fast-forward to overlap");
-    const size_t wb = sizeof(uint32_t) * (size_t)TB_SWING_WORDS * h->n;
+    const size_t wb = sizeof(float4) * (size_t)TB_FF_REC * h->n;
     h->last_slot = -1;
     for (int k = 0; k < TB_FF_SLOTS; ++k) {
       HIP_TRY(hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
-      HIP_TRY(hipMalloc((void**)&h->d_ff_words[k], wb));
-      HIP_TRY(hipMalloc((void**)&h->d_ff_flag[k], (size_t)h->n));
-      HIP_TRY(hipMemset(h->d_ff_flag[k], 0, (size_t)h->n));
+      HIP_TRY(hipMalloc((void**)&h->d_ff_rec[k], wb));
+      HIP_TRY(hipMemset(h->d_ff_rec[k], 0, wb));  // word 30 of a record = 1 while an env is parked in it
       HIP_TRY(hipEventCreateWithFlags(&h->ev_step[k], hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&h->ev_ff[k], hipEventDisableTiming));
     }

@@ -589,18 +589,21 @@ def test_float32_drift_vs_float64_truth(torch):
     assert np.array_equal(g["step_count"], c["step_count"])
 
 
-@pytest.mark.parametrize("n,reg_rows", [(4096, True), (1000, True), (1000, False)])
-def test_pipelined_fast_forward_is_bit_identical(torch, n, reg_rows):
+@pytest.mark.parametrize("n,reg_rows,ff", [(4096, True, {}), (1000, True, {}), (1000, False, {}),
+                                           (1000, None, dict(ff_lanes_per_wave=1)), (1000, None, dict(ff_lanes_per_wave=7)), (4096, None, dict(ff_lanes_per_wave=64, ff_sort=False)),
+                                           (1000, None, dict(ff_sort=True)), (4096, None, dict(ff_sort=True)), (40000, None, {})])
+def test_pipelined_fast_forward_is_bit_identical(torch, n, reg_rows, ff):
     """tb_set_pipeline: the fast-forward runs on a side stream and writes the terminal step's
     reward late; after flush() every output equals the unpipelined path bit for bit (both builds
     of the pipelined step kernel: static contact rows in registers, as small batches run it, and in
-    scratch)"""
+    scratch; every way tb_ff_kernel hands parked envs to lanes, TbOptions.ff_lanes_per_wave / ff_sort:
+    1, 7 or 64 per wave, sorted by predicted flight length in 512-env groups, and what 40 000 envs get by default)"""
     from tennisbot_rl_amd.rollout import RolloutBuffer
     from tennisbot_rl_amd.stepper import BatchedEnv
     T = 26 * 4 + 7
     rng = np.random.default_rng(41)
     acts = torch.from_numpy(rng.uniform(-1, 1, (T, n, 6)).astype(np.float32)).cuda()
-    a = BatchedEnv(ENV_SWING, n, seed=6, pipeline=True, options=dict(swing_reg_rows=reg_rows))
+    a = BatchedEnv(ENV_SWING, n, seed=6, pipeline=True, options=dict(swing_reg_rows=reg_rows, **ff))
     b = BatchedEnv(ENV_SWING, n, seed=6)
     ba, bb = RolloutBuffer(ENV_SWING, T, n, "cuda:0"), RolloutBuffer(ENV_SWING, T, n, "cuda:0")
     ba.actions.copy_(acts); bb.actions.copy_(acts)
@@ -616,8 +619,13 @@ def test_pipelined_fast_forward_is_bit_identical(torch, n, reg_rows):
     wa, da = a.get_state_words(); wb, db = b.get_state_words()
     assert torch.equal(wa, wb) and torch.equal(da, db)
     assert a.counters() == b.counters()
-    # a state injection breaks the lockstep assumption: the library falls back to in-kernel loops
+    # a restored lockstep state keeps the pipeline armed (tb_set_state re-derives the phase) ...
     a.set_state_words(wa, da)
+    assert a.phase() == T % 26
+    # ... a masked reset breaks the lockstep: from here on every step may end some env's episode, every launch
+    # gets a slot and a (mostly idle) fast-forward kernel behind it
+    mask = (torch.arange(n, device="cuda:0") % 3 == 0)
+    assert torch.equal(a.reset(mask), b.reset(mask)) and a.phase() == -1
     for t in range(30):
         oa, ra, dna = a.step(acts[t]); ob, rb, dnb = b.step(acts[t])
         a.flush()
