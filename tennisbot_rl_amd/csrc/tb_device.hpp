@@ -688,8 +688,12 @@ TB_DEV void solve_contacts(const KParams& P, Rows<RG>& R, Racket& rk, Ball& b) {
 // ---------------------------------------------------------------- one 1/240 s substep
 TB_DEV void integrate_velocities(const KParams& P, Racket& rk, Ball& b, vec3 Fr, vec3 Tr, vec3 Fb) {
   const float dt = P.dt, g = P.gravity;
+  // the three speeds that do not wait for anything are taken first, side by side: a correctly rounded sqrtf is a
+  // ~16-instruction dependent chain, and three independent chains in one block interleave where three chains behind
+  // three branches queue (the values and every operation on them are the same as before: bit-identical)
+  const float speed_r = sqrtf(dot(rk.v, rk.v)), speed_b = sqrtf(dot(b.v, b.v)), spin_b = sqrtf(dot(b.w, b.w));
   {
-    float kd = FMA(P.lin_damp, sqrtf(dot(rk.v, rk.v)), P.lin_damp);
+    float kd = FMA(P.lin_damp, speed_r, P.lin_damp);
     vec3 a = mk(FMA(Fr.x, P.racket_inv_mass, -(rk.v.x * kd)), FMA(Fr.y, P.racket_inv_mass, -(rk.v.y * kd)),
                 FMA(Fr.z, P.racket_inv_mass, -(rk.v.z * kd)) - g);
     rk.v = fma3(dt, a, rk.v);
@@ -714,13 +718,13 @@ TB_DEV void integrate_velocities(const KParams& P, Racket& rk, Ball& b, vec3 Fr,
   }
   {
     if (P.magnus_k != 0.0f) Fb = fma3(P.magnus_k, cross(b.w, b.v), Fb);
-    float kd = FMA(P.lin_damp, sqrtf(dot(b.v, b.v)), P.lin_damp);
+    float kd = FMA(P.lin_damp, speed_b, P.lin_damp);
     vec3 a = mk(FMA(Fb.x, P.ball_inv_mass, -(b.v.x * kd)), FMA(Fb.y, P.ball_inv_mass, -(b.v.y * kd)),
                 FMA(Fb.z, P.ball_inv_mass, -(b.v.z * kd)) - g);
     b.v = fma3(dt, a, b.v);
     bool spinning = (b.w.x != 0.0f) | (b.w.y != 0.0f) | (b.w.z != 0.0f);
     if (spinning) {
-      float ka = FMA(P.ang_damp, sqrtf(dot(b.w, b.w)), P.ang_damp);
+      float ka = FMA(P.ang_damp, spin_b, P.ang_damp);
       vec3 aw = mk(-(b.w.x * ka), -(b.w.y * ka), -(b.w.z * ka));
       b.w = fma3(dt, aw, b.w);
     }

@@ -636,72 +636,72 @@ __global__ void tb_mark_kernel(unsigned long long* count) {
 // tb_set_racket_scale: one stream-ordered 4-byte store into the device-resident parameter block
 __global__ void tb_poke_kernel(float* dst, float v) { *dst = v; }
 
-// Finishes parked SwingRacket fast-forwards (side stream): same device code as the in-step loop, lane by lane; what
-// this kernel decides is WHICH lane runs which parked env, because the loop's cost is set by the slowest lane of a
-// wave and by the contact paths ANY lane of the wave enters (wave votes):
-//   SORT = false: wave w takes the A.ff_lanes records [w L, (w+1) L): at small batch sizes (4096 envs = 64 full waves
-//     on a chip with 1024 SIMDs) a few envs per wave spread the work over the idle SIMDs, a wave seldom has a lane in
-//     a contact path, and its loop length is that of its few lanes, not the maximum of 64;
-//   SORT = true: a 512-thread workgroup loads its 512 records, orders them by predicted flight length (predict_flight;
-//     counting sort over 256 bins in LDS, the records move through LDS) and wave k runs the k-th 64 of them: lanes of
-//     a wave finish together instead of idling until the longest flight of 64 random envs has landed (mean 108
-//     substeps, maximum of 64: ~170), and they are in the same phase of the flight, which is what makes the wave
-//     votes effective.
-// Results do not depend on the assignment (one lane = one world); tests/test_gpu_parity.py runs every variant.
-#define TB_FF_SORT_BLOCK 512
-template <bool RG, bool SORT>
-__global__ void __launch_bounds__(SORT ? TB_FF_SORT_BLOCK : 64) tb_ff_kernel(KArgs A) {
+// Orders the parked records of a slot by predicted flight length (predict_flight), 1024 at a time: counting sort over
+// 256 bins in LDS, each thread then writes its own record to its sorted place in a second buffer, which tb_ff_kernel
+// runs over 64 records per wave. Why: the fast-forward loop's cost is set by the slowest lane of a wave and by the contact
+// paths ANY lane enters (wave votes). 64 random envs: mean flight 108 substeps, maximum ~170, every lane landing in a
+// substep of its own (one contact solve per lane, paid by the whole wave). Sorted, the lanes of a wave finish together
+// and are in the same phase of the flight. A kernel of its own (not a prologue of tb_ff_kernel) so that the fast-forward
+// waves stay independent one-wave workgroups: a workgroup's registers are only released when its LAST wave ends, and
+// sorted workgroups would hold their short-flight waves' slots idle until their longest flight has landed (measured:
+// -20 % at 1 M envs). The source record's parked flag is cleared here; results never depend on which lane runs which env.
+#define TB_FF_SORT_BLOCK 1024
+__global__ void __launch_bounds__(TB_FF_SORT_BLOCK) tb_ff_sort_kernel(KArgs A, float4* sorted) {
+  __shared__ int s_hist[256];
+  const int lane = threadIdx.x & 63;
+  const int src = blockIdx.x * TB_FF_SORT_BLOCK + threadIdx.x;
+  if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
+  float4 r[TB_FF_REC];
+#pragma unroll
+  for (int k = 0; k < TB_FF_REC; ++k) r[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  int key = 255;  // not parked / beyond the batch: behind every real flight
+  if (src < A.n) {
+    float4* g = A.ff_rec + (size_t)src * TB_FF_REC;
+#pragma unroll
+    for (int k = 0; k < TB_FF_REC; ++k) r[k] = g[k];
+    if (__float_as_uint(r[7].z) == 1u) {
+      reinterpret_cast<uint32_t*>(g + 7)[2] = 0u;  // the copy in `sorted` is the parked one from here on
+      const int it = predict_flight(A.P, mk(r[3].y, r[3].z, r[3].w), mk(r[4].x, r[4].y, r[4].z));
+      key = it < 254 ? it : 254;
+    }
+  }
+  __syncthreads();
+  const int rank = atomicAdd(&s_hist[key], 1);
+  __syncthreads();
+  if (threadIdx.x < 64) {  // exclusive scan of the 256 bins by one wave: 4 bins per lane
+    const int c0 = s_hist[4 * lane], c1 = s_hist[4 * lane + 1], c2 = s_hist[4 * lane + 2], c3 = s_hist[4 * lane + 3];
+    const int sum = c0 + c1 + c2 + c3;
+    int inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { int o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
+    const int base = inc - sum;
+    s_hist[4 * lane] = base; s_hist[4 * lane + 1] = base + c0; s_hist[4 * lane + 2] = base + c0 + c1; s_hist[4 * lane + 3] = base + c0 + c1 + c2;
+  }
+  __syncthreads();
+  float4* d = sorted + ((size_t)blockIdx.x * TB_FF_SORT_BLOCK + (size_t)(s_hist[key] + rank)) * TB_FF_REC;  // (the buffer is padded to whole groups)
+#pragma unroll
+  for (int k = 0; k < TB_FF_REC; ++k) d[k] = r[k];
+}
+
+// Finishes parked SwingRacket fast-forwards (side stream): same device code as the in-step loop, lane by lane. Wave w
+// takes the A.ff_lanes records [w L, (w+1) L) of A.ff_rec -- the slot itself, or its copy sorted by tb_ff_sort_kernel
+// (A.n then counts the padded groups). L < 64 (small batches, TbOptions.ff_lanes_per_wave) spreads few envs per wave
+// over more SIMDs: the kernel gets shorter (380 -> 250 us at 4096 envs with L = 16) but its waves then sit on the SIMDs
+// the step kernels need (-4 ... -7 % whole-rollout rate), so 64 is the default from 4096 envs on.
+template <bool RG>
+__global__ void __launch_bounds__(64) tb_ff_kernel(KArgs A) {
   __shared__ float4 s_hull[TB_HULL_LDS];
-  __shared__ float4 s_rec[SORT ? TB_FF_SORT_BLOCK * TB_FF_REC : 1];
-  __shared__ int s_hist[SORT ? 256 : 1];
   const int lane = threadIdx.x & 63;
   float4 r[TB_FF_REC];
   bool live = false;
-  if (SORT) {
-    const int src = blockIdx.x * TB_FF_SORT_BLOCK + threadIdx.x;
-    if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
-    int key = 255;  // not parked / beyond the batch: behind every real flight
+  const int src = blockIdx.x * A.ff_lanes + lane;
+  if (lane < A.ff_lanes && src < A.n) {
+    const float4* g = A.ff_rec + (size_t)src * TB_FF_REC;
 #pragma unroll
-    for (int k = 0; k < TB_FF_REC; ++k) r[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (src < A.n) {
-      const float4* g = A.ff_rec + (size_t)src * TB_FF_REC;
-#pragma unroll
-      for (int k = 0; k < TB_FF_REC; ++k) r[k] = g[k];
-      if (__float_as_uint(r[7].z) == 1u) {
-        int it = predict_flight(A.P, mk(r[3].y, r[3].z, r[3].w), mk(r[4].x, r[4].y, r[4].z));
-        key = it < 254 ? it : 254;
-      }
-    }
-    stage_hull(s_hull, A);  // (its barrier also publishes the zeroed histogram)
-    const int rank = atomicAdd(&s_hist[key], 1);
-    __syncthreads();
-    if (threadIdx.x < 64) {  // exclusive scan of the 256 bins by one wave: 4 bins per lane
-      int c0 = s_hist[4 * lane], c1 = s_hist[4 * lane + 1], c2 = s_hist[4 * lane + 2], c3 = s_hist[4 * lane + 3];
-      int sum = c0 + c1 + c2 + c3, inc = sum;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) { int o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
-      int base = inc - sum;
-      s_hist[4 * lane] = base; s_hist[4 * lane + 1] = base + c0; s_hist[4 * lane + 2] = base + c0 + c1; s_hist[4 * lane + 3] = base + c0 + c1 + c2;
-    }
-    __syncthreads();
-    const int pos = s_hist[key] + rank;
-#pragma unroll
-    for (int k = 0; k < TB_FF_REC; ++k) s_rec[pos * TB_FF_REC + k] = r[k];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < TB_FF_REC; ++k) r[k] = s_rec[threadIdx.x * TB_FF_REC + k];
+    for (int k = 0; k < TB_FF_REC; ++k) r[k] = g[k];
     live = __float_as_uint(r[7].z) == 1u;
-  } else {
-    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int src = wave * A.ff_lanes + lane;
-    if (lane < A.ff_lanes && src < A.n) {
-      const float4* g = A.ff_rec + (size_t)src * TB_FF_REC;
-#pragma unroll
-      for (int k = 0; k < TB_FF_REC; ++k) r[k] = g[k];
-      live = __float_as_uint(r[7].z) == 1u;
-    }
-    stage_hull(s_hull, A);
   }
+  stage_hull(s_hull, A);
   uint32_t cnt[TB_N_COUNTERS];
 #pragma unroll
   for (int k = 0; k < TB_N_COUNTERS; ++k) cnt[k] = 0u;
@@ -727,9 +727,21 @@ __global__ void __launch_bounds__(SORT ? TB_FF_SORT_BLOCK : 64) tb_ff_kernel(KAr
     if (A.term_obs) write_obs<TB_ENV_SWING>(A.term_obs, (size_t)i, o);
     A.reward[i] = rew;
     if (A.substeps) A.substeps[i] = ns;
-    reinterpret_cast<uint32_t*>(A.ff_rec + (size_t)i * TB_FF_REC + 7)[2] = 0u;  // the record is free again
+    reinterpret_cast<uint32_t*>(A.ff_rec + (size_t)src * TB_FF_REC + 7)[2] = 0u;  // the record is free again
   }
   flush_counters(A.counters, cnt);
+#ifdef TB_DIAG_STAMPS
+  {  // the lane that stayed in the loop longest has the wave's complete account (see tb_step_kernel)
+    unsigned int mine = 0u;
+    for (int k = 0; k < 6; ++k) mine += st.acc[k];
+    unsigned int best = mine;
+    for (int off = 32; off > 0; off >>= 1) { unsigned int o = __shfl_xor(best, off, 64); best = o > best ? o : best; }
+    const unsigned long long holders = __ballot(mine == best);
+    if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)holders) - 1u)
+      for (int k = 0; k < 6; ++k) atomicAdd(&g_diag_cycles[k], (unsigned long long)st.acc[k]);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_diag_cycles[9], 1ull);
+  }
+#endif
 }
 
 // reset kernel (masked)
@@ -881,6 +893,7 @@ struct TbHandle {
   const void *last_term, *last_sub;  // shared late-written buffers force ordering between fast-forwards
   int last_slot;
   float4* d_ff_rec[TB_FF_SLOTS];  // [n][TB_FF_REC] parked records (park_env)
+  float4* d_ff_sorted[TB_FF_SLOTS];  // ff_sort: the slot's records in the order tb_ff_sort_kernel gives them, padded to whole sort groups
   int ff_lanes, ff_sort;          // how tb_ff_kernel hands records to lanes (TbOptions.ff_lanes_per_wave / ff_sort, or chosen from n)
   hipEvent_t ev_step[TB_FF_SLOTS], ev_ff[TB_FF_SLOTS];
   int ff_busy[TB_FF_SLOTS], next_slot;
@@ -949,22 +962,20 @@ int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const 
   // phase every step is followed by this kernel and nearly every record is idle: plain 64 per wave, one flag test each
   const bool sort = h->ff_sort && h->phase_valid;
   a.ff_lanes = sort || !h->phase_valid ? 64 : h->ff_lanes;
-  dim3 grid, block;
-  if (sort) { grid = dim3((unsigned)((h->n + TB_FF_SORT_BLOCK - 1) / TB_FF_SORT_BLOCK)); block = dim3(TB_FF_SORT_BLOCK); }
-  else { grid = dim3((unsigned)((h->n + a.ff_lanes - 1) / a.ff_lanes)); block = dim3(64); }
+  const int groups = (h->n + TB_FF_SORT_BLOCK - 1) / TB_FF_SORT_BLOCK;
   HIP_TRY(hipEventRecord(h->ev_step[slot], s));
   HIP_TRY(hipStreamWaitEvent(h->side[slot], h->ev_step[slot], 0));
   // two fast-forwards that write the same terminal-obs / substeps buffer must finish in order
   if (h->last_slot >= 0 && h->last_slot != slot && ((term && term == h->last_term) || (substeps && substeps == h->last_sub)))
     HIP_TRY(hipStreamWaitEvent(h->side[slot], h->ev_ff[h->last_slot], 0));
-  const bool rg = extended_contacts(h->kp);
   if (sort) {
-    if (rg) hipLaunchKernelGGL((tb_ff_kernel<true, true>), grid, block, 0, h->side[slot], a);
-    else hipLaunchKernelGGL((tb_ff_kernel<false, true>), grid, block, 0, h->side[slot], a);
-  } else {
-    if (rg) hipLaunchKernelGGL((tb_ff_kernel<true, false>), grid, block, 0, h->side[slot], a);
-    else hipLaunchKernelGGL((tb_ff_kernel<false, false>), grid, block, 0, h->side[slot], a);
+    hipLaunchKernelGGL(tb_ff_sort_kernel, dim3((unsigned)groups), dim3(TB_FF_SORT_BLOCK), 0, h->side[slot], a, h->d_ff_sorted[slot]);
+    HIP_TRY(hipGetLastError());
+    a.ff_rec = h->d_ff_sorted[slot]; a.n = groups * TB_FF_SORT_BLOCK;  // (outputs are addressed by the env index each record carries)
   }
+  const dim3 grid((unsigned)((a.n + a.ff_lanes - 1) / a.ff_lanes)), block(64);
+  if (extended_contacts(h->kp)) hipLaunchKernelGGL(tb_ff_kernel<true>, grid, block, 0, h->side[slot], a);
+  else hipLaunchKernelGGL(tb_ff_kernel<false>, grid, block, 0, h->side[slot], a);
   HIP_TRY(hipGetLastError());
   if (h->h_marks && h->marks_on) {  // progress marks: count this fast-forward as finished, in stream order behind it
     hipLaunchKernelGGL(tb_mark_kernel, dim3(1), dim3(1), 0, h->side[slot], h->h_marks + TB_MAX_MARKS);
@@ -1126,10 +1137,10 @@ int tb_create(const TbParams* params, const TbOptions* options, int env_kind, in
   // kernel runs at 70 % of HBM peak and occupancy counts, loses 3 % at 1 M envs
   h->reg_rows = env_kind == TB_ENV_TENNIS && (opt.tennis_reg_rows ? opt.tennis_reg_rows > 0 : 1);
   h->swing_reg_rows = env_kind == TB_ENV_SWING && (opt.swing_reg_rows ? opt.swing_reg_rows > 0 : n_envs <= 131072);
-  // fast-forward: spread small batches over the chip's 1024 SIMDs (>= 4 envs per wave), sort the lanes of large ones
+  // fast-forward: sort the lanes of large batches by predicted flight length; below 4096 envs a few envs per wave
   h->ff_sort = opt.ff_sort ? opt.ff_sort > 0 : n_envs >= 32768;
   h->ff_lanes = opt.ff_lanes_per_wave;
-  if (!h->ff_lanes) { h->ff_lanes = 4; while (h->ff_lanes < 64 && (long long)h->ff_lanes * 1024 < n_envs) h->ff_lanes <<= 1; }
+  if (!h->ff_lanes) { h->ff_lanes = 4; while (h->ff_lanes < 64 && (long long)h->ff_lanes * 64 < n_envs) h->ff_lanes <<= 1; }
   const int nw = words_of(env_kind);
   hipError_t err;
 #define CREATE_TRY(expr) if ((err = (expr)) != hipSuccess) { int rc = fail((int)err, #expr); tb_destroy(h); return rc; }
@@ -1159,6 +1170,7 @@ int tb_destroy(TbHandle* h) {
   if (h->d_counters) (void)hipFree(h->d_counters);
   for (int k = 0; k < TB_FF_SLOTS; ++k) {
     if (h->d_ff_rec[k]) (void)hipFree(h->d_ff_rec[k]);
+    if (h->d_ff_sorted[k]) (void)hipFree(h->d_ff_sorted[k]);
     if (h->ev_step[k]) (void)hipEventDestroy(h->ev_step[k]);
     if (h->ev_ff[k]) (void)hipEventDestroy(h->ev_ff[k]);
   }
@@ -1180,6 +1192,11 @@ int tb_set_pipeline(TbHandle* h, int enable) {
       HIP_TRY(hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
       HIP_TRY(hipMalloc((void**)&h->d_ff_rec[k], wb));
       HIP_TRY(hipMemset(h->d_ff_rec[k], 0, wb));  // word 30 of a record = 1 while an env is parked in it
+      if (h->ff_sort) {
+        const size_t sb = sizeof(float4) * (size_t)TB_FF_REC * TB_FF_SORT_BLOCK * ((h->n + TB_FF_SORT_BLOCK - 1) / TB_FF_SORT_BLOCK);
+        HIP_TRY(hipMalloc((void**)&h->d_ff_sorted[k], sb));
+        HIP_TRY(hipMemset(h->d_ff_sorted[k], 0, sb));
+      }
       HIP_TRY(hipEventCreateWithFlags(&h->ev_step[k], hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&h->ev_ff[k], hipEventDisableTiming));
     }

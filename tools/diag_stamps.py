@@ -26,7 +26,11 @@ rng = np.random.Generator(np.random.PCG64(0))
 acts = torch.from_numpy(rng.uniform(-1, 1, (104, n, 6)).astype(np.float32)).cuda()
 from tennisbot_rl_amd.params import F_DEFAULT, F_RACKET_GROUND, default_params  # noqa: E402
 flags = F_DEFAULT | (F_RACKET_GROUND if os.environ.get("TB_DIAG_RACKET_GROUND") == "1" else 0)
-env = stepper.BatchedEnv(ENV_SWING, n, seed=0, reuse_buffers=True, params=default_params(flags=flags))
+lanes = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # > 0: pipelined, tb_ff_kernel with that many parked envs per wave
+if lanes:
+    env = stepper.BatchedEnv(ENV_SWING, n, seed=0, params=default_params(flags=flags), pipeline=True, track_terminal_obs=False, options=dict(ff_lanes_per_wave=lanes, ff_sort=False))
+else:
+    env = stepper.BatchedEnv(ENV_SWING, n, seed=0, reuse_buffers=True, params=default_params(flags=flags))
 env.reset()
 names = ["between substeps", "racket narrowphase", "static narrowphase", "velocity update", "contact solve", "pose update"]
 buf = (ctypes.c_ulonglong * 16)()
@@ -36,6 +40,7 @@ for ep in range(2):
             L.tb_diag_read_stamps(buf, 1)
             short = list(buf)
         env.step(acts[(ep * 26 + t) % 104])
+    env.flush() if lanes else None
     L.tb_diag_read_stamps(buf, 1)
     ff = list(buf)
     for label, v, launches in (("25 short steps", short, 25), ("fast-forward step", ff, 1)):
@@ -50,4 +55,8 @@ for ep in range(2):
             print("    shader clock while this kernel ran: %.2f GHz (s_memtime / s_memrealtime)" % (v[8] / v[14] * 0.1))
         print("    wave-substeps %d, with a lane inside the racket's bounding sphere %d, with a lane running the outline sweep %d (lane-sweeps %d)"
               % (v[13], v[12], v[11], v[10]))
-print("max substeps of last fast-forward:", int(env.last_substeps().max()))
+if lanes:
+    print("(pipelined: 'fast-forward step' = the 26th step kernel + tb_ff_kernel with %d envs per wave; per wave-substep: %s)" % (
+        lanes, ", ".join("%s %.0f" % (names[k], ff[k] / max(ff[13], 1)) for k in range(6))))
+else:
+    print("max substeps of last fast-forward:", int(env.last_substeps().max()))

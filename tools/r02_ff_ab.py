@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""A/B of the fast-forward kernel's lane assignment on ONE box (boxes differ by several percent): whole-rollout
+rate of SwingRacket-v0 for TbOptions.ff_lanes_per_wave / ff_sort variants, plus the one-episode rollout (26 steps +
+join) that exposes the fast-forward kernel's own duration."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+
+def measure(n, T, opts, reps=5, flags=None):
+    from tennisbot_rl_amd.params import ENV_SWING, F_DEFAULT, default_params
+    from tennisbot_rl_amd.rollout import RolloutBuffer
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    dev = torch.device("cuda", 0)
+    env = BatchedEnv(ENV_SWING, n, device=dev, seed=0, params=default_params(flags=F_DEFAULT if flags is None else flags), track_terminal_obs=False, pipeline=True, options=opts)
+    buf = RolloutBuffer(ENV_SWING, T, n, dev)
+    buf.actions.uniform_(-1.0, 1.0)
+    buf.bind(env)
+    env.reset()
+    for t in range(26):
+        buf.step_into(env, t)
+    env.flush()
+    g = env.capture(lambda: buf.step_range(env, 0, T))
+    g.replay(); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); g.replay(); torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    # one episode + join: 26 step launches, then nothing to hide the fast-forward behind
+    g1 = env.capture(lambda: buf.step_range(env, 0, 26))
+    g1.replay(); torch.cuda.synchronize()
+    one = 1e9
+    for _ in range(reps):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); g1.replay(); torch.cuda.synchronize()
+        one = min(one, time.perf_counter() - t0)
+    c = env.counters()
+    env.close(); del buf
+    torch.cuda.empty_cache()
+    return {"n": n, "T": T, "opts": opts, "steps_per_s": n * T / best, "us_per_step": best / T * 1e6, "one_episode_ms": one * 1e3, "timeouts": c["timeouts"]}
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    out = []
+    if which in ("all", "small"):
+        for lanes in (64, 32, 16, 8, 4, 2):
+            out.append(measure(4096, 1040, dict(ff_lanes_per_wave=lanes, ff_sort=False)))
+            print(json.dumps(out[-1]), flush=True)
+        out.append(measure(4096, 1040, dict(ff_sort=True)))
+        print(json.dumps(out[-1]), flush=True)
+        for n in (16384, 32768):
+            for o in (dict(ff_lanes_per_wave=64, ff_sort=False), dict(ff_lanes_per_wave=16, ff_sort=False), dict(ff_sort=True)):
+                out.append(measure(n, 520, o))
+                print(json.dumps(out[-1]), flush=True)
+    if which in ("all", "large"):
+        for n in (262144, 1048576):
+            for o in (dict(ff_lanes_per_wave=64, ff_sort=False), dict(ff_sort=True)):
+                out.append(measure(n, 104, o, reps=3))
+                print(json.dumps(out[-1]), flush=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r02_ff_ab_%s.json" % which), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
