@@ -164,9 +164,11 @@ typedef struct TbOptions {
   int32_t block;            /* threads per workgroup of the step kernels: 64, 128 or 256 (auto: 64 up to 131072 envs, 256 above) */
   int32_t tennis_reg_rows;  /* Tennisbot static contact rows in registers: 1 on, -1 off (auto: on) */
   int32_t swing_reg_rows;   /* the same for the pipelined SwingRacket step kernel: 1 on, -1 off (auto: on up to 131072 envs) */
-  int32_t ff_lanes_per_wave; /* parked envs per wave of the fast-forward kernel, 1..64 (auto: spread n envs over the chip's SIMDs) */
-  int32_t ff_sort;          /* order parked envs by predicted flight length before the fast-forward: 1 on, -1 off (auto: on from 32768 envs) */
-  int32_t reserved[2];
+  int32_t ff_lanes_per_wave; /* parked envs per wave in the first fast-forward phase, 1..64 (auto: 64 from 4096 envs on, fewer below) */
+  int32_t ff_sort;          /* order parked envs by their ball's ballistic flight estimate before the fast-forward: 1 on (auto: off --
+                             * with random actions the flight lengths are decided by events inside the loop, not by the parked state) */
+  int32_t ff_phases;        /* the fast-forward as 1, 2 or 3 kernels: budgeted loop, then its compacted survivors (auto: 3) */
+  int32_t reserved;
 } TbOptions;
 
 /* library identity / shape queries (host only, no device touched) */

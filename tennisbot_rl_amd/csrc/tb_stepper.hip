@@ -48,7 +48,10 @@ struct KArgs {
   // pipelined fast-forward (tb_set_pipeline): a step that starts a SwingRacket fast-forward parks
   // the env's pre-loop state in a slot and resets the env; tb_ff_kernel finishes it on a side stream
   float4* ff_rec;         // [n][TB_FF_REC] slot: one 128-byte record per env (park_env), word 30 = 1 while parked
-  int ff_lanes;           // tb_ff_kernel: parked envs per wave (sparse waves at small batch sizes), 64 when it sorts
+  int ff_lanes;           // tb_ff_kernel: parked envs per wave (a few per wave at small batch sizes)
+  float4* ff_next;        // tb_ff_kernel: where envs still running when their budget is spent are compacted to (null = last phase: no budget)
+  int* ff_next_count;     // ... and how many there are so far
+  const int* ff_src_count;  // tb_ff_kernel, phases 2+: how many records ff_rec holds (null = A.n slots, parked or not)
   int defer;
   // fused policy inference (tb_policy_step): actions are computed in-kernel from pol_obs
   const float* pol_weights;  // packed SB3 MlpPolicy towers, see PolicyNet
@@ -267,9 +270,11 @@ TB_DEV vec3 restoring_force(const EnvRegs& e) {  // swingracket_env.py:135-141
 //                    later ones with the restoring force of :135-141.
 // `in_ff` = start inside the fast-forward (tb_ff_kernel resuming a parked env).
 // `defer`  = leave the fast-forward to tb_ff_kernel: sets `parked` instead of looping.
-template <bool RG, bool REGROWS = false, bool COLD = false>
+// BUDGET  = tb_ff_kernel only: leave the loop after `budget` substeps with the env still running (`parked` again): the
+//           next phase kernel resumes it from the saved state, with the restoring force recomputed from that state.
+template <bool RG, bool REGROWS = false, bool COLD = false, bool BUDGET = false>
 TB_DEV float swing_loop(const KParams& P, const float4* hull, EnvRegs& e, vec3 F, vec3 T, bool in_ff, bool defer, bool& parked,
-                        int& ns, uint32_t* cnt TB_STAMP_ARG) {
+                        int& ns, uint32_t* cnt TB_STAMP_ARG, int budget = 0) {
   const vec3 zero = mk(0.0f, 0.0f, 0.0f);
   float reward = 0.0f;
   for (;;) {
@@ -287,6 +292,7 @@ TB_DEV float swing_loop(const KParams& P, const float4* hull, EnvRegs& e, vec3 F
       if (e.step_count > 800) { if (!e.done) cnt[3]++; e.done = TB_DONE_PENDING_FORCE; }  // :127-128
       if (e.done) break;
       F = restoring_force(e);  // :135-141 (also issued when done just became true; it then waits in the accumulator: TB_DONE_PENDING_FORCE)
+      if (BUDGET && --budget <= 0) { parked = true; break; }
     }
   }
   return reward;
@@ -683,24 +689,23 @@ __global__ void __launch_bounds__(TB_FF_SORT_BLOCK) tb_ff_sort_kernel(KArgs A, f
   for (int k = 0; k < TB_FF_REC; ++k) d[k] = r[k];
 }
 
-// Finishes parked SwingRacket fast-forwards (side stream): same device code as the in-step loop, lane by lane. Wave w
-// takes the A.ff_lanes records [w L, (w+1) L) of A.ff_rec -- the slot itself, or its copy sorted by tb_ff_sort_kernel
-// (A.n then counts the padded groups). L < 64 (small batches, TbOptions.ff_lanes_per_wave) spreads few envs per wave
-// over more SIMDs: the kernel gets shorter (380 -> 250 us at 4096 envs with L = 16) but its waves then sit on the SIMDs
-// the step kernels need (-4 ... -7 % whole-rollout rate), so 64 is the default from 4096 envs on.
+// Finishes parked SwingRacket fast-forwards (side stream): same device code as the in-step loop, lane by lane.
+// What this kernel adds is lane utilisation. A wave loops until its slowest lane is done, and with random actions the
+// flights are 103 substeps for 80 % of the envs (balls that were never struck drop from the same height) but 111 at the
+// 90th percentile, 167 at the 99th and up to 775 -- decided by what happens DURING the loop (the tumbling racket strikes
+// the ball, it lands on the goal or the net), not by anything the parked state shows. 64 random lanes wait for their
+// maximum: ~170 substeps per wave for a mean of 108 (63 %). So the loop runs in PHASES: every lane gets a budget --
+// the ballistic estimate of its ball's remaining flight (predict_flight) plus a margin -- and a lane whose env is still
+// running when the budget is spent writes its state to a compacted list and leaves; the next phase kernel runs those
+// survivors, packed 64 to a wave again, with a new estimate; the last phase has no budget. Measured wave-substeps per
+// 64 envs: 170 -> 112 + 0.1 x 60 + ... ~ 125. The state a survivor carries is exactly the loop's state (the restoring
+// force is a function of it), so results are bit-identical however the phases cut (tests/test_gpu_parity.py).
+//   phase 1: wave w takes the A.ff_lanes records [w L, (w+1) L) of the slot (L < 64: few envs per wave at small batches);
+//   phases 2+: grid-stride over the *A.ff_src_count survivors of the previous phase, 64 per wave.
 template <bool RG>
 __global__ void __launch_bounds__(64) tb_ff_kernel(KArgs A) {
   __shared__ float4 s_hull[TB_HULL_LDS];
   const int lane = threadIdx.x & 63;
-  float4 r[TB_FF_REC];
-  bool live = false;
-  const int src = blockIdx.x * A.ff_lanes + lane;
-  if (lane < A.ff_lanes && src < A.n) {
-    const float4* g = A.ff_rec + (size_t)src * TB_FF_REC;
-#pragma unroll
-    for (int k = 0; k < TB_FF_REC; ++k) r[k] = g[k];
-    live = __float_as_uint(r[7].z) == 1u;
-  }
   stage_hull(s_hull, A);
   uint32_t cnt[TB_N_COUNTERS];
 #pragma unroll
@@ -710,24 +715,58 @@ __global__ void __launch_bounds__(64) tb_ff_kernel(KArgs A) {
   for (int k = 0; k < 8; ++k) st.acc[k] = 0u;
   st.t = stamp_now();
 #endif
-  if (live) {
+  const int n_src = A.ff_src_count ? *A.ff_src_count : A.n;
+  for (int base = blockIdx.x * A.ff_lanes; base < n_src; base += gridDim.x * A.ff_lanes) {
+    float4 r[TB_FF_REC];
+    bool live = false;
+    const int src = base + lane;
+    if (lane < A.ff_lanes && src < n_src) {
+      const float4* g = A.ff_rec + (size_t)src * TB_FF_REC;
+#pragma unroll
+      for (int k = 0; k < TB_FF_REC; ++k) r[k] = g[k];
+      live = (__float_as_uint(r[7].z) & 255u) != 0u;
+    }
+    bool unfinished = false;
     EnvRegs e;
-    int i;
-    unpark_env(r, e, i);
-    int ns = 1;           // the step kernel ran the first substep of this agent step
-    bool parked = false;
-    const vec3 zero = mk(0.0f, 0.0f, 0.0f);
-    float rew = swing_loop<RG>(A.P, s_hull, e, zero, zero, true, false, parked, ns, cnt TB_STAMP_PASS);
-    cnt[6] += (uint32_t)(ns - 1);
-    if (!(finite3(e.r.p) && finite3(e.r.v) && finite3(e.r.w) && finite3(e.b.p) && finite3(e.b.v) && finite3(e.b.w) &&
-          isfinite(e.r.q.x) && isfinite(e.r.q.y) && isfinite(e.r.q.z) && isfinite(e.r.q.w)))
-      cnt[7]++;
-    float o[TB_SWING_OBS_DIM];
-    make_obs<TB_ENV_SWING>(e, o);
-    if (A.term_obs) write_obs<TB_ENV_SWING>(A.term_obs, (size_t)i, o);
-    A.reward[i] = rew;
-    if (A.substeps) A.substeps[i] = ns;
-    reinterpret_cast<uint32_t*>(A.ff_rec + (size_t)src * TB_FF_REC + 7)[2] = 0u;  // the record is free again
+    int i = 0, ns = 1;  // fresh from the step kernel: it ran the first substep of this agent step
+    if (live) {
+      unpark_env(r, e, i);
+      const uint32_t tag = __float_as_uint(r[7].z);
+      if ((tag & 255u) == 2u) ns = (int)(tag >> 8);  // a survivor of an earlier phase: substeps so far
+      const vec3 zero = mk(0.0f, 0.0f, 0.0f);
+      // the first loop substep runs without any force (the accumulators were cleared by the agent's substep), every later
+      // one with the restoring force of the state before it (swingracket_env.py:135-141): what a resumed env recomputes
+      const vec3 F0 = e.step_count > 26 ? restoring_force(e) : zero;
+      const int budget = A.ff_next ? 4 * predict_flight(A.P, e.b.p, e.b.v) + 8 : 0x7fffffff;
+      const int ns0 = ns;
+      float rew = swing_loop<RG, false, false, true>(A.P, s_hull, e, F0, zero, true, false, unfinished, ns, cnt TB_STAMP_PASS, budget);
+      cnt[6] += (uint32_t)(ns - ns0);
+      if (!unfinished) {
+        if (!(finite3(e.r.p) && finite3(e.r.v) && finite3(e.r.w) && finite3(e.b.p) && finite3(e.b.v) && finite3(e.b.w) &&
+              isfinite(e.r.q.x) && isfinite(e.r.q.y) && isfinite(e.r.q.z) && isfinite(e.r.q.w)))
+          cnt[7]++;
+        float o[TB_SWING_OBS_DIM];
+        make_obs<TB_ENV_SWING>(e, o);
+        if (A.term_obs) write_obs<TB_ENV_SWING>(A.term_obs, (size_t)i, o);
+        A.reward[i] = rew;  // (a survivor has earned nothing yet: every reward of the loop is paid in its last substep)
+        if (A.substeps) A.substeps[i] = ns;
+      }
+      reinterpret_cast<uint32_t*>(A.ff_rec + (size_t)src * TB_FF_REC + 7)[2] = 0u;  // the record is free again
+    }
+    if (A.ff_next) {  // survivors: one atomic per wave reserves their places in the next phase's list
+      const unsigned long long m = __ballot(unfinished);
+      if (m) {
+        int first = 0;
+        if (lane == 0) first = atomicAdd(A.ff_next_count, __popcll(m));
+        first = __shfl(first, 0, 64);
+        if (unfinished) {
+          park_env(A.ff_next, first + __popcll(m & ((1ull << lane) - 1ull)), e);
+          uint32_t* w = reinterpret_cast<uint32_t*>(A.ff_next + (size_t)(first + __popcll(m & ((1ull << lane) - 1ull))) * TB_FF_REC + 7);
+          w[2] = 2u | ((uint32_t)ns << 8);
+          w[3] = (uint32_t)i;
+        }
+      }
+    }
   }
   flush_counters(A.counters, cnt);
 #ifdef TB_DIAG_STAMPS
@@ -894,6 +933,9 @@ struct TbHandle {
   int last_slot;
   float4* d_ff_rec[TB_FF_SLOTS];  // [n][TB_FF_REC] parked records (park_env)
   float4* d_ff_sorted[TB_FF_SLOTS];  // ff_sort: the slot's records in the order tb_ff_sort_kernel gives them, padded to whole sort groups
+  float4* d_ff_list[TB_FF_SLOTS][2];  // survivors of fast-forward phases 1 and 2 (worst case: every env), compacted
+  int* d_ff_count[TB_FF_SLOTS];       // [2] their numbers
+  int ff_phases;                      // 1 = one kernel runs every loop to its end; 2, 3 = budgeted phases + survivor kernels
   int ff_lanes, ff_sort;          // how tb_ff_kernel hands records to lanes (TbOptions.ff_lanes_per_wave / ff_sort, or chosen from n)
   hipEvent_t ev_step[TB_FF_SLOTS], ev_ff[TB_FF_SLOTS];
   int ff_busy[TB_FF_SLOTS], next_slot;
@@ -973,9 +1015,24 @@ int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const 
     HIP_TRY(hipGetLastError());
     a.ff_rec = h->d_ff_sorted[slot]; a.n = groups * TB_FF_SORT_BLOCK;  // (outputs are addressed by the env index each record carries)
   }
-  const dim3 grid((unsigned)((a.n + a.ff_lanes - 1) / a.ff_lanes)), block(64);
-  if (extended_contacts(h->kp)) hipLaunchKernelGGL(tb_ff_kernel<true>, grid, block, 0, h->side[slot], a);
-  else hipLaunchKernelGGL(tb_ff_kernel<false>, grid, block, 0, h->side[slot], a);
+  // phases: budgeted loop + survivor kernels (see tb_ff_kernel). Without the host knowing the episode phase nearly every
+  // record is idle: one plain kernel.
+  const int phases = h->phase_valid ? h->ff_phases : 1;
+  const bool rg = extended_contacts(h->kp);
+  if (phases > 1) HIP_TRY(hipMemsetAsync(h->d_ff_count[slot], 0, 2 * sizeof(int), h->side[slot]));
+  for (int ph = 0; ph < phases; ++ph) {
+    KArgs k = a;
+    dim3 grid((unsigned)((a.n + a.ff_lanes - 1) / a.ff_lanes)), block(64);
+    if (ph > 0) {  // survivors of phase ph: a compacted list of unknown length, walked by a fixed grid
+      k.ff_rec = h->d_ff_list[slot][ph - 1]; k.ff_src_count = h->d_ff_count[slot] + (ph - 1); k.ff_lanes = 64;
+      int g = h->n / 512; g = g < 64 ? 64 : g;
+      grid = dim3((unsigned)g);
+    }
+    if (ph + 1 < phases) { k.ff_next = h->d_ff_list[slot][ph]; k.ff_next_count = h->d_ff_count[slot] + ph; }
+    if (rg) hipLaunchKernelGGL(tb_ff_kernel<true>, grid, block, 0, h->side[slot], k);
+    else hipLaunchKernelGGL(tb_ff_kernel<false>, grid, block, 0, h->side[slot], k);
+    HIP_TRY(hipGetLastError());
+  }
   HIP_TRY(hipGetLastError());
   if (h->h_marks && h->marks_on) {  // progress marks: count this fast-forward as finished, in stream order behind it
     hipLaunchKernelGGL(tb_mark_kernel, dim3(1), dim3(1), 0, h->side[slot], h->h_marks + TB_MAX_MARKS);
@@ -1119,6 +1176,7 @@ int tb_create(const TbParams* params, const TbOptions* options, int env_kind, in
     memcpy(&opt, options, options->struct_size < sizeof opt ? options->struct_size : sizeof opt);
     if (opt.block != 0 && opt.block != 64 && opt.block != 128 && opt.block != 256) return fail(TB_E_INVAL, "tb_create: TbOptions.block must be 0, 64, 128 or 256");
     if (opt.ff_lanes_per_wave < 0 || opt.ff_lanes_per_wave > 64) return fail(TB_E_INVAL, "tb_create: TbOptions.ff_lanes_per_wave must be in [0, 64]");
+    if (opt.ff_phases < 0 || opt.ff_phases > 3) return fail(TB_E_INVAL, "tb_create: TbOptions.ff_phases must be in [0, 3]");
   }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -1138,7 +1196,8 @@ int tb_create(const TbParams* params, const TbOptions* options, int env_kind, in
   h->reg_rows = env_kind == TB_ENV_TENNIS && (opt.tennis_reg_rows ? opt.tennis_reg_rows > 0 : 1);
   h->swing_reg_rows = env_kind == TB_ENV_SWING && (opt.swing_reg_rows ? opt.swing_reg_rows > 0 : n_envs <= 131072);
   // fast-forward: sort the lanes of large batches by predicted flight length; below 4096 envs a few envs per wave
-  h->ff_sort = opt.ff_sort ? opt.ff_sort > 0 : n_envs >= 32768;
+  h->ff_sort = opt.ff_sort > 0;  // opt-in: pays when flight lengths can be told from the parked state (a trained policy's struck balls)
+  h->ff_phases = opt.ff_phases >= 1 && opt.ff_phases <= 3 ? opt.ff_phases : 3;
   h->ff_lanes = opt.ff_lanes_per_wave;
   if (!h->ff_lanes) { h->ff_lanes = 4; while (h->ff_lanes < 64 && (long long)h->ff_lanes * 64 < n_envs) h->ff_lanes <<= 1; }
   const int nw = words_of(env_kind);
@@ -1171,6 +1230,9 @@ int tb_destroy(TbHandle* h) {
   for (int k = 0; k < TB_FF_SLOTS; ++k) {
     if (h->d_ff_rec[k]) (void)hipFree(h->d_ff_rec[k]);
     if (h->d_ff_sorted[k]) (void)hipFree(h->d_ff_sorted[k]);
+    if (h->d_ff_list[k][0]) (void)hipFree(h->d_ff_list[k][0]);
+    if (h->d_ff_list[k][1]) (void)hipFree(h->d_ff_list[k][1]);
+    if (h->d_ff_count[k]) (void)hipFree(h->d_ff_count[k]);
     if (h->ev_step[k]) (void)hipEventDestroy(h->ev_step[k]);
     if (h->ev_ff[k]) (void)hipEventDestroy(h->ev_ff[k]);
   }
@@ -1192,6 +1254,9 @@ int tb_set_pipeline(TbHandle* h, int enable) {
       HIP_TRY(hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
       HIP_TRY(hipMalloc((void**)&h->d_ff_rec[k], wb));
       HIP_TRY(hipMemset(h->d_ff_rec[k], 0, wb));  // word 30 of a record = 1 while an env is parked in it
+      for (int ph = 0; ph + 1 < h->ff_phases; ++ph) HIP_TRY(hipMalloc((void**)&h->d_ff_list[k][ph], wb));
+      HIP_TRY(hipMalloc((void**)&h->d_ff_count[k], 2 * sizeof(int)));
+      HIP_TRY(hipMemset(h->d_ff_count[k], 0, 2 * sizeof(int)));
       if (h->ff_sort) {
         const size_t sb = sizeof(float4) * (size_t)TB_FF_REC * TB_FF_SORT_BLOCK * ((h->n + TB_FF_SORT_BLOCK - 1) / TB_FF_SORT_BLOCK);
         HIP_TRY(hipMalloc((void**)&h->d_ff_sorted[k], sb));

@@ -82,17 +82,17 @@ class TbOptions(ctypes.Structure):
     They never change a result, only which bit-identical instantiation runs."""
     _fields_ = [("struct_size", ctypes.c_uint32), ("block", ctypes.c_int32), ("tennis_reg_rows", ctypes.c_int32),
                 ("swing_reg_rows", ctypes.c_int32), ("ff_lanes_per_wave", ctypes.c_int32), ("ff_sort", ctypes.c_int32),
-                ("reserved", ctypes.c_int32 * 2)]
+                ("ff_phases", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
-def make_options(block=0, tennis_reg_rows=None, swing_reg_rows=None, ff_lanes_per_wave=0, ff_sort=None):
+def make_options(block=0, tennis_reg_rows=None, swing_reg_rows=None, ff_lanes_per_wave=0, ff_sort=None, ff_phases=0):
     """None = auto; True / False force a variant on / off"""
     def tri(x):
         return 0 if x is None else (1 if x else -1)
     o = TbOptions()
     o.struct_size = ctypes.sizeof(TbOptions)
     o.block, o.tennis_reg_rows, o.swing_reg_rows = int(block), tri(tennis_reg_rows), tri(swing_reg_rows)
-    o.ff_lanes_per_wave, o.ff_sort = int(ff_lanes_per_wave), tri(ff_sort)
+    o.ff_lanes_per_wave, o.ff_sort, o.ff_phases = int(ff_lanes_per_wave), tri(ff_sort), int(ff_phases)
     return o
 
 

@@ -591,13 +591,15 @@ def test_float32_drift_vs_float64_truth(torch):
 
 @pytest.mark.parametrize("n,reg_rows,ff", [(4096, True, {}), (1000, True, {}), (1000, False, {}),
                                            (1000, None, dict(ff_lanes_per_wave=1)), (1000, None, dict(ff_lanes_per_wave=7)), (4096, None, dict(ff_lanes_per_wave=64, ff_sort=False)),
-                                           (1000, None, dict(ff_sort=True)), (4096, None, dict(ff_sort=True)), (40000, None, {})])
+                                           (1000, None, dict(ff_sort=True)), (4096, None, dict(ff_sort=True, ff_phases=2)), (40000, None, {}),
+                                           (4096, None, dict(ff_phases=1)), (4096, None, dict(ff_phases=2)), (70000, None, dict(ff_phases=3, ff_sort=True))])
 def test_pipelined_fast_forward_is_bit_identical(torch, n, reg_rows, ff):
     """tb_set_pipeline: the fast-forward runs on a side stream and writes the terminal step's
     reward late; after flush() every output equals the unpipelined path bit for bit (both builds
     of the pipelined step kernel: static contact rows in registers, as small batches run it, and in
     scratch; every way tb_ff_kernel hands parked envs to lanes, TbOptions.ff_lanes_per_wave / ff_sort:
-    1, 7 or 64 per wave, sorted by predicted flight length in 512-env groups, and what 40 000 envs get by default)"""
+    1, 7 or 64 per wave, sorted by predicted flight length in 1024-env groups; the loop in one kernel or cut into
+    budgeted phases whose survivors are compacted for the next kernel, TbOptions.ff_phases)"""
     from tennisbot_rl_amd.rollout import RolloutBuffer
     from tennisbot_rl_amd.stepper import BatchedEnv
     T = 26 * 4 + 7

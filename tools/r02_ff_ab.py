@@ -48,18 +48,15 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     out = []
     if which in ("all", "small"):
-        for lanes in (64, 32, 16, 8, 4, 2):
-            out.append(measure(4096, 1040, dict(ff_lanes_per_wave=lanes, ff_sort=False)))
+        for o in (dict(ff_phases=1), dict(ff_phases=2), dict(ff_phases=3), dict(ff_phases=3, ff_lanes_per_wave=16), dict(ff_phases=3, ff_sort=True)):
+            out.append(measure(4096, 1040, o))
             print(json.dumps(out[-1]), flush=True)
-        out.append(measure(4096, 1040, dict(ff_sort=True)))
-        print(json.dumps(out[-1]), flush=True)
-        for n in (16384, 32768):
-            for o in (dict(ff_lanes_per_wave=64, ff_sort=False), dict(ff_lanes_per_wave=16, ff_sort=False), dict(ff_sort=True)):
-                out.append(measure(n, 520, o))
-                print(json.dumps(out[-1]), flush=True)
+        for o in (dict(ff_phases=1), dict(ff_phases=3)):
+            out.append(measure(32768, 520, o))
+            print(json.dumps(out[-1]), flush=True)
     if which in ("all", "large"):
         for n in (262144, 1048576):
-            for o in (dict(ff_lanes_per_wave=64, ff_sort=False), dict(ff_sort=True)):
+            for o in (dict(ff_phases=1), dict(ff_phases=2), dict(ff_phases=3), dict(ff_phases=3, ff_sort=True)):
                 out.append(measure(n, 104, o, reps=3))
                 print(json.dumps(out[-1]), flush=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r02_ff_ab_%s.json" % which), "w"), indent=1)
