@@ -163,7 +163,10 @@ TB_DEV bool racket_in_reach(const KParams& P, vec3 d, float s) {
   float reach = ((P.hull_bound_radius * s + P.hull_margin) + P.ball_radius) + P.contact_threshold;
   return !(dot(d, d) > reach * reach);
 }
-template <bool SCALED>
+// RELOAD: read the cull planes from LDS at every call instead of letting the compiler hoist the loop-invariant reads
+// out of the fast-forward loop, where they occupy 36 VGPRs for the whole kernel (183 -> 166: a third wave per SIMD;
+// +15 % SwingRacket at 1 M envs, same box; at 4096 envs, one wave per SIMD, the reads only lengthen the loop)
+template <bool SCALED, bool RELOAD = false>
 TB_DEV Hit sphere_vs_racket_sweep(const KParams& P, const float4* hull, const Racket& rk, vec3 d, float s) {
   Hit h;
   h.hit = false; h.dist = 0.0f; h.n = mk(0, 0, 0); h.rr = mk(0, 0, 0);
@@ -182,7 +185,11 @@ TB_DEV Hit sphere_vs_racket_sweep(const KParams& P, const float4* hull, const Ra
   //      is a narrow wedge: a tumbling racket's ball spends many substeps there.)
   if (((SCALED ? ax * s : ax) - P.hull_margin) - r >= thr) return h;
   float sep = -3.0e38f;
-  const float* cp = reinterpret_cast<const float*>(hull + TB_HULL_PLANES);
+  const float4* cpl = hull + TB_HULL_PLANES;
+  if (RELOAD) asm volatile("" : "+v"(cpl));  // an address the compiler cannot see through: the reads stay here
+  float cp[3 * TB_N_CULL];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { float4 t = cpl[k]; cp[4 * k] = t.x; cp[4 * k + 1] = t.y; cp[4 * k + 2] = t.z; cp[4 * k + 3] = t.w; }
 #pragma unroll
   for (int k = 0; k < TB_N_CULL; ++k) sep = fmaxf(sep, FMA(cp[3 * k + 1], l.z, cp[3 * k] * l.y) - cp[3 * k + 2]);
   if (((SCALED ? sep * s : sep) - P.hull_margin) - r >= thr + 1.0e-4f) return h;
@@ -766,7 +773,7 @@ TB_DEV void integrate_pose(const KParams& P, Racket& rk, Ball& b) {
 // COLD: the contact path reads its constants from the LDS copy of the parameter block instead of holding them in SGPRs all the
 // time. Pays where SGPRs are scarce and contacts rare (the policy rollout kernel: 97 -> 70 spill writes, collect +10 %); costs VGPRs and
 // LDS reads where throughput counts (SwingRacket at 1 M envs -15 %, Tennisbot -4 %), so only that kernel asks for it.
-template <int KIND, bool RG, bool REGROWS = false, bool COLD = false>
+template <int KIND, bool RG, bool REGROWS = false, bool COLD = false, bool RELOAD = false>
 TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, vec3 Fr, vec3 Tr, vec3 Fb, float goal_x, float goal_y, float scale TB_STAMP_ARG) {
   int bits = 0;
   TB_STAMP(st, 0);  // everything between two substeps (loop control, env logic)
@@ -786,7 +793,7 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, ve
 #ifdef TB_DIAG_STAMPS
     if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)__ballot(1)) - 1u) atomicAdd(&g_diag_cycles[12], 1ull);  // wave-substeps with a lane in reach
 #endif
-    if (near_racket) hr = sphere_vs_racket_sweep<KIND == TB_ENV_TENNIS>(P, hull, rk, d, scale);
+    if (near_racket) hr = sphere_vs_racket_sweep<KIND == TB_ENV_TENNIS, RELOAD>(P, hull, rk, d, scale);
   }
 #ifdef TB_DIAG_STAMPS
   if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)__ballot(1)) - 1u) atomicAdd(&g_diag_cycles[13], 1ull);  // wave-substeps

@@ -272,13 +272,13 @@ TB_DEV vec3 restoring_force(const EnvRegs& e) {  // swingracket_env.py:135-141
 // `defer`  = leave the fast-forward to tb_ff_kernel: sets `parked` instead of looping.
 // BUDGET  = tb_ff_kernel only: leave the loop after `budget` substeps with the env still running (`parked` again): the
 //           next phase kernel resumes it from the saved state, with the restoring force recomputed from that state.
-template <bool RG, bool REGROWS = false, bool COLD = false, bool BUDGET = false>
+template <bool RG, bool REGROWS = false, bool COLD = false, bool BUDGET = false, bool RELOAD = false>
 TB_DEV float swing_loop(const KParams& P, const float4* hull, EnvRegs& e, vec3 F, vec3 T, bool in_ff, bool defer, bool& parked,
                         int& ns, uint32_t* cnt TB_STAMP_ARG, int budget = 0) {
   const vec3 zero = mk(0.0f, 0.0f, 0.0f);
   float reward = 0.0f;
   for (;;) {
-    int bits = substep<TB_ENV_SWING, RG, REGROWS, COLD>(P, hull, e.r, e.b, F, T, zero, e.aux[0], e.aux[1], 1.0f TB_STAMP_PASS);  // :82 / :107
+    int bits = substep<TB_ENV_SWING, RG, REGROWS, COLD, RELOAD>(P, hull, e.r, e.b, F, T, zero, e.aux[0], e.aux[1], 1.0f TB_STAMP_PASS);  // :82 / :107
     e.step_count += 1; ns++;                                                                                   // :83 / :108
     if (bits & CT_RACKET) cnt[0]++;
     if (!in_ff) {
@@ -702,7 +702,9 @@ __global__ void __launch_bounds__(TB_FF_SORT_BLOCK) tb_ff_sort_kernel(KArgs A, f
 // force is a function of it), so results are bit-identical however the phases cut (tests/test_gpu_parity.py).
 //   phase 1: wave w takes the A.ff_lanes records [w L, (w+1) L) of the slot (L < 64: few envs per wave at small batches);
 //   phases 2+: grid-stride over the *A.ff_src_count survivors of the previous phase, 64 per wave.
-template <bool RG>
+// BIG: the instantiation for batches that fill the chip several times over (occupancy counts: cull planes re-read from
+// LDS, see sphere_vs_racket_sweep); below that the loop's latency counts and the planes stay in registers.
+template <bool RG, bool BIG>
 __global__ void __launch_bounds__(64) tb_ff_kernel(KArgs A) {
   __shared__ float4 s_hull[TB_HULL_LDS];
   const int lane = threadIdx.x & 63;
@@ -739,7 +741,7 @@ __global__ void __launch_bounds__(64) tb_ff_kernel(KArgs A) {
       const vec3 F0 = e.step_count > 26 ? restoring_force(e) : zero;
       const int budget = A.ff_next ? 4 * predict_flight(A.P, e.b.p, e.b.v) + 8 : 0x7fffffff;
       const int ns0 = ns;
-      float rew = swing_loop<RG, false, false, true>(A.P, s_hull, e, F0, zero, true, false, unfinished, ns, cnt TB_STAMP_PASS, budget);
+      float rew = swing_loop<RG, false, false, true, BIG>(A.P, s_hull, e, F0, zero, true, false, unfinished, ns, cnt TB_STAMP_PASS, budget);
       cnt[6] += (uint32_t)(ns - ns0);
       if (!unfinished) {
         if (!(finite3(e.r.p) && finite3(e.r.v) && finite3(e.r.w) && finite3(e.b.p) && finite3(e.b.v) && finite3(e.b.w) &&
@@ -1029,8 +1031,9 @@ int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const 
       grid = dim3((unsigned)g);
     }
     if (ph + 1 < phases) { k.ff_next = h->d_ff_list[slot][ph]; k.ff_next_count = h->d_ff_count[slot] + ph; }
-    if (rg) hipLaunchKernelGGL(tb_ff_kernel<true>, grid, block, 0, h->side[slot], k);
-    else hipLaunchKernelGGL(tb_ff_kernel<false>, grid, block, 0, h->side[slot], k);
+    const bool big = h->n >= 131072;
+    if (rg) { if (big) hipLaunchKernelGGL((tb_ff_kernel<true, true>), grid, block, 0, h->side[slot], k); else hipLaunchKernelGGL((tb_ff_kernel<true, false>), grid, block, 0, h->side[slot], k); }
+    else { if (big) hipLaunchKernelGGL((tb_ff_kernel<false, true>), grid, block, 0, h->side[slot], k); else hipLaunchKernelGGL((tb_ff_kernel<false, false>), grid, block, 0, h->side[slot], k); }
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipGetLastError());
@@ -1197,7 +1200,8 @@ int tb_create(const TbParams* params, const TbOptions* options, int env_kind, in
   h->swing_reg_rows = env_kind == TB_ENV_SWING && (opt.swing_reg_rows ? opt.swing_reg_rows > 0 : n_envs <= 131072);
   // fast-forward: sort the lanes of large batches by predicted flight length; below 4096 envs a few envs per wave
   h->ff_sort = opt.ff_sort > 0;  // opt-in: pays when flight lengths can be told from the parked state (a trained policy's struck balls)
-  h->ff_phases = opt.ff_phases >= 1 && opt.ff_phases <= 3 ? opt.ff_phases : 3;
+  // measured on one box: 3 phases +11 % at 1 M envs, +-0 at 256 K, -16 % at 32 K and 4096 (two more kernels in every episode's chain)
+  h->ff_phases = opt.ff_phases >= 1 && opt.ff_phases <= 3 ? opt.ff_phases : (n_envs >= 524288 ? 3 : 1);
   h->ff_lanes = opt.ff_lanes_per_wave;
   if (!h->ff_lanes) { h->ff_lanes = 4; while (h->ff_lanes < 64 && (long long)h->ff_lanes * 64 < n_envs) h->ff_lanes <<= 1; }
   const int nw = words_of(env_kind);

@@ -46,9 +46,17 @@ def measure(n, T, opts, reps=5, flags=None):
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if len(sys.argv) > 2:  # extra hipcc flags: build that variant of the library into /tmp and measure it instead (same-box A/B)
+        import subprocess
+        from tennisbot_rl_amd import stepper
+        from tennisbot_rl_amd.build import HIPCC_FLAGS, SOURCES, hipcc
+        lib = "/tmp/libtb_variant.so"
+        subprocess.check_call([hipcc()] + HIPCC_FLAGS + sys.argv[2:] + ["-o", lib] + SOURCES)
+        stepper.use_library(lib)
+        print("variant", sys.argv[2:], flush=True)
     out = []
     if which in ("all", "small"):
-        for o in (dict(ff_phases=1), dict(ff_phases=2), dict(ff_phases=3), dict(ff_phases=3, ff_lanes_per_wave=16), dict(ff_phases=3, ff_sort=True)):
+        for o in (dict(ff_phases=1), dict(ff_phases=3)):
             out.append(measure(4096, 1040, o))
             print(json.dumps(out[-1]), flush=True)
         for o in (dict(ff_phases=1), dict(ff_phases=3)):
@@ -56,7 +64,7 @@ def main():
             print(json.dumps(out[-1]), flush=True)
     if which in ("all", "large"):
         for n in (262144, 1048576):
-            for o in (dict(ff_phases=1), dict(ff_phases=2), dict(ff_phases=3), dict(ff_phases=3, ff_sort=True)):
+            for o in (dict(ff_phases=1), dict(ff_phases=3)):
                 out.append(measure(n, 104, o, reps=3))
                 print(json.dumps(out[-1]), flush=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r02_ff_ab_%s.json" % which), "w"), indent=1)
