@@ -54,6 +54,8 @@ def _lib(precision):
         L.tbo_query_racket.restype = i32
         L.tbo_query_racket_ground.argtypes = [ctypes.POINTER(TbParams), vp, vp, vp]
         L.tbo_query_racket_ground.restype = i32
+        L.tbo_get_manifold.argtypes = [vp, i32, vp, vp]
+        L.tbo_get_manifold.restype = i32
         L.tbo_query_box.argtypes = [ctypes.POINTER(TbParams), vp, vp, vp]
         L.tbo_query_box.restype = i32
         L.tbo_query_goal.argtypes = [ctypes.POINTER(TbParams), ctypes.c_float, ctypes.c_float, vp, vp]
@@ -133,6 +135,16 @@ class OracleBatch:
         """dict of named float64 arrays [n, k] (+ step_count, episode, done)."""
         v, d = self.get_state_f64()
         return rows_to_dict(self.kind, v, d)
+
+
+def _manifold(self, env=0):
+    """racket<->court contact cache of one env: (hull vertex ids, [n, 3] impulses jn / jt1 / jt2 of the last solve)"""
+    ids, imp = np.zeros(4, np.int32), np.zeros(12, np.float64)
+    n = self.L.tbo_get_manifold(self.h, int(env), _p(ids), _p(imp))
+    return ids[:n].copy(), imp.reshape(4, 3)[:n].copy()
+
+
+OracleBatch.manifold = _manifold
 
 
 def rows_to_dict(kind, vals, done):

@@ -212,6 +212,17 @@ static void prm_from(Prm *Q, const TbParams *P) {
 typedef struct { v3 p; q4 q; v3 v; v3 w; } Racket;
 typedef struct { v3 p; v3 v; v3 w; } Ball;
 
+/* racket <-> court contact cache (TB_F_RACKET_GROUND): up to 4 hull vertices in contact with the ground's top face,
+ * each with the impulses the last solve gave it (the next solve starts from them), and the outline vertex the last
+ * support query ended at (the next one starts its walk there). See racket_vs_ground. */
+#define MAX_RG 4
+typedef struct {
+  int n;
+  int id[MAX_RG];                             /* hull vertex k = 2 i + side (side 0: x = -half thickness) */
+  real jn[MAX_RG], jt1[MAX_RG], jt2[MAX_RG];
+  int deep;                                   /* outline vertex index of the last support point */
+} Manifold;
+
 typedef struct {
   Racket r;
   Ball b;
@@ -219,6 +230,7 @@ typedef struct {
   int32_t step_count;
   uint32_t episode;
   uint8_t done;
+  Manifold m;
 } Env;
 
 struct TboBatch {
@@ -371,7 +383,6 @@ static Hit sphere_vs_goal(const Prm *P, real gx, real gy, v3 c) {
  * points) keep trading tiny impulses that are large only relative to themselves. */
 #define ROW_BALL_STATIC 0 /* ball pushed off a static shape */
 #define ROW_BALL_RACKET 1 /* ball pushed off the racket, racket pushed back */
-#define ROW_RACKET_COURT 2 /* racket pushed off the court ground (TB_F_RACKET_GROUND) */
 typedef struct {
   int kind;
   v3 n, rr, t1, t2; /* n: toward the pushed body; rr: contact point relative to the racket COM */
@@ -391,7 +402,6 @@ static inline v3 racket_invI(const Prm *P, q4 q, v3 x, real inv_s2) {
   return qrot(q, b);
 }
 static inline v3 rel_vel(const Row *c, const Racket *rk, const Ball *b, v3 rb) {
-  if (c->kind == ROW_RACKET_COURT) return add3(rk->v, cross3(rk->w, c->rr));
   v3 pv = add3(b->v, cross3(b->w, rb));
   if (c->kind == ROW_BALL_RACKET) pv = sub3(pv, add3(rk->v, cross3(rk->w, c->rr)));
   return pv;
@@ -410,11 +420,6 @@ static inline void plane_space(v3 n, v3 *p, v3 *q) {
   }
 }
 static inline void apply_impulse(const Prm *P, const Row *c, Racket *rk, Ball *b, v3 rb, v3 dir, real j, int angular_ball) {
-  if (c->kind == ROW_RACKET_COURT) {
-    rk->v = axpy3(j * P->racket_inv_mass, dir, rk->v);
-    rk->w = axpy3(j, racket_invI(P, rk->q, cross3(c->rr, dir), c->inv_s2), rk->w);
-    return;
-  }
   b->v = axpy3(j * P->ball_inv_mass, dir, b->v);
   if (angular_ball) b->w = axpy3(j * P->ball_inv_inertia, cross3(rb, dir), b->w);
   if (c->kind == ROW_BALL_RACKET) {
@@ -430,8 +435,7 @@ static void setup_row(const Prm *P, Row *c, const Hit *h, int kind, real e, real
   plane_space(c->n, &c->t1, &c->t2);
   v3 rb = mul3(-r, c->n);
   real kn, kt1, kt2;
-  if (kind == ROW_RACKET_COURT) { kn = P->racket_inv_mass; kt1 = kn; kt2 = kn; }
-  else { kn = P->ball_inv_mass; kt1 = FMA(P->ball_inv_inertia, r * r, P->ball_inv_mass); kt2 = kt1; }
+  kn = P->ball_inv_mass; kt1 = FMA(P->ball_inv_inertia, r * r, P->ball_inv_mass); kt2 = kt1;
   if (kind == ROW_BALL_RACKET) { kn = kn + P->racket_inv_mass; kt1 = kt1 + P->racket_inv_mass; kt2 = kt2 + P->racket_inv_mass; }
   if (kind != ROW_BALL_STATIC) {
     v3 a;
@@ -447,7 +451,7 @@ static void setup_row(const Prm *P, Row *c, const Hit *h, int kind, real e, real
   c->target = rest + pos; /* the normal row drives vn toward this value */
   /* [3P-recalled] Bullet's torsional rows for rolling friction: angular-only Jacobians along the two
    * friction directions, target relative spin 0, effective mass 1 / (t.I_b^-1 t + t.I_r^-1 t) */
-  c->roll = kind == ROW_RACKET_COURT ? R(0) : roll;
+  c->roll = roll;
   if (c->roll > R(0)) {
     real k1 = P->ball_inv_inertia, k2 = P->ball_inv_inertia;
     if (kind == ROW_BALL_RACKET) {
@@ -458,15 +462,22 @@ static void setup_row(const Prm *P, Row *c, const Hit *h, int kind, real e, real
   }
 }
 
-/* racket vs the court's ground box (court.urdf:19-24), SURVEY.md A.3 / 8f.3. Bullet would build a
- * persistent manifold of up to 4 points over several frames; this restatement is stateless: the
- * candidates are the hull's 2 x n_hull vertices closer to the ground's top face than the manifold
- * threshold (and above the court), of which up to 4 are kept the way Bullet reduces a manifold --
- * the deepest, the one farthest from it, the one spanning the largest triangle with those two, and
- * the one spanning the largest triangle on the other side. Ties go to the lowest vertex index
- * k = 2 i + side. All distances are taken in the racket frame (rotation invariant). A vertex that is
- * already below the box's bottom face is under the court, not in contact with its top. */
-#define MAX_RG 4
+/* racket vs the court's ground box (court.urdf:19-24) with a PERSISTENT manifold, the way Bullet's
+ * convex-convex pair works [3P-recalled]: per substep the narrowphase finds ONE point -- the deepest -- and adds it to the
+ * pair's cached manifold of at most 4 points; cached points are refreshed with the new pose and dropped once they are farther
+ * from the ground than the manifold threshold; a fifth point replaces the cached one whose removal leaves the largest
+ * contact area (the deepest is never dropped); every point keeps the impulses of the last solve, and the next solve starts
+ * from them (warm start). A racket that has come to rest is therefore solved in one or two sweeps, and one that flies
+ * costs a support query. Restated for a prism over a convex outline above a plane:
+ *   - contact points are hull VERTICES (k = 2 i + side); the deepest vertex is found by walking the outline downhill from
+ *     where the last query ended (the height of outline vertex i, zr . v_i, is unimodal around a convex polygon);
+ *   - a point is in contact while its height above the ground's top face is < racket_ground_threshold * scale and it is
+ *     over the court (|x|, |y| inside the box) -- however deep: a tumbling racket's tip moves 3 cm per substep, three times
+ *     the thickness of the 1 cm ground box, and Bullet's penetration solver (EPA) separates a hull from a thin plate it has
+ *     pierced along the plate's normal all the same. Only a racket whose COM is below the plate is under the court;
+ *   - warm-start factor 1 (Bullet: 0.85): the converged impulses do not depend on it, the number of sweeps does.
+ * The cache lives in the env (Env.m), across substeps AND across env.step() calls; it is not part of the state words
+ * (a restored or injected state starts with an empty cache, like a fresh PyBullet world). */
 static inline v3 hull_vertex(const Prm *P, int k, real s) {
   real hx = P->racket_half_thick * s;
   return V3((k & 1) ? hx : -hx, P->hull_edges[k >> 1][0] * s, P->hull_edges[k >> 1][1] * s);
@@ -476,71 +487,152 @@ static inline real vertex_height(const Prm *P, const Racket *rk, v3 zr, v3 v) {
   real dz = FMA(zr.x, v.x, FMA(zr.z, v.z, zr.y * v.y));
   return ((rk->p.z + dz) - P->hull_margin) - P->ground_half[2];
 }
-static int racket_vs_ground(const Prm *P, const Racket *rk, real s, Hit out[MAX_RG]) {
+/* the (y, z) part of that height for outline vertex i */
+static inline real outline_height(const Prm *P, v3 zr, int i, real s) {
+  return FMA(zr.z, P->hull_edges[i][1] * s, zr.y * (P->hull_edges[i][0] * s));
+}
+static inline int vertex_supported(const Prm *P, const Racket *rk, v3 xr, v3 yr, v3 v, real h, real thr) {
+  if (!(h < thr)) return 0; /* above the manifold threshold */
+  real wx = rk->p.x + FMA(xr.x, v.x, FMA(xr.z, v.z, xr.y * v.y)), wy = rk->p.y + FMA(yr.x, v.x, FMA(yr.z, v.z, yr.y * v.y));
+  return !(FABS(wx) > P->ground_half[0] || FABS(wy) > P->ground_half[1]);
+}
+/* Bullet's calcArea4Points on racket-frame positions: the largest of the three ways to cross two diagonals */
+static inline real area4(v3 p0, v3 p1, v3 p2, v3 p3) {
+  v3 c0 = cross3(sub3(p0, p1), sub3(p2, p3)), c1 = cross3(sub3(p0, p2), sub3(p1, p3)), c2 = cross3(sub3(p0, p3), sub3(p1, p2));
+  real a0 = dot3(c0, c0), a1 = dot3(c1, c1), a2 = dot3(c2, c2);
+  real m = a0 > a1 ? a0 : a1;
+  return m > a2 ? m : a2;
+}
+/* updates the cache M for the racket's present pose; fills out[] (one Hit per cached point, in cache order) */
+static int racket_vs_ground(const Prm *P, const Racket *rk, real s, Manifold *M, Hit out[MAX_RG]) {
   const real top = P->ground_half[2], thr = P->racket_ground_threshold * s;
-  if ((rk->p.z - (P->hull_bound_radius * s + P->hull_margin)) - top >= thr) return 0;
-  v3 xr = qrot_inv(rk->q, V3(R(1), R(0), R(0))), yr = qrot_inv(rk->q, V3(R(0), R(1), R(0))), zr = qrot_inv(rk->q, V3(R(0), R(0), R(1)));
-  uint64_t cand[2] = {0, 0};
-  int p0 = -1; real h0 = R(0);
-  for (int k = 0; k < 2 * P->n_hull; ++k) {
-    v3 v = hull_vertex(P, k, s);
-    real h = vertex_height(P, rk, zr, v);
-    if (!(h < thr) || h < -(R(2) * top)) continue; /* above the manifold threshold, or already below the 2*hz thick box */
-    real wx = rk->p.x + FMA(xr.x, v.x, FMA(xr.z, v.z, xr.y * v.y)), wy = rk->p.y + FMA(yr.x, v.x, FMA(yr.z, v.z, yr.y * v.y));
-    if (FABS(wx) > P->ground_half[0] || FABS(wy) > P->ground_half[1]) continue;
-    cand[k & 1] |= (uint64_t)1 << (k >> 1);
-    if (p0 < 0 || h < h0) { p0 = k; h0 = h; }
+  if ((rk->p.z - (P->hull_bound_radius * s + P->hull_margin)) - top >= thr || !(rk->p.z > top)) { M->n = 0; return 0; }
+  const int nh = P->n_hull;
+  v3 zr = qrot_inv(rk->q, V3(R(0), R(0), R(1)));
+  /* support query: walk the outline downhill from the last support point */
+  int i = M->deep;
+  real fi = outline_height(P, zr, i, s);
+  for (int it = 0; it < nh; ++it) {
+    int j = i + 1 == nh ? 0 : i + 1;
+    real fj = outline_height(P, zr, j, s);
+    if (fj < fi) { i = j; fi = fj; continue; }
+    j = i == 0 ? nh - 1 : i - 1;
+    fj = outline_height(P, zr, j, s);
+    if (fj < fi) { i = j; fi = fj; continue; }
+    break;
   }
-  if (p0 < 0) return 0;
-  int pick[MAX_RG] = {p0, -1, -1, -1};
-  v3 v0 = hull_vertex(P, p0, s);
-  real best = R(0);
-  for (int k = 0; k < 2 * P->n_hull; ++k) { /* farthest from the deepest */
-    if (!((cand[k & 1] >> (k >> 1)) & 1)) continue;
-    v3 d = sub3(hull_vertex(P, k, s), v0);
-    real d2 = dot3(d, d);
-    if (d2 > best) { best = d2; pick[1] = k; }
-  }
-  v3 c2 = V3(R(0), R(0), R(0));
-  if (pick[1] >= 0) {
-    v3 e = sub3(hull_vertex(P, pick[1], s), v0);
-    best = R(0);
-    for (int k = 0; k < 2 * P->n_hull; ++k) { /* largest triangle */
-      if (!((cand[k & 1] >> (k >> 1)) & 1)) continue;
-      v3 c = cross3(sub3(hull_vertex(P, k, s), v0), e);
-      real a2 = dot3(c, c);
-      if (a2 > best) { best = a2; pick[2] = k; c2 = c; }
-    }
-    if (pick[2] >= 0) {
-      best = R(0);
-      for (int k = 0; k < 2 * P->n_hull; ++k) { /* largest triangle on the other side of p0-p1 */
-        if (!((cand[k & 1] >> (k >> 1)) & 1)) continue;
-        v3 c = cross3(sub3(hull_vertex(P, k, s), v0), e);
-        if (!(dot3(c, c2) < R(0))) continue;
-        real a2 = dot3(c, c);
-        if (a2 > best) { best = a2; pick[3] = k; }
-      }
-    }
-  }
+  M->deep = i;
+  const int side = zr.x > R(0) ? 0 : 1; /* the face that looks down */
+  const real hx = P->racket_half_thick * s;
+  const real h_deep = ((rk->p.z + FMA(zr.x, side ? hx : -hx, fi)) - P->hull_margin) - top;
+  if (M->n == 0 && !(h_deep < thr)) return 0; /* nothing cached, nothing near: the common case of a racket in flight */
+  v3 xr = qrot_inv(rk->q, V3(R(1), R(0), R(0))), yr = qrot_inv(rk->q, V3(R(0), R(1), R(0)));
+  /* refresh the cached points, drop the ones that have left */
+  real h[MAX_RG + 1];
   int n = 0;
-  for (int j = 0; j < MAX_RG; ++j) {
-    if (pick[j] < 0) continue;
-    v3 v = hull_vertex(P, pick[j], s);
-    Hit *h = &out[n++];
-    h->hit = 1;
-    h->dist = vertex_height(P, rk, zr, v);
-    h->n = V3(R(0), R(0), R(1));
-    h->rr = qrot(rk->q, v);
-    h->rr.z = h->rr.z - P->hull_margin; /* the point on the inflated hull */
+  for (int j = 0; j < M->n; ++j) {
+    v3 v = hull_vertex(P, M->id[j], s);
+    real hj = vertex_height(P, rk, zr, v);
+    if (!vertex_supported(P, rk, xr, yr, v, hj, thr)) continue;
+    M->id[n] = M->id[j]; M->jn[n] = M->jn[j]; M->jt1[n] = M->jt1[j]; M->jt2[n] = M->jt2[j]; h[n] = hj; ++n;
   }
-  return n;
+  M->n = n;
+  /* add the support point */
+  const int kd = 2 * i + side;
+  int known = 0;
+  for (int j = 0; j < n; ++j) known |= M->id[j] == kd;
+  v3 vd = hull_vertex(P, kd, s);
+  if (!known && vertex_supported(P, rk, xr, yr, vd, h_deep, thr)) {
+    int slot = n;
+    if (n == MAX_RG) { /* full: the new point replaces the cached one (never the deepest) whose loss keeps the largest area */
+      int deepest = 0;
+      for (int j = 1; j < MAX_RG; ++j) if (h[j] < h[deepest]) deepest = j;
+      if (h_deep < h[deepest]) deepest = -1; /* the new point is the deepest of the five: any cached one may go */
+      v3 c[MAX_RG];
+      for (int j = 0; j < MAX_RG; ++j) c[j] = hull_vertex(P, M->id[j], s);
+      real best = R(-1);
+      slot = -1;
+      for (int j = 0; j < MAX_RG; ++j) {
+        if (j == deepest) continue;
+        real a = area4(j == 0 ? vd : c[0], j == 1 ? vd : c[1], j == 2 ? vd : c[2], j == 3 ? vd : c[3]);
+        if (a > best) { best = a; slot = j; }
+      }
+    } else M->n = n + 1;
+    M->id[slot] = kd; M->jn[slot] = R(0); M->jt1[slot] = R(0); M->jt2[slot] = R(0); h[slot] = h_deep;
+  }
+  for (int j = 0; j < M->n; ++j) {
+    v3 v = hull_vertex(P, M->id[j], s);
+    Hit *o = &out[j];
+    o->hit = 1;
+    o->dist = h[j];
+    o->n = V3(R(0), R(0), R(1));
+    o->rr = qrot(rk->q, v);
+    o->rr.z = o->rr.z - P->hull_margin; /* the point on the inflated hull */
+  }
+  return M->n;
 }
 
-static void solve_contacts(const Prm *P, Row *rows, int nrows, Racket *rk, Ball *b) {
+/* World-frame inverse inertia of the racket, W = R diag(I^-1 / s^2) R^T (6 unique entries), for the racket<->court rows:
+ * with up to 4 points x 3 directions per solve, one matrix per substep is cheaper than 12 rotate-scale-rotate round trips. */
+typedef struct { real xx, xy, xz, yy, yz, zz; } Sym3;
+static Sym3 world_inv_inertia(const Prm *P, q4 q, real inv_s2) {
+  real x2 = q.x + q.x, y2 = q.y + q.y, z2 = q.z + q.z;
+  real xx = q.x * x2, xy = q.x * y2, xz = q.x * z2, yy = q.y * y2, yz = q.y * z2, zz = q.z * z2, wx = q.w * x2, wy = q.w * y2, wz = q.w * z2;
+  real r00 = R(1) - (yy + zz), r01 = xy - wz, r02 = xz + wy, r10 = xy + wz, r11 = R(1) - (xx + zz), r12 = yz - wx, r20 = xz - wy, r21 = yz + wx, r22 = R(1) - (xx + yy);
+  real d0 = P->racket_inv_inertia[0] * inv_s2, d1 = P->racket_inv_inertia[1] * inv_s2, d2 = P->racket_inv_inertia[2] * inv_s2;
+  Sym3 W;
+  W.xx = FMA(r02 * d2, r02, FMA(r01 * d1, r01, (r00 * d0) * r00));
+  W.xy = FMA(r02 * d2, r12, FMA(r01 * d1, r11, (r00 * d0) * r10));
+  W.xz = FMA(r02 * d2, r22, FMA(r01 * d1, r21, (r00 * d0) * r20));
+  W.yy = FMA(r12 * d2, r12, FMA(r11 * d1, r11, (r10 * d0) * r10));
+  W.yz = FMA(r12 * d2, r22, FMA(r11 * d1, r21, (r10 * d0) * r20));
+  W.zz = FMA(r22 * d2, r22, FMA(r21 * d1, r21, (r20 * d0) * r20));
+  return W;
+}
+static inline v3 sym3_mul(const Sym3 *W, v3 a) {
+  return V3(FMA(W->xz, a.z, FMA(W->xy, a.y, W->xx * a.x)), FMA(W->yz, a.z, FMA(W->yy, a.y, W->xy * a.x)), FMA(W->zz, a.z, FMA(W->yz, a.y, W->xz * a.x)));
+}
+/* one racket<->court row: contact normal +z, friction directions btPlaneSpace1(+z) = (0,-1,0), (1,0,0); an = W (rr x n) etc. */
+typedef struct { v3 rr, an, at1, at2; real target, kn, kt1, kt2, jn, jt1, jt2; } RowG;
+static void setup_ground_row(const Prm *P, RowG *c, const Hit *h, const Sym3 *W, const Racket *rk) {
+  v3 rr = h->rr;
+  c->rr = rr;
+  v3 a = V3(rr.y, -rr.x, R(0));
+  c->an = sym3_mul(W, a);  c->kn = R(1) / (P->racket_inv_mass + dot3(a, c->an));
+  a = V3(rr.z, R(0), -rr.x);
+  c->at1 = sym3_mul(W, a); c->kt1 = R(1) / (P->racket_inv_mass + dot3(a, c->at1));
+  a = V3(R(0), rr.z, -rr.y);
+  c->at2 = sym3_mul(W, a); c->kt2 = R(1) / (P->racket_inv_mass + dot3(a, c->at2));
+  v3 pv = add3(rk->v, cross3(rk->w, rr));
+  real vn = pv.z;
+  real rest = FABS(vn) < P->rest_vel_threshold ? R(0) : P->rest_racket_court * (-vn);
+  if (rest < R(0)) rest = R(0);
+  real pos = h->dist > R(0) ? -(h->dist * P->inv_dt) : -(h->dist * P->erp) * P->inv_dt;
+  c->target = rest + pos;
+}
+
+#ifdef TBO_TRACE_STATIONARY
+int g_stat_first[4096]; int g_stat_n;
+int tbo_debug_stationary(int *out) { memcpy(out, g_stat_first, sizeof(int) * g_stat_n); int n = g_stat_n; g_stat_n = 0; return n; }
+#endif
+/* diagnostics: solver sweeps and solves so far (single-threaded use) */
+static uint64_t g_sweeps, g_solves;
+void tbo_debug_solver(uint64_t out[2], int reset) { out[0] = g_sweeps; out[1] = g_solves; if (reset) { g_sweeps = 0; g_solves = 0; } }
+static void solve_contacts(const Prm *P, Row *rows, int nrows, RowG *rg, int nrg, Racket *rk, Ball *b) {
   const real r = P->ball_radius;
+  g_solves++;
   real jref = R(0); /* largest normal impulse seen in this solve: the scale updates are judged against */
+  /* warm start of the racket<->court rows: the cached impulses of the last solve are applied before the first sweep */
+  for (int i = 0; i < nrg; ++i) {
+    RowG *c = &rg[i];
+    if (c->jn > jref) jref = c->jn;
+    rk->v.z = FMA(c->jn, P->racket_inv_mass, rk->v.z);  rk->w = axpy3(c->jn, c->an, rk->w);
+    rk->v.y = FMA(-c->jt1, P->racket_inv_mass, rk->v.y); rk->w = axpy3(c->jt1, c->at1, rk->w);
+    rk->v.x = FMA(c->jt2, P->racket_inv_mass, rk->v.x);  rk->w = axpy3(c->jt2, c->at2, rk->w);
+  }
   for (int it = 0; it < P->solver_iters; ++it) {
     int moved = 0;
+    g_sweeps++;
     for (int i = 0; i < nrows; ++i) {
       Row *c = &rows[i];
       v3 rb = mul3(-r, c->n);
@@ -551,6 +643,19 @@ static void solve_contacts(const Prm *P, Row *rows, int nrows, Racket *rk, Ball 
       c->jn = jn;
       if (jn > jref) jref = jn;
       if (d != R(0)) { apply_impulse(P, c, rk, b, rb, c->n, d, 0); if (FABS(d) > P->solver_tol * jref) moved = 1; }
+    }
+    for (int i = 0; i < nrg; ++i) { /* racket<->court normals */
+      RowG *c = &rg[i];
+      real vn = add3(rk->v, cross3(rk->w, c->rr)).z;
+      real jn = FMA(c->target - vn, c->kn, c->jn);
+      if (jn < R(0)) jn = R(0);
+      real d = jn - c->jn;
+      c->jn = jn;
+      if (jn > jref) jref = jn;
+      if (d != R(0)) {
+        rk->v.z = FMA(d, P->racket_inv_mass, rk->v.z); rk->w = axpy3(d, c->an, rk->w);
+        if (FABS(d) > P->solver_tol * jref) moved = 1;
+      }
     }
     for (int i = 0; i < nrows; ++i) { /* rolling rows: after the normals, before sliding friction */
       Row *c = &rows[i];
@@ -588,6 +693,33 @@ static void solve_contacts(const Prm *P, Row *rows, int nrows, Racket *rk, Ball 
         real d = jt - *acc;
         *acc = jt;
         if (d != R(0)) { apply_impulse(P, c, rk, b, rb, t, d, 1); if (FABS(d) > P->solver_tol * (FABS(jt) > jref ? FABS(jt) : jref)) moved = 1; }
+      }
+    }
+    for (int i = 0; i < nrg; ++i) { /* racket<->court friction: t1 = (0,-1,0), t2 = (1,0,0) */
+      RowG *c = &rg[i];
+      real lim = P->fric_racket_court * c->jn;
+      if (!(lim > R(0))) continue;
+      {
+        real vt = -(add3(rk->v, cross3(rk->w, c->rr)).y);
+        real jt = FMA(-vt, c->kt1, c->jt1);
+        jt = jt < -lim ? -lim : (jt > lim ? lim : jt);
+        real d = jt - c->jt1;
+        c->jt1 = jt;
+        if (d != R(0)) {
+          rk->v.y = FMA(-d, P->racket_inv_mass, rk->v.y); rk->w = axpy3(d, c->at1, rk->w);
+          if (FABS(d) > P->solver_tol * (FABS(jt) > jref ? FABS(jt) : jref)) moved = 1;
+        }
+      }
+      {
+        real vt = add3(rk->v, cross3(rk->w, c->rr)).x;
+        real jt = FMA(-vt, c->kt2, c->jt2);
+        jt = jt < -lim ? -lim : (jt > lim ? lim : jt);
+        real d = jt - c->jt2;
+        c->jt2 = jt;
+        if (d != R(0)) {
+          rk->v.x = FMA(d, P->racket_inv_mass, rk->v.x); rk->w = axpy3(d, c->at2, rk->w);
+          if (FABS(d) > P->solver_tol * (FABS(jt) > jref ? FABS(jt) : jref)) moved = 1;
+        }
       }
     }
     if (!moved) break;
@@ -662,8 +794,9 @@ static void integrate_pose(const Prm *P, Racket *rk, Ball *b) {
   }
 }
 
-static int substep(const Prm *P, int kind, Racket *rk, Ball *b, v3 Fr, v3 Tr, v3 Fb, real gx, real gy, real scale) {
-  Row rows[4 + MAX_RG];
+static int substep(const Prm *P, int kind, Racket *rk, Ball *b, Manifold *M, v3 Fr, v3 Tr, v3 Fb, real gx, real gy, real scale) {
+  Row rows[4];
+  RowG rg[MAX_RG];
   int nrows = 0, bits = 0;
   Hit h;
   if (P->flags & TB_F_RACKET_BALL) {
@@ -680,7 +813,7 @@ static int substep(const Prm *P, int kind, Racket *rk, Ball *b, v3 Fr, v3 Tr, v3
   if (hc.hit) bits |= CT_GOAL;
   Hit hrg[MAX_RG];
   int nrg = 0;
-  if (P->flags & TB_F_RACKET_GROUND) nrg = racket_vs_ground(P, rk, scale, hrg);
+  if (P->flags & TB_F_RACKET_GROUND) nrg = racket_vs_ground(P, rk, scale, M, hrg);
   if (nrg) bits |= CT_RACKET_COURT;
 
   integrate_velocities(P, rk, b, Fr, Tr, Fb);
@@ -690,8 +823,15 @@ static int substep(const Prm *P, int kind, Racket *rk, Ball *b, v3 Fr, v3 Tr, v3
     if (bits & CT_GROUND) setup_row(P, &rows[nrows++], &hg, ROW_BALL_STATIC, P->rest_court, P->fric_court, P->roll_court, rk, b, scale);
     if (bits & CT_NET) setup_row(P, &rows[nrows++], &hn, ROW_BALL_STATIC, P->rest_court, P->fric_court, P->roll_court, rk, b, scale);
     if (bits & CT_GOAL) setup_row(P, &rows[nrows++], &hc, ROW_BALL_STATIC, P->rest_goal, P->fric_goal, P->roll_goal, rk, b, scale);
-    for (int j = 0; j < nrg; ++j) setup_row(P, &rows[nrows++], &hrg[j], ROW_RACKET_COURT, P->rest_racket_court, P->fric_racket_court, R(0), rk, b, scale);
-    solve_contacts(P, rows, nrows, rk, b);
+    if (nrg) {
+      Sym3 W = world_inv_inertia(P, rk->q, R(1) / (scale * scale));
+      for (int j = 0; j < nrg; ++j) {
+        setup_ground_row(P, &rg[j], &hrg[j], &W, rk);
+        rg[j].jn = M->jn[j]; rg[j].jt1 = M->jt1[j]; rg[j].jt2 = M->jt2[j];
+      }
+    }
+    solve_contacts(P, rows, nrows, rg, nrg, rk, b);
+    for (int j = 0; j < nrg; ++j) { M->jn[j] = rg[j].jn; M->jt1[j] = rg[j].jt1; M->jt2[j] = rg[j].jt2; }
   }
   integrate_pose(P, rk, b);
   return bits;
@@ -756,6 +896,7 @@ static void reset_env(const struct TboBatch *B, Env *e, uint64_t env_id) {
   }
   e->step_count = 0;
   e->done = TB_DONE_NO;
+  memset(&e->m, 0, sizeof e->m); /* a rebuilt world has no contacts yet */
 }
 
 /* ------------------------------------------------------------------ step() */
@@ -775,7 +916,7 @@ static real swing_step(const Prm *P, Env *e, const float *a, int *substeps, uint
     F = add3(F, V3(R(-50) * (e->r.p.x - e->aux[2]), R(-2) * (e->r.p.y - e->aux[3]), R(-2) * ((e->r.p.z - e->aux[4]) - R(4))));
     e->done = TB_DONE_YES;
   }
-  int bits = substep(P, TB_ENV_SWING, &e->r, &e->b, F, T, zero, e->aux[0], e->aux[1], R(1)); /* :82 */
+  int bits = substep(P, TB_ENV_SWING, &e->r, &e->b, &e->m, F, T, zero, e->aux[0], e->aux[1], R(1)); /* :82 */
   e->step_count += 1;                                                                   /* :83 */
   int ns = 1;
   real reward = R(0);
@@ -784,7 +925,17 @@ static real swing_step(const Prm *P, Env *e, const float *a, int *substeps, uint
   if (e->step_count > 25) {                                     /* :105 */
     v3 Fp = zero; /* forces were cleared by the substep above */
     while (!e->done) { /* :106 */
-      bits = substep(P, TB_ENV_SWING, &e->r, &e->b, Fp, zero, zero, e->aux[0], e->aux[1], R(1)); /* :107 */
+#ifdef TBO_TRACE_STATIONARY
+      Racket r0 = e->r; Ball b0 = e->b; Manifold m0 = e->m;
+#endif
+      bits = substep(P, TB_ENV_SWING, &e->r, &e->b, &e->m, Fp, zero, zero, e->aux[0], e->aux[1], R(1)); /* :107 */
+#ifdef TBO_TRACE_STATIONARY
+      { extern int g_stat_first[4096]; extern int g_stat_n;
+        static __thread int first; if (e->step_count == 26) first = -1;
+        int same = !memcmp(&r0, &e->r, sizeof r0) && !memcmp(&b0, &e->b, sizeof b0) && m0.n == e->m.n && !memcmp(m0.jn, e->m.jn, sizeof m0.jn) && !memcmp(m0.jt1, e->m.jt1, sizeof m0.jt1) && !memcmp(m0.jt2, e->m.jt2, sizeof m0.jt2);
+        if (same && first < 0) first = e->step_count; if (!same) first = -1;
+        if (e->step_count + 1 > 800 && g_stat_n < 4096) g_stat_first[g_stat_n++] = first; }
+#endif
       e->step_count += 1; ns++;
       if (bits & CT_RACKET) cnt[0]++;
       if (bits & (CT_GROUND | CT_NET)) { e->done = TB_DONE_PENDING_FORCE; reward += moved_dist_to_goal(e); cnt[1]++; } /* :111-114 */
@@ -794,6 +945,7 @@ static real swing_step(const Prm *P, Env *e, const float *a, int *substeps, uint
     }
   }
   *substeps = ns;
+  if (e->m.n == 0) e->m.deep = 0; /* an empty cache is not kept between env.step() calls: the next support walk starts at vertex 0 */
   return reward;
 }
 
@@ -808,13 +960,13 @@ static real tennis_step(const Prm *P, Env *e, const float *a, float *obs, int *r
   v3 F = V3(R(a[0]) * R(10), R(a[1]) * R(10), R(4) * R(9.81)); /* :112-115 */
   v3 Fb = zero;
   if (e->step_count < 5) Fb = V3(e->aux[0], e->aux[1], e->aux[2]); /* :118-119 */
-  int bits = substep(P, TB_ENV_TENNIS, &e->r, &e->b, F, zero, Fb, R(0), R(0), e->aux[3]); /* :121 */
+  int bits = substep(P, TB_ENV_TENNIS, &e->r, &e->b, &e->m, F, zero, Fb, R(0), R(0), e->aux[3]); /* :121 */
   e->step_count += 1;                                                        /* :122 */
   if (bits & CT_RACKET) cnt[0]++;
   fill_obs(TB_ENV_TENNIS, e, obs); /* :134-136 */
   real reward = R(0);
   *ret_done = 0;
-  if (e->step_count < 5) return reward; /* :138-139: returns the literal False, not self.done */
+  if (e->step_count < 5) { if (e->m.n == 0) e->m.deep = 0; return reward; } /* :138-139: returns the literal False, not self.done */
   real dz = e->b.p.z - e->r.p.z, dy = e->b.p.y - e->r.p.y;
   real delta = SQRT(FMA(dz, dz, dy * dy)); /* :142-143 */
   if (bits & CT_RACKET) { reward += R(25); reward += dist_to_reward(delta); } /* :170-174 */
@@ -826,6 +978,7 @@ static real tennis_step(const Prm *P, Env *e, const float *a, float *obs, int *r
   /* :197-198 `3 > x > 15` can never hold: no penalty */
   if (e->step_count > 1000) { if (!e->done) cnt[3]++; e->done = TB_DONE_YES; } /* :201-203 */
   *ret_done = e->done != TB_DONE_NO; /* :207 */
+  if (e->m.n == 0) e->m.deep = 0;
   return reward;
 }
 
@@ -950,10 +1103,16 @@ void tbo_set_state(TboBatch *B, const uint32_t *words, const uint8_t *done) {
     memcpy(&e->step_count, &words[(size_t)(nw - 2) * n + i], 4);
     e->episode = words[(size_t)(nw - 1) * n + i];
     e->done = done ? done[i] : TB_DONE_NO;
+    memset(&e->m, 0, sizeof e->m); /* the contact cache is not part of the state words */
   }
 }
 
 /* unit-level hooks for the known-answer tests */
+int tbo_get_manifold(TboBatch *B, int env, int32_t ids[MAX_RG], double imp[3 * MAX_RG]) {
+  const Manifold *M = &B->e[env].m;
+  for (int j = 0; j < MAX_RG; ++j) { ids[j] = j < M->n ? M->id[j] : -1; imp[3 * j] = j < M->n ? M->jn[j] : 0; imp[3 * j + 1] = j < M->n ? M->jt1[j] : 0; imp[3 * j + 2] = j < M->n ? M->jt2[j] : 0; }
+  return M->n;
+}
 int tbo_query_racket(const TbParams *P0, const float rp[3], const float rq[4], const float c[3], double out[8]) {
   Prm Pq, *P = &Pq; prm_from(P, P0);
   Racket rk; memset(&rk, 0, sizeof rk);
@@ -969,7 +1128,9 @@ int tbo_query_racket_ground(const TbParams *P0, const float rp[3], const float r
   rk.p = V3(R(rp[0]), R(rp[1]), R(rp[2]));
   rk.q.x = R(rq[0]); rk.q.y = R(rq[1]); rk.q.z = R(rq[2]); rk.q.w = R(rq[3]);
   Hit h[MAX_RG];
-  int n = racket_vs_ground(P, &rk, P->racket_scale, h);
+  Manifold M; memset(&M, 0, sizeof M);
+  int n = 0;
+  for (int pass = 0; pass < MAX_RG; ++pass) n = racket_vs_ground(P, &rk, P->racket_scale, &M, h); /* one point per query: let the cache fill */
   for (int j = 0; j < n; ++j) { out[8 * j] = h[j].dist; out[8 * j + 1] = h[j].rr.x; out[8 * j + 2] = h[j].rr.y; out[8 * j + 3] = h[j].rr.z; }
   return n;
 }

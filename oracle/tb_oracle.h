@@ -35,6 +35,7 @@ void tbo_set_state(TboBatch *b, const uint32_t *words, const uint8_t *done);
 void tbo_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 int tbo_query_racket(const TbParams *p, const float rp[3], const float rq[4], const float c[3], double out[8]);
 int tbo_query_racket_ground(const TbParams *p, const float rp[3], const float rq[4], double out[32]);
+int tbo_get_manifold(TboBatch *b, int env, int32_t ids[4], double impulses[12]); /* racket<->court contact cache of one env */
 int tbo_query_box(const TbParams *p, const float half[3], const float c[3], double out[4]);
 int tbo_query_goal(const TbParams *p, float gx, float gy, const float c[3], double out[4]);
 

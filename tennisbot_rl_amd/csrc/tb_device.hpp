@@ -496,17 +496,31 @@ TB_DEV bool rolling_racket(const KParams& P, const RowR& c, RollR& q, Racket& rk
   return moved;
 }
 
-// racket vs the court's ground box (TB_F_RACKET_GROUND; opt-in). Bullet would
-// grow a persistent manifold of up to 4 points over several frames; here the manifold is rebuilt
-// every substep from the hull's 2 x n_hull vertices that are closer to the ground's top face than
-// the manifold threshold (and above the court): the deepest, the one farthest from it, the one
-// spanning the largest triangle with those two and the one spanning the largest triangle on the
-// other side -- Bullet's own reduction rule, applied in the racket frame. Ties: lowest k = 2i+side.
+// racket vs the court's ground box (TB_F_RACKET_GROUND; court.urdf:19-24) with a PERSISTENT manifold,
+// the way Bullet's convex-convex pair works [3P-recalled]: per substep the narrowphase finds ONE point -- the deepest hull
+// vertex, by walking the outline downhill from where the last query ended -- and adds it to a cache of at most 4 points;
+// cached points are refreshed with the new pose and dropped once they are above the manifold threshold; a fifth point
+// replaces the cached one whose loss keeps the largest contact area (never the deepest); every point keeps the impulses of
+// the last solve and the next solve starts from them. A racket in flight costs the bounding-sphere test (or, near the
+// ground, a short support walk); a racket at rest a refresh of 4 vertices and one or two solver sweeps -- not the 76-vertex
+// scan + cold 4-point solve of the stateless round-1 manifold (30 x a free-flight substep). The CPU restatement's
+// racket_vs_ground (the checker, test infrastructure only) is the same algorithm operation by operation.
+// WHERE THE CACHE LIVES: in LDS, one private column per lane (word w of lane t at m[w * stride + t]: conflict-free), 48
+// words: per point its vertex id, the three impulses, and what a solve needs of it (height, arm, effective masses, target).
+// Not registers: 14 + 4 x 19 live VGPRs for a path few lanes take would cost every substep of every kernel an occupancy
+// step. Not scratch either: measured, 1 KB of scratch per lane (cache + rows + an out-of-line function's frame) cut the
+// step kernels' rate by a quarter at 4096 envs and by two thirds at 1 M with the flag OFF, just by being allocated.
+// Only the count and the walk's start vertex are registers. The rows' angular responses W (rr x dir) are recomputed
+// from the arm where they are used (W, 6 registers, lives for one solve): same values as the oracle's stored ones.
 constexpr int TB_MAX_RG = 4;
-struct RowG {  // racket pushed off the ground: n = +z
-  vec3 rr, an, at1, at2;
-  float target, kn, kt1, kt2, jn, jt1, jt2;
+constexpr int TB_MANI_LDS = 12 * TB_MAX_RG;  // words per lane
+enum { MW_ID = 0, MW_JN, MW_JT1, MW_JT2, MW_H, MW_RX, MW_RY, MW_RZ, MW_KN, MW_KT1, MW_KT2, MW_TGT };
+struct Manifold {
+  int n, deep;     // cached points; outline vertex the last support walk ended at
+  float* m;        // this lane's column of the workgroup's LDS scratchpad
+  int stride;      // lanes per workgroup
 };
+TB_DEV float& mw(const Manifold& M, int j, int w) { return M.m[(12 * j + w) * M.stride]; }
 TB_DEV vec3 hull_vertex(const KParams& P, const float4* hull, int k, float s) {
   float hx = P.racket_half_thick * s;
   float4 e0 = hull[2 * (k >> 1)];
@@ -516,131 +530,180 @@ TB_DEV float vertex_height(const KParams& P, const Racket& rk, vec3 zr, vec3 v) 
   float dz = FMA(zr.x, v.x, FMA(zr.z, v.z, zr.y * v.y));
   return ((rk.p.z + dz) - P.hull_margin) - P.ground_half[2];
 }
-// picks[j] = vertex index or -1; returns the number of picks. zr = world z axis in the racket frame.
-// Pass 1 visits the outline once (both faces share the (y, z) part of every dot product); the
-// selection passes visit candidates only, in ascending k (ties go to the lowest index).
-TB_DEV int racket_vs_ground(const KParams& P, const float4* hull, const Racket& rk, float s, int* picks, vec3& zr) {
+TB_DEV float outline_height(const float4* hull, vec3 zr, int i, float s) {
+  float4 e0 = hull[2 * i];
+  return FMA(zr.z, e0.y * s, zr.y * (e0.x * s));
+}
+TB_DEV bool vertex_supported(const KParams& P, const Racket& rk, vec3 xr, vec3 yr, vec3 v, float h, float thr) {
+  if (!(h < thr)) return false;  // above the manifold threshold (however deep below it: see the oracle's note on thin plates)
+  float wx = rk.p.x + FMA(xr.x, v.x, FMA(xr.z, v.z, xr.y * v.y)), wy = rk.p.y + FMA(yr.x, v.x, FMA(yr.z, v.z, yr.y * v.y));
+  return !(fabsf(wx) > P.ground_half[0] || fabsf(wy) > P.ground_half[1]);
+}
+TB_DEV float area4(vec3 p0, vec3 p1, vec3 p2, vec3 p3) {  // Bullet's calcArea4Points
+  vec3 c0 = cross(p0 - p1, p2 - p3), c1 = cross(p0 - p2, p1 - p3), c2 = cross(p0 - p3, p1 - p2);
+  float a0 = dot(c0, c0), a1 = dot(c1, c1), a2 = dot(c2, c2);
+  float m = a0 > a1 ? a0 : a1;
+  return m > a2 ? m : a2;
+}
+// the bounding sphere is clear of the manifold threshold, or the racket's COM is below the court: no contact, cache emptied
+TB_DEV bool racket_clear_of_ground(const KParams& P, const Racket& rk, float s) {
   const float top = P.ground_half[2], thr = P.racket_ground_threshold * s;
-  picks[0] = -1; picks[1] = -1; picks[2] = -1; picks[3] = -1;
-  if ((rk.p.z - (P.hull_bound_radius * s + P.hull_margin)) - top >= thr) return 0;
-  vec3 xr = rotate_inv(rk.q, mk(1.0f, 0.0f, 0.0f)), yr = rotate_inv(rk.q, mk(0.0f, 1.0f, 0.0f));
-  zr = rotate_inv(rk.q, mk(0.0f, 0.0f, 1.0f));
+  return (rk.p.z - (P.hull_bound_radius * s + P.hull_margin)) - top >= thr || !(rk.p.z > top);
+}
+// updates the cache for the racket's present pose (height and arm of every cached point included); returns the number of
+// points. The caller has tested racket_clear_of_ground.
+TB_DEV int racket_vs_ground(const KParams& P, const float4* hull, const Racket& rk, float s, Manifold& M) {
+  const float top = P.ground_half[2], thr = P.racket_ground_threshold * s;
+  const int nh = P.n_hull;
+  const vec3 zr = rotate_inv(rk.q, mk(0.0f, 0.0f, 1.0f));
+  int i = M.deep;
+  float fi = outline_height(hull, zr, i, s);
+  for (int it = 0; it < nh; ++it) {
+    int j = i + 1 == nh ? 0 : i + 1;
+    float fj = outline_height(hull, zr, j, s);
+    if (fj < fi) { i = j; fi = fj; continue; }
+    j = i == 0 ? nh - 1 : i - 1;
+    fj = outline_height(hull, zr, j, s);
+    if (fj < fi) { i = j; fi = fj; continue; }
+    break;
+  }
+  M.deep = i;
+  const int side = zr.x > 0.0f ? 0 : 1;  // the face that looks down
   const float hx = P.racket_half_thick * s;
-  unsigned long long cand0 = 0ull, cand1 = 0ull;
-  int p0 = -1;
-  float h0 = 0.0f;
-  for (int i = 0; i < P.n_hull; ++i) {
-    float4 e0 = hull[2 * i];
-    float vy = e0.x * s, vz = e0.y * s;
-    float bz = FMA(zr.z, vz, zr.y * vy), bx = FMA(xr.z, vz, xr.y * vy), by = FMA(yr.z, vz, yr.y * vy);
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-      float vx = side ? hx : -hx;
-      float h = ((rk.p.z + FMA(zr.x, vx, bz)) - P.hull_margin) - top;
-      if (!(h < thr) || h < -(2.0f * top)) continue;  // above the manifold threshold, or already below the 2*hz thick box
-      float wx = rk.p.x + FMA(xr.x, vx, bx), wy = rk.p.y + FMA(yr.x, vx, by);
-      if (fabsf(wx) > P.ground_half[0] || fabsf(wy) > P.ground_half[1]) continue;
-      if (side) cand1 |= 1ull << i; else cand0 |= 1ull << i;
-      if (p0 < 0 || h < h0) { p0 = 2 * i + side; h0 = h; }
-    }
+  const float h_deep = ((rk.p.z + FMA(zr.x, side ? hx : -hx, fi)) - P.hull_margin) - top;
+  if (M.n == 0 && !(h_deep < thr)) return 0;  // nothing cached, nothing near: the common case of a racket close to the ground
+  const vec3 xr = rotate_inv(rk.q, mk(1.0f, 0.0f, 0.0f)), yr = rotate_inv(rk.q, mk(0.0f, 1.0f, 0.0f));
+  int n = 0;
+#pragma unroll 1
+  for (int j = 0; j < M.n; ++j) {  // refresh the cached points, drop the ones that have left
+    const int k = __float_as_int(mw(M, j, MW_ID));
+    vec3 v = hull_vertex(P, hull, k, s);
+    float hj = vertex_height(P, rk, zr, v);
+    if (!vertex_supported(P, rk, xr, yr, v, hj, thr)) continue;
+    if (n != j) { mw(M, n, MW_ID) = mw(M, j, MW_ID); mw(M, n, MW_JN) = mw(M, j, MW_JN); mw(M, n, MW_JT1) = mw(M, j, MW_JT1); mw(M, n, MW_JT2) = mw(M, j, MW_JT2); }
+    mw(M, n, MW_H) = hj;
+    ++n;
   }
-  if (p0 < 0) return 0;
-  picks[0] = p0;
-  const vec3 v0 = hull_vertex(P, hull, p0, s);
-  float best = 0.0f;
-  for (unsigned long long m = cand0 | cand1; m; m &= m - 1ull) {  // farthest from the deepest
-    const int i = __ffsll((long long)m) - 1;
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-      if (!(((side ? cand1 : cand0) >> i) & 1ull)) continue;
-      vec3 d = hull_vertex(P, hull, 2 * i + side, s) - v0;
-      float d2 = dot(d, d);
-      if (d2 > best) { best = d2; picks[1] = 2 * i + side; }
-    }
-  }
-  if (picks[1] >= 0) {
-    const vec3 e = hull_vertex(P, hull, picks[1], s) - v0;
-    vec3 c2 = mk(0.0f, 0.0f, 0.0f);
-    best = 0.0f;
-    for (unsigned long long m = cand0 | cand1; m; m &= m - 1ull) {  // largest triangle
-      const int i = __ffsll((long long)m) - 1;
-#pragma unroll
-      for (int side = 0; side < 2; ++side) {
-        if (!(((side ? cand1 : cand0) >> i) & 1ull)) continue;
-        vec3 c = cross(hull_vertex(P, hull, 2 * i + side, s) - v0, e);
-        float a2 = dot(c, c);
-        if (a2 > best) { best = a2; picks[2] = 2 * i + side; c2 = c; }
+  M.n = n;
+  const int kd = 2 * i + side;
+  bool known = false;
+#pragma unroll 1
+  for (int j = 0; j < n; ++j) known |= __float_as_int(mw(M, j, MW_ID)) == kd;
+  const vec3 vd = hull_vertex(P, hull, kd, s);
+  if (!known && vertex_supported(P, rk, xr, yr, vd, h_deep, thr)) {
+    int slot = n;
+    if (n == TB_MAX_RG) {  // full: the new point replaces the cached one (never the deepest) whose loss keeps the largest area
+      int deepest = 0;
+      float hd = mw(M, 0, MW_H);
+#pragma unroll 1
+      for (int j = 1; j < TB_MAX_RG; ++j) { float hj = mw(M, j, MW_H); if (hj < hd) { deepest = j; hd = hj; } }
+      if (h_deep < hd) deepest = -1;
+      const vec3 c0 = hull_vertex(P, hull, __float_as_int(mw(M, 0, MW_ID)), s), c1 = hull_vertex(P, hull, __float_as_int(mw(M, 1, MW_ID)), s),
+                 c2 = hull_vertex(P, hull, __float_as_int(mw(M, 2, MW_ID)), s), c3 = hull_vertex(P, hull, __float_as_int(mw(M, 3, MW_ID)), s);
+      float best = -1.0f;
+      slot = -1;
+#pragma unroll 1
+      for (int j = 0; j < TB_MAX_RG; ++j) {
+        if (j == deepest) continue;
+        float a = area4(j == 0 ? vd : c0, j == 1 ? vd : c1, j == 2 ? vd : c2, j == 3 ? vd : c3);
+        if (a > best) { best = a; slot = j; }
       }
-    }
-    if (picks[2] >= 0) {
-      best = 0.0f;
-      for (unsigned long long m = cand0 | cand1; m; m &= m - 1ull) {  // largest triangle on the other side of p0-p1
-        const int i = __ffsll((long long)m) - 1;
-#pragma unroll
-        for (int side = 0; side < 2; ++side) {
-          if (!(((side ? cand1 : cand0) >> i) & 1ull)) continue;
-          vec3 c = cross(hull_vertex(P, hull, 2 * i + side, s) - v0, e);
-          if (!(dot(c, c2) < 0.0f)) continue;
-          float a2 = dot(c, c);
-          if (a2 > best) { best = a2; picks[3] = 2 * i + side; }
-        }
-      }
-    }
+    } else M.n = n + 1;
+    mw(M, slot, MW_ID) = __int_as_float(kd); mw(M, slot, MW_JN) = 0.0f; mw(M, slot, MW_JT1) = 0.0f; mw(M, slot, MW_JT2) = 0.0f; mw(M, slot, MW_H) = h_deep;
   }
-  return (picks[1] >= 0) + (picks[2] >= 0) + (picks[3] >= 0) + 1;
+#pragma unroll 1
+  for (int j = 0; j < M.n; ++j) {
+    vec3 v = hull_vertex(P, hull, __float_as_int(mw(M, j, MW_ID)), s);
+    vec3 r = rotate(rk.q, v);
+    mw(M, j, MW_RX) = r.x; mw(M, j, MW_RY) = r.y; mw(M, j, MW_RZ) = r.z - P.hull_margin;  // the point on the inflated hull
+  }
+  return M.n;
 }
-template <bool SCALED>
-TB_DEV void setup_ground_row(const KParams& P, const float4* hull, RowG& c, int k, float s, vec3 zr, const Racket& rk) {
-  const vec3 n = mk(0.0f, 0.0f, 1.0f);
-  const float inv_s2 = SCALED ? 1.0f / (s * s) : 1.0f;
-  vec3 t1, t2;
-  plane_space(n, t1, t2);
-  vec3 v = hull_vertex(P, hull, k, s);
-  float dist = vertex_height(P, rk, zr, v);
-  c.rr = rotate(rk.q, v);
-  c.rr.z = c.rr.z - P.hull_margin;  // the point on the inflated hull
-  c.jn = 0.0f; c.jt1 = 0.0f; c.jt2 = 0.0f;
-  vec3 a;
-  a = cross(c.rr, n);  c.an = racket_invI<SCALED>(P, rk.q, a, inv_s2);  c.kn = 1.0f / (P.racket_inv_mass + dot(a, c.an));
-  a = cross(c.rr, t1); c.at1 = racket_invI<SCALED>(P, rk.q, a, inv_s2); c.kt1 = 1.0f / (P.racket_inv_mass + dot(a, c.at1));
-  a = cross(c.rr, t2); c.at2 = racket_invI<SCALED>(P, rk.q, a, inv_s2); c.kt2 = 1.0f / (P.racket_inv_mass + dot(a, c.at2));
-  c.target = contact_target(P, dot(n, rk.v + cross(rk.w, c.rr)), dist, P.rest_racket_court);
+
+// World-frame inverse inertia W = R diag(I^-1 / s^2) R^T (6 unique entries) for the racket<->court rows: with up to
+// 4 points x 3 directions per solve, one matrix per substep is cheaper than 12 rotate-scale-rotate round trips.
+struct Sym3 { float xx, xy, xz, yy, yz, zz; };
+TB_DEV Sym3 world_inv_inertia(const KParams& P, quat q, float inv_s2) {
+  float x2 = q.x + q.x, y2 = q.y + q.y, z2 = q.z + q.z;
+  float xx = q.x * x2, xy = q.x * y2, xz = q.x * z2, yy = q.y * y2, yz = q.y * z2, zz = q.z * z2, wx = q.w * x2, wy = q.w * y2, wz = q.w * z2;
+  float r00 = 1.0f - (yy + zz), r01 = xy - wz, r02 = xz + wy, r10 = xy + wz, r11 = 1.0f - (xx + zz), r12 = yz - wx, r20 = xz - wy, r21 = yz + wx, r22 = 1.0f - (xx + yy);
+  float d0 = P.racket_inv_inertia[0] * inv_s2, d1 = P.racket_inv_inertia[1] * inv_s2, d2 = P.racket_inv_inertia[2] * inv_s2;
+  Sym3 W;
+  W.xx = FMA(r02 * d2, r02, FMA(r01 * d1, r01, (r00 * d0) * r00));
+  W.xy = FMA(r02 * d2, r12, FMA(r01 * d1, r11, (r00 * d0) * r10));
+  W.xz = FMA(r02 * d2, r22, FMA(r01 * d1, r21, (r00 * d0) * r20));
+  W.yy = FMA(r12 * d2, r12, FMA(r11 * d1, r11, (r10 * d0) * r10));
+  W.yz = FMA(r12 * d2, r22, FMA(r11 * d1, r21, (r10 * d0) * r20));
+  W.zz = FMA(r22 * d2, r22, FMA(r21 * d1, r21, (r20 * d0) * r20));
+  return W;
 }
-TB_DEV bool normal_ground(const KParams& P, RowG& c, Racket& rk, float& jref) {
-  const vec3 n = mk(0.0f, 0.0f, 1.0f);
-  float vn = dot(n, rk.v + cross(rk.w, c.rr));
-  float jn = FMA(c.target - vn, c.kn, c.jn);
+TB_DEV vec3 sym3_mul(const Sym3& W, vec3 a) {
+  return mk(FMA(W.xz, a.z, FMA(W.xy, a.y, W.xx * a.x)), FMA(W.yz, a.z, FMA(W.yy, a.y, W.xy * a.x)), FMA(W.zz, a.z, FMA(W.yz, a.y, W.xz * a.x)));
+}
+// one racket<->court row: normal +z, friction directions btPlaneSpace1(+z) = (0,-1,0), (1,0,0); rr x n = (rr.y, -rr.x, 0),
+// rr x t1 = (rr.z, 0, -rr.x), rr x t2 = (0, rr.z, -rr.y)
+TB_DEV vec3 mani_arm(const Manifold& M, int j) { return mk(mw(M, j, MW_RX), mw(M, j, MW_RY), mw(M, j, MW_RZ)); }
+TB_DEV void setup_ground_row(const KParams& P, const Manifold& M, int j, const Sym3& W, const Racket& rk) {
+  const vec3 rr = mani_arm(M, j);
+  const float dist = mw(M, j, MW_H);
+  vec3 a = mk(rr.y, -rr.x, 0.0f);
+  mw(M, j, MW_KN) = 1.0f / (P.racket_inv_mass + dot(a, sym3_mul(W, a)));
+  a = mk(rr.z, 0.0f, -rr.x);
+  mw(M, j, MW_KT1) = 1.0f / (P.racket_inv_mass + dot(a, sym3_mul(W, a)));
+  a = mk(0.0f, rr.z, -rr.y);
+  mw(M, j, MW_KT2) = 1.0f / (P.racket_inv_mass + dot(a, sym3_mul(W, a)));
+  vec3 pv = rk.v + cross(rk.w, rr);
+  float vn = pv.z;
+  float rest = fabsf(vn) < P.rest_vel_threshold ? 0.0f : P.rest_racket_court * (-vn);
+  if (rest < 0.0f) rest = 0.0f;
+  float pos = dist > 0.0f ? -(dist * P.inv_dt) : -(dist * P.erp) * P.inv_dt;
+  mw(M, j, MW_TGT) = rest + pos;
+}
+TB_DEV void warm_start_ground(const KParams& P, const Manifold& M, int j, const Sym3& W, Racket& rk, float& jref) {
+  const vec3 rr = mani_arm(M, j);
+  const float jn = mw(M, j, MW_JN), jt1 = mw(M, j, MW_JT1), jt2 = mw(M, j, MW_JT2);
+  if (jn > jref) jref = jn;
+  rk.v.z = FMA(jn, P.racket_inv_mass, rk.v.z);   rk.w = fma3(jn, sym3_mul(W, mk(rr.y, -rr.x, 0.0f)), rk.w);
+  rk.v.y = FMA(-jt1, P.racket_inv_mass, rk.v.y); rk.w = fma3(jt1, sym3_mul(W, mk(rr.z, 0.0f, -rr.x)), rk.w);
+  rk.v.x = FMA(jt2, P.racket_inv_mass, rk.v.x);  rk.w = fma3(jt2, sym3_mul(W, mk(0.0f, rr.z, -rr.y)), rk.w);
+}
+TB_DEV bool normal_ground(const KParams& P, const Manifold& M, int j, const Sym3& W, Racket& rk, float& jref) {
+  const vec3 rr = mani_arm(M, j);
+  const float old = mw(M, j, MW_JN);
+  float vn = (rk.v + cross(rk.w, rr)).z;
+  float jn = FMA(mw(M, j, MW_TGT) - vn, mw(M, j, MW_KN), old);
   if (jn < 0.0f) jn = 0.0f;
-  float d = jn - c.jn;
-  c.jn = jn;
+  float d = jn - old;
+  mw(M, j, MW_JN) = jn;
   if (jn > jref) jref = jn;
   if (d == 0.0f) return false;
-  rk.v = fma3(d * P.racket_inv_mass, n, rk.v);
-  rk.w = fma3(d, c.an, rk.w);
+  rk.v.z = FMA(d, P.racket_inv_mass, rk.v.z);
+  rk.w = fma3(d, sym3_mul(W, mk(rr.y, -rr.x, 0.0f)), rk.w);
   return fabsf(d) > P.solver_tol * jref;
 }
-TB_DEV bool friction_ground(const KParams& P, RowG& c, Racket& rk, float jref) {
-  float lim = P.fric_racket_court * c.jn;
+TB_DEV bool friction_ground(const KParams& P, const Manifold& M, int j, const Sym3& W, Racket& rk, float jref) {
+  float lim = P.fric_racket_court * mw(M, j, MW_JN);
   if (!(lim > 0.0f)) return false;
+  const vec3 rr = mani_arm(M, j);
   bool moved = false;
-  vec3 t1, t2;
-  plane_space(mk(0.0f, 0.0f, 1.0f), t1, t2);
-  float d;
-  bool m = clamp_friction(dot(t1, rk.v + cross(rk.w, c.rr)), c.kt1, lim, P.solver_tol, jref, c.jt1, d);
-  if (d != 0.0f) { moved |= m; rk.v = fma3(d * P.racket_inv_mass, t1, rk.v); rk.w = fma3(d, c.at1, rk.w); }
-  m = clamp_friction(dot(t2, rk.v + cross(rk.w, c.rr)), c.kt2, lim, P.solver_tol, jref, c.jt2, d);
-  if (d != 0.0f) { moved |= m; rk.v = fma3(d * P.racket_inv_mass, t2, rk.v); rk.w = fma3(d, c.at2, rk.w); }
+  float d, acc = mw(M, j, MW_JT1);
+  bool m = clamp_friction(-((rk.v + cross(rk.w, rr)).y), mw(M, j, MW_KT1), lim, P.solver_tol, jref, acc, d);
+  mw(M, j, MW_JT1) = acc;
+  if (d != 0.0f) { moved |= m; rk.v.y = FMA(-d, P.racket_inv_mass, rk.v.y); rk.w = fma3(d, sym3_mul(W, mk(rr.z, 0.0f, -rr.x)), rk.w); }
+  acc = mw(M, j, MW_JT2);
+  m = clamp_friction((rk.v + cross(rk.w, rr)).x, mw(M, j, MW_KT2), lim, P.solver_tol, jref, acc, d);
+  mw(M, j, MW_JT2) = acc;
+  if (d != 0.0f) { moved |= m; rk.v.x = FMA(d, P.racket_inv_mass, rk.v.x); rk.w = fma3(d, sym3_mul(W, mk(0.0f, rr.z, -rr.y)), rk.w); }
   return moved;
 }
 
-// RG = the kernel was instantiated with racket<->court contact. Its rows are statically indexed
-// (registers): unlike ball contacts, a racket resting on the ground is solved on EVERY substep of
-// every such lane, where scratch-resident rows cost ~150 us per substep (measured). The price --
-// ~80 more VGPRs -- is paid only by the RG instantiations, which the host launches only when
-// TB_F_RACKET_GROUND is set; the default kernels do not contain any of this.
+// RG = the kernel was instantiated with the extended contact set: racket<->court contact (TB_F_RACKET_GROUND; its cache and
+// rows live in LDS, see Manifold) and the rolling-friction rows (TbParams.roll_*); run-time flags / coefficients pick either.
+// The default kernels carry neither: measured with both compiled in but switched off, the step kernels lost 3.5 % at 4096
+// envs and SwingRacket 18 % at 1 M (195 instead of 166 VGPRs in the fast-forward loop: a wave per SIMD less).
 template <bool RG> struct Rows;
 template <> struct Rows<false> { RowR rk; RowS st[3]; bool on[4]; };
-template <> struct Rows<true> { RowR rk; RowS st[3]; bool on[4]; RowG rg[TB_MAX_RG]; int nrg; RollR qrk; RollS qst[3]; };
+template <> struct Rows<true> { RowR rk; RowS st[3]; bool on[4]; RollR qrk; RollS qst[3]; };
 
 // REGROWS: the three static rows statically indexed too, i.e. in registers (~40 VGPRs more): the right
 // trade where balls bounce on the court all the time -- Tennisbot at every batch size (+8 ... +28 % in
@@ -648,8 +711,12 @@ template <> struct Rows<true> { RowR rk; RowS st[3]; bool on[4]; RowG rg[TB_MAX_
 // envs (+2.7 % at 4096); in SwingRacket's fast-forward loop the registers cost more than they give
 // (-6 % at 4096 envs, -17 % at 1 M). Same arithmetic either way.
 template <bool RG, bool REGROWS>
-TB_DEV void solve_contacts(const KParams& P, Rows<RG>& R, Racket& rk, Ball& b) {
+TB_DEV void solve_contacts(const KParams& P, Rows<RG>& R, const Manifold& M, int nrg, const Sym3& W, Racket& rk, Ball& b) {
   float jref = 0.0f;
+  if constexpr (RG) {
+#pragma unroll 1
+    for (int j = 0; j < nrg; ++j) warm_start_ground(P, M, j, W, rk, jref);  // the cached impulses of the last solve
+  }
   for (int it = 0; it < P.solver_iters; ++it) {
     bool moved = false;
     if (R.on[0]) moved |= normal_racket(P, R.rk, rk, b, jref);
@@ -663,9 +730,8 @@ TB_DEV void solve_contacts(const KParams& P, Rows<RG>& R, Racket& rk, Ball& b) {
         if (R.on[i + 1]) moved |= normal_static(P, R.st[i], b, jref);
     }
     if constexpr (RG) {
-#pragma unroll
-      for (int j = 0; j < TB_MAX_RG; ++j)
-        if (j < R.nrg) moved |= normal_ground(P, R.rg[j], rk, jref);
+#pragma unroll 1
+      for (int j = 0; j < nrg; ++j) moved |= normal_ground(P, M, j, W, rk, jref);
     }
     if constexpr (RG) {  // rolling rows: after the normals, before sliding friction
       if (R.on[0]) moved |= rolling_racket(P, R.rk, R.qrk, rk, b, jref);
@@ -684,9 +750,8 @@ TB_DEV void solve_contacts(const KParams& P, Rows<RG>& R, Racket& rk, Ball& b) {
         if (R.on[i + 1]) moved |= friction_static(P, R.st[i], b, jref);
     }
     if constexpr (RG) {
-#pragma unroll
-      for (int j = 0; j < TB_MAX_RG; ++j)
-        if (j < R.nrg) moved |= friction_ground(P, R.rg[j], rk, jref);
+#pragma unroll 1
+      for (int j = 0; j < nrg; ++j) moved |= friction_ground(P, M, j, W, rk, jref);
     }
     if (!moved) break;
   }
@@ -774,11 +839,20 @@ TB_DEV void integrate_pose(const KParams& P, Racket& rk, Ball& b) {
 // time. Pays where SGPRs are scarce and contacts rare (the policy rollout kernel: 97 -> 70 spill writes, collect +10 %); costs VGPRs and
 // LDS reads where throughput counts (SwingRacket at 1 M envs -15 %, Tennisbot -4 %), so only that kernel asks for it.
 template <int KIND, bool RG, bool REGROWS = false, bool COLD = false, bool RELOAD = false>
-TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, vec3 Fr, vec3 Tr, vec3 Fb, float goal_x, float goal_y, float scale TB_STAMP_ARG) {
+TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Manifold& M, vec3 Fr, vec3 Tr, vec3 Fb, float goal_x, float goal_y, float scale TB_STAMP_ARG) {
   int bits = 0;
   TB_STAMP(st, 0);  // everything between two substeps (loop control, env logic)
   // the velocity update touches velocities only and the narrowphase reads poses only: their order
   // is free, and running it first keeps the Hit records from staying live across it
+  // racket <-> court: poses only, like every narrowphase, so it may run before the velocity update as well; the common case
+  // is the bounding-sphere test failing (racket in flight, or hovering as in Tennisbot)
+  int nrg = 0;
+  if constexpr (RG) {  // the RG instantiations also serve rolling friction alone: the flag decides at run time
+    if (P.flags & TB_F_RACKET_GROUND) {
+      if (racket_clear_of_ground(P, rk, scale)) M.n = 0;
+      else nrg = racket_vs_ground(P, hull, rk, scale, M);
+    }
+  }
   integrate_velocities(P, rk, b, Fr, Tr, Fb);
   TB_STAMP(st, 3);  // velocity update
   Hit hr, hg, hn, hc;
@@ -817,23 +891,20 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, ve
   if (hg.hit) bits |= CT_GROUND;
   if (hn.hit) bits |= CT_NET;
   if (hc.hit) bits |= CT_GOAL;
-  int rg_picks[TB_MAX_RG] = {-1, -1, -1, -1};
-  vec3 rg_zr = mk(0.0f, 0.0f, 0.0f);
-  if constexpr (RG) {  // the RG instantiations also serve rolling friction alone: the flag decides at run time
-    if (P.flags & TB_F_RACKET_GROUND)
-      if (racket_vs_ground(P, hull, rk, scale, rg_picks, rg_zr) > 0) bits |= CT_RACKET_COURT;
-  }
+  if (nrg) bits |= CT_RACKET_COURT;
 
   if (__any(bits != 0)) {
     if (bits) {  // only lanes that touch something enter the solver
       const KParams& PC = COLD ? *reinterpret_cast<const KParams*>(hull + TB_HULL_KP) : P;
       Rows<RG> R;
+      Sym3 W;
+      W.xx = 0.0f; W.xy = 0.0f; W.xz = 0.0f; W.yy = 0.0f; W.yz = 0.0f; W.zz = 0.0f;
       if constexpr (RG) {
-        R.nrg = (rg_picks[0] >= 0) + (rg_picks[1] >= 0) + (rg_picks[2] >= 0) + (rg_picks[3] >= 0);
-        // picks are found in order 0..3 and a later one exists only if the earlier ones do: compact already
-#pragma unroll
-        for (int j = 0; j < TB_MAX_RG; ++j)
-          if (rg_picks[j] >= 0) setup_ground_row<KIND == TB_ENV_TENNIS>(PC, hull, R.rg[j], rg_picks[j], scale, rg_zr, rk);
+        if (nrg) {
+          W = world_inv_inertia(PC, rk.q, 1.0f / (scale * scale));
+#pragma unroll 1
+          for (int j = 0; j < nrg; ++j) setup_ground_row(PC, M, j, W, rk);
+        }
       }
       R.on[0] = bits & CT_RACKET; R.on[1] = bits & CT_GROUND; R.on[2] = bits & CT_NET; R.on[3] = bits & CT_GOAL;
       if (R.on[0]) setup_racket<KIND == TB_ENV_TENNIS>(PC, R.rk, hr, rk, b, scale);
@@ -846,7 +917,7 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, ve
         if (R.on[2]) setup_roll_static(PC, R.qst[1], PC.roll_court);
         if (R.on[3]) setup_roll_static(PC, R.qst[2], PC.roll_goal);
       }
-      solve_contacts<RG, REGROWS>(PC, R, rk, b);
+      solve_contacts<RG, REGROWS>(PC, R, M, nrg, W, rk, b);
     }
   }
   TB_STAMP(st, 4);  // contact solve

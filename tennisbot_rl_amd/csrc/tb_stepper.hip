@@ -43,6 +43,8 @@ struct KArgs {
   int32_t* substeps;      // [n] or null
   const uint8_t* mask;    // reset kernel: [n] or null
   unsigned long long* counters;  // [TB_COUNTER_SHARDS][TB_N_COUNTERS]
+  uint32_t* mani;         // [TB_MANI_WORDS][n] racket<->court contact caches (Manifold), valid where mflag is set
+  uint8_t* mflag;         // [n] 1 = env i has cached contact points
   unsigned long long seed, env_id_base;
   int n, T;
   // pipelined fast-forward (tb_set_pipeline): a step that starts a SwingRacket fast-forward parks
@@ -115,6 +117,43 @@ TB_DEV void store_env(uint32_t* w, uint8_t* done_state, int n, int i, const EnvR
   }
   w[(size_t)(Dims<KIND>::W - 2) * n + i] = (uint32_t)e.step_count;
   done_state[i] = (uint8_t)e.done;
+}
+
+// The racket<->court contact cache between launches: handle-owned rows next to the state (not part of the state words: a
+// restored state starts with an empty cache, like the oracle's). One flag byte per env is read by every launch; the 14 words
+// behind it only by lanes that have cached points -- a racket on the ground.
+#define TB_MANI_WORDS 14
+// every kernel that steps envs gets TB_MANI_LDS words of dynamic LDS per thread for the caches (tb_device.hpp, Manifold)
+extern __shared__ float s_mani[];
+TB_DEV void init_manifold(Manifold& M, int lane_in_block, int lanes) { M.n = 0; M.deep = 0; M.m = s_mani + lane_in_block; M.stride = lanes; }
+TB_DEV void load_manifold(const KArgs& A, int i, Manifold& M) {
+  const uint32_t w0 = A.mani[i], w1 = A.mani[(size_t)A.n + i];
+  M.n = (int)(w0 & 255u); M.deep = (int)(w0 >> 8);
+#pragma unroll 1
+  for (int j = 0; j < TB_MAX_RG; ++j) {
+    mw(M, j, MW_ID) = __int_as_float((int)((w1 >> (8 * j)) & 255u));
+    mw(M, j, MW_JN) = __uint_as_float(A.mani[(size_t)(2 + j) * A.n + i]);
+    mw(M, j, MW_JT1) = __uint_as_float(A.mani[(size_t)(6 + j) * A.n + i]);
+    mw(M, j, MW_JT2) = __uint_as_float(A.mani[(size_t)(10 + j) * A.n + i]);
+  }
+}
+TB_DEV void store_manifold(const KArgs& A, int i, const Manifold& M, bool had) {
+  if (M.n > 0) {
+    uint32_t w1 = 0u;
+#pragma unroll 1
+    for (int j = 0; j < TB_MAX_RG; ++j) {
+      const bool on = j < M.n;
+      w1 |= (uint32_t)(on ? __float_as_int(mw(M, j, MW_ID)) : 0) << (8 * j);
+      A.mani[(size_t)(2 + j) * A.n + i] = on ? __float_as_uint(mw(M, j, MW_JN)) : 0u;
+      A.mani[(size_t)(6 + j) * A.n + i] = on ? __float_as_uint(mw(M, j, MW_JT1)) : 0u;
+      A.mani[(size_t)(10 + j) * A.n + i] = on ? __float_as_uint(mw(M, j, MW_JT2)) : 0u;
+    }
+    A.mani[i] = (uint32_t)M.n | ((uint32_t)M.deep << 8);
+    A.mani[(size_t)A.n + i] = w1;
+    A.mflag[i] = 1;
+  } else if (had) {
+    A.mflag[i] = 0;
+  }
 }
 
 template <int KIND>
@@ -206,8 +245,8 @@ TB_DEV void reset_env(const KArgs& A, const float4* KP, int i, EnvRegs& e) {
 // fast-forward kernel hands records to lanes in another order than the env index (sorted by predicted flight
 // length, or a few per wave), and a lane that fetches a whole 128-byte line wastes nothing, where a gather from
 // the SoA rows would pull a 32-byte sector per word.
-#define TB_FF_REC 8  // float4 per record
-TB_DEV void park_env(float4* rec, int i, const EnvRegs& e) {
+#define TB_FF_REC 12  // float4 per record: state (8) + the racket<->court contact cache (4)
+TB_DEV void park_env(float4* rec, int i, const EnvRegs& e, const Manifold& M) {
   float4* r = rec + (size_t)i * TB_FF_REC;
   r[0] = make_float4(e.r.p.x, e.r.p.y, e.r.p.z, e.r.q.x);
   r[1] = make_float4(e.r.q.y, e.r.q.z, e.r.q.w, e.r.v.x);
@@ -217,8 +256,37 @@ TB_DEV void park_env(float4* rec, int i, const EnvRegs& e) {
   r[5] = make_float4(e.b.w.y, e.b.w.z, e.aux[0], e.aux[1]);
   r[6] = make_float4(e.aux[2], e.aux[3], e.aux[4], e.aux[5]);
   r[7] = make_float4(__int_as_float(e.step_count), __uint_as_float(e.episode), __uint_as_float(1u), __int_as_float(i));
+  // (statically indexed: registers; lanes without cached points -- nearly all -- skip the LDS reads)
+  uint32_t ids = 0u;
+  float imp[3 * TB_MAX_RG];
+#pragma unroll
+  for (int j = 0; j < 3 * TB_MAX_RG; ++j) imp[j] = 0.0f;
+  if (M.n > 0) {
+#pragma unroll
+    for (int j = 0; j < TB_MAX_RG; ++j) {
+      const bool on = j < M.n;
+      ids |= (uint32_t)(on ? __float_as_int(mw(M, j, MW_ID)) : 0) << (8 * j);
+      imp[j] = on ? mw(M, j, MW_JN) : 0.0f; imp[TB_MAX_RG + j] = on ? mw(M, j, MW_JT1) : 0.0f; imp[2 * TB_MAX_RG + j] = on ? mw(M, j, MW_JT2) : 0.0f;
+    }
+  }
+  r[8] = make_float4(__uint_as_float((uint32_t)M.n | ((uint32_t)M.deep << 8)), __uint_as_float(ids), imp[0], imp[1]);
+  r[9] = make_float4(imp[2], imp[3], imp[4], imp[5]);
+  r[10] = make_float4(imp[6], imp[7], imp[8], imp[9]);
+  r[11] = make_float4(imp[10], imp[11], 0.0f, 0.0f);
 }
-TB_DEV void unpark_env(const float4* r, EnvRegs& e, int& env_index) {
+TB_DEV void unpark_env(const float4* r, EnvRegs& e, Manifold& M, int& env_index) {
+  {
+    const uint32_t w0 = __float_as_uint(r[8].x), ids = __float_as_uint(r[8].y);
+    const float imp[3 * TB_MAX_RG] = {r[8].z, r[8].w, r[9].x, r[9].y, r[9].z, r[9].w, r[10].x, r[10].y, r[10].z, r[10].w, r[11].x, r[11].y};
+    M.n = (int)(w0 & 255u); M.deep = (int)(w0 >> 8);
+    if (M.n > 0) {
+#pragma unroll
+      for (int j = 0; j < TB_MAX_RG; ++j) {
+        mw(M, j, MW_ID) = __int_as_float((int)((ids >> (8 * j)) & 255u));
+        mw(M, j, MW_JN) = imp[j]; mw(M, j, MW_JT1) = imp[TB_MAX_RG + j]; mw(M, j, MW_JT2) = imp[2 * TB_MAX_RG + j];
+      }
+    }
+  }
   e.r.p = mk(r[0].x, r[0].y, r[0].z);
   e.r.q.x = r[0].w; e.r.q.y = r[1].x; e.r.q.z = r[1].y; e.r.q.w = r[1].z;
   e.r.v = mk(r[1].w, r[2].x, r[2].y);
@@ -273,12 +341,12 @@ TB_DEV vec3 restoring_force(const EnvRegs& e) {  // swingracket_env.py:135-141
 // BUDGET  = tb_ff_kernel only: leave the loop after `budget` substeps with the env still running (`parked` again): the
 //           next phase kernel resumes it from the saved state, with the restoring force recomputed from that state.
 template <bool RG, bool REGROWS = false, bool COLD = false, bool BUDGET = false, bool RELOAD = false>
-TB_DEV float swing_loop(const KParams& P, const float4* hull, EnvRegs& e, vec3 F, vec3 T, bool in_ff, bool defer, bool& parked,
+TB_DEV float swing_loop(const KParams& P, const float4* hull, EnvRegs& e, Manifold& M, vec3 F, vec3 T, bool in_ff, bool defer, bool& parked,
                         int& ns, uint32_t* cnt TB_STAMP_ARG, int budget = 0) {
   const vec3 zero = mk(0.0f, 0.0f, 0.0f);
   float reward = 0.0f;
   for (;;) {
-    int bits = substep<TB_ENV_SWING, RG, REGROWS, COLD, RELOAD>(P, hull, e.r, e.b, F, T, zero, e.aux[0], e.aux[1], 1.0f TB_STAMP_PASS);  // :82 / :107
+    int bits = substep<TB_ENV_SWING, RG, REGROWS, COLD, RELOAD>(P, hull, e.r, e.b, M, F, T, zero, e.aux[0], e.aux[1], 1.0f TB_STAMP_PASS);  // :82 / :107
     e.step_count += 1; ns++;                                                                                   // :83 / :108
     if (bits & CT_RACKET) cnt[0]++;
     if (!in_ff) {
@@ -299,7 +367,7 @@ TB_DEV float swing_loop(const KParams& P, const float4* hull, EnvRegs& e, vec3 F
 }
 
 template <bool RG, bool REGROWS = false, bool COLD = false>
-TB_DEV float swing_step(const KParams& P, const float4* hull, EnvRegs& e, const float* a, int& ns, uint32_t* cnt, bool defer, bool& parked TB_STAMP_ARG) {
+TB_DEV float swing_step(const KParams& P, const float4* hull, EnvRegs& e, Manifold& M, const float* a, int& ns, uint32_t* cnt, bool defer, bool& parked TB_STAMP_ARG) {
   vec3 F = mk(a[0] * 400.0f, a[1] * 400.0f, FMA(a[2], 400.0f, 4.0f * 9.81f));  // :76-77
   vec3 T = mk(a[3] * 5.0f, a[4] * 5.0f, a[5] * 5.0f);                          // :78
   if (e.done == TB_DONE_PENDING_FORCE) {  // the force of :135-141 is still in the accumulator
@@ -307,7 +375,9 @@ TB_DEV float swing_step(const KParams& P, const float4* hull, EnvRegs& e, const 
     e.done = TB_DONE_YES;
   }
   ns = 0;
-  return swing_loop<RG, REGROWS, COLD>(P, hull, e, F, T, false, defer, parked, ns, cnt TB_STAMP_PASS);
+  const float rew = swing_loop<RG, REGROWS, COLD>(P, hull, e, M, F, T, false, defer, parked, ns, cnt TB_STAMP_PASS);
+  if (!parked && M.n == 0) M.deep = 0;  // an empty cache is not kept between env.step() calls (a parked env's call is not over: its record keeps it)
+  return rew;
 }
 
 // tennisbot_env.py:90-102
@@ -317,12 +387,13 @@ TB_DEV float dist_to_reward(float d) {
 
 // tennisbot_env.py:104-207 (the DELAY_MODE sleep at :124-126 is dropped on purpose)
 template <bool RG, bool REGROWS = false, bool COLD = false>
-TB_DEV float tennis_step(const KParams& P, const float4* hull, EnvRegs& e, const float* a, float* obs, bool& ret_done, uint32_t* cnt TB_STAMP_ARG) {
+TB_DEV float tennis_step(const KParams& P, const float4* hull, EnvRegs& e, Manifold& M, const float* a, float* obs, bool& ret_done, uint32_t* cnt TB_STAMP_ARG) {
   const vec3 zero = mk(0.0f, 0.0f, 0.0f);
   vec3 F = mk(a[0] * 10.0f, a[1] * 10.0f, 4.0f * 9.81f);  // :112-115
   vec3 Fb = zero;
   if (e.step_count < 5) Fb = mk(e.aux[0], e.aux[1], e.aux[2]);  // :118-119
-  int bits = substep<TB_ENV_TENNIS, RG, REGROWS, COLD>(P, hull, e.r, e.b, F, zero, Fb, 0.0f, 0.0f, e.aux[3] TB_STAMP_PASS);  // :121
+  int bits = substep<TB_ENV_TENNIS, RG, REGROWS, COLD>(P, hull, e.r, e.b, M, F, zero, Fb, 0.0f, 0.0f, e.aux[3] TB_STAMP_PASS);  // :121
+  if (M.n == 0) M.deep = 0;  // an empty cache is not kept between env.step() calls
   e.step_count += 1;                                                                // :122
   if (bits & CT_RACKET) cnt[0]++;
   make_obs<TB_ENV_TENNIS>(e, obs);  // :134-136
@@ -415,6 +486,12 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
     load_env<KIND>(w_words, w_done, w_n, i, e);
     if (!POLICY) load_actions<KIND>(w_actions, (size_t)i, a);
   }
+  Manifold M;
+  init_manifold(M, POLICY ? (int)(threadIdx.x & 63) : (int)threadIdx.x, POLICY ? 64 : (int)blockDim.x);
+  bool had_contacts = false;
+  if constexpr (RG) {
+    if (live && !(POLICY && threadIdx.x >= 64)) { had_contacts = A.mflag[i] != 0; if (had_contacts) load_manifold(A, i, M); }
+  }
   if (POLICY) {
     // one barrier for both hand-offs (outline table, action means); the outline rows are requested
     // before the towers' operands and parked in a register meanwhile
@@ -460,7 +537,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
       bool d, parked = false;
       float rew;
       if (KIND == TB_ENV_SWING) {
-        rew = swing_step<RG, REGROWS>(A.P, s_hull, e, a, ns, cnt, LEAN || A.defer != 0, parked TB_STAMP_PASS);
+        rew = swing_step<RG, REGROWS>(A.P, s_hull, e, M, a, ns, cnt, LEAN || A.defer != 0, parked TB_STAMP_PASS);
         make_obs<TB_ENV_SWING>(e, o);
         d = e.done != TB_DONE_NO;  // swingracket_env.py:145 returns self.done
         if (parked) {
@@ -468,14 +545,14 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
           // done = 1 is known now; reward, terminal obs and substep count of this step are written
           // later by tb_ff_kernel from the parked state. The env itself restarts immediately.
           if (A.ff_rec) {
-            park_env(A.ff_rec, i, e);
+            park_env(A.ff_rec, i, e, M);
           } else {
             cnt[8]++;  // lockstep invariant broken (see launch_step): reported, never silent
           }
           d = true;
         }
       } else {
-        rew = tennis_step<RG, REGROWS>(A.P, s_hull, e, a, o, d, cnt TB_STAMP_PASS);
+        rew = tennis_step<RG, REGROWS>(A.P, s_hull, e, M, a, o, d, cnt TB_STAMP_PASS);
       }
       cnt[6] += (uint32_t)(ns - 1);  // substeps beyond the first of each agent step
       ns_total += ns;
@@ -487,6 +564,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
         if (A.term_obs && !parked) write_obs<KIND>(A.term_obs, (size_t)i, o);
         e.episode += 1u;
         reset_env<KIND>(A, s_hull + TB_HULL_KP, i, e);
+        M.n = 0; M.deep = 0;  // a rebuilt world has no contacts yet
         make_obs<KIND>(e, o);
         any_reset = true;
       }
@@ -499,6 +577,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
 #endif
     if (A.substeps) A.substeps[i] = ns_total;
     store_env<KIND>(A.words, A.done_state, A.n, i, e, any_reset);
+    if constexpr (RG) { if (M.n > 0 || had_contacts) store_manifold(A, i, M, had_contacts); }
   }
 #ifdef TB_DIAG_STAMPS
   if ((threadIdx.x & 63) == 0) atomicAdd(&g_diag_cycles[7], t_loaded - t_entry);  // state + outline loads landed
@@ -570,6 +649,8 @@ __global__ void __launch_bounds__(320) tb_policy_rollout_kernel(KArgs A) {
   const bool live = i < A.n;
   EnvRegs e;
   if (live) load_env<KIND>(A.words, A.done_state, A.n, i, e);
+  Manifold M;
+  init_manifold(M, lane, 64);  // (never touched: this kernel is not instantiated with the extended contact set)
   uint32_t cnt[TB_N_COUNTERS];
 #pragma unroll
   for (int k = 0; k < TB_N_COUNTERS; ++k) cnt[k] = 0u;
@@ -594,19 +675,19 @@ __global__ void __launch_bounds__(320) tb_policy_rollout_kernel(KArgs A) {
       bool d, parked = false;
       float rew;
       if (KIND == TB_ENV_SWING) {
-        rew = swing_step<false, false, true>(A.P, s_hull, e, a, ns, cnt, true, parked TB_STAMP_PASS);  // never loops in here: see tb_step_kernel<LEAN>; COLD
+        rew = swing_step<false, false, true>(A.P, s_hull, e, M, a, ns, cnt, true, parked TB_STAMP_PASS);  // never loops in here: see tb_step_kernel<LEAN>; COLD
         make_obs<TB_ENV_SWING>(e, o);
         d = e.done != TB_DONE_NO;
         if (parked) {
           if (A.ff_rec) {
-            park_env(A.ff_rec, i, e);
+            park_env(A.ff_rec, i, e, M);
           } else {
             cnt[8]++;  // lockstep invariant broken (see launch_policy_rollout): reported, never silent
           }
           d = true;
         }
       } else {
-        rew = tennis_step<false, true, true>(A.P, s_hull, e, a, o, d, cnt TB_STAMP_PASS);
+        rew = tennis_step<false, true, true>(A.P, s_hull, e, M, a, o, d, cnt TB_STAMP_PASS);
       }
       cnt[6] += (uint32_t)(ns - 1);
       if (!(finite3(e.r.p) && finite3(e.r.v) && finite3(e.r.w) && finite3(e.b.p) && finite3(e.b.v) && finite3(e.b.w) &&
@@ -616,6 +697,7 @@ __global__ void __launch_bounds__(320) tb_policy_rollout_kernel(KArgs A) {
         cnt[5]++;
         e.episode += 1u;
         reset_env<KIND>(A, s_hull + TB_HULL_KP, i, e);
+        M.n = 0; M.deep = 0;
         make_obs<KIND>(e, o);
         any_reset = true;
       }
@@ -730,9 +812,11 @@ __global__ void __launch_bounds__(64) tb_ff_kernel(KArgs A) {
     }
     bool unfinished = false;
     EnvRegs e;
+    Manifold M;
+    init_manifold(M, lane, 64);
     int i = 0, ns = 1;  // fresh from the step kernel: it ran the first substep of this agent step
     if (live) {
-      unpark_env(r, e, i);
+      unpark_env(r, e, M, i);
       const uint32_t tag = __float_as_uint(r[7].z);
       if ((tag & 255u) == 2u) ns = (int)(tag >> 8);  // a survivor of an earlier phase: substeps so far
       const vec3 zero = mk(0.0f, 0.0f, 0.0f);
@@ -741,7 +825,7 @@ __global__ void __launch_bounds__(64) tb_ff_kernel(KArgs A) {
       const vec3 F0 = e.step_count > 26 ? restoring_force(e) : zero;
       const int budget = A.ff_next ? 4 * predict_flight(A.P, e.b.p, e.b.v) + 8 : 0x7fffffff;
       const int ns0 = ns;
-      float rew = swing_loop<RG, false, false, true, BIG>(A.P, s_hull, e, F0, zero, true, false, unfinished, ns, cnt TB_STAMP_PASS, budget);
+      float rew = swing_loop<RG, false, false, true, BIG>(A.P, s_hull, e, M, F0, zero, true, false, unfinished, ns, cnt TB_STAMP_PASS, budget);
       cnt[6] += (uint32_t)(ns - ns0);
       if (!unfinished) {
         if (!(finite3(e.r.p) && finite3(e.r.v) && finite3(e.r.w) && finite3(e.b.p) && finite3(e.b.v) && finite3(e.b.w) &&
@@ -762,7 +846,7 @@ __global__ void __launch_bounds__(64) tb_ff_kernel(KArgs A) {
         if (lane == 0) first = atomicAdd(A.ff_next_count, __popcll(m));
         first = __shfl(first, 0, 64);
         if (unfinished) {
-          park_env(A.ff_next, first + __popcll(m & ((1ull << lane) - 1ull)), e);
+          park_env(A.ff_next, first + __popcll(m & ((1ull << lane) - 1ull)), e, M);
           uint32_t* w = reinterpret_cast<uint32_t*>(A.ff_next + (size_t)(first + __popcll(m & ((1ull << lane) - 1ull))) * TB_FF_REC + 7);
           w[2] = 2u | ((uint32_t)ns << 8);
           w[3] = (uint32_t)i;
@@ -795,6 +879,7 @@ __global__ void __launch_bounds__(256) tb_reset_kernel(KArgs A) {
   e.episode = A.words[(size_t)(Dims<KIND>::W - 1) * A.n + i] + 1u;
   reset_env<KIND>(A, A.hull + TB_HULL_KP, i, e);
   store_env<KIND>(A.words, A.done_state, A.n, i, e, true);
+  A.mflag[i] = 0;  // a rebuilt world has no contacts yet
   if (A.obs) {
     float o[Dims<KIND>::O];
     make_obs<KIND>(e, o);
@@ -925,6 +1010,8 @@ struct TbHandle {
   float4* h_hull;  // pinned staging copy of the outline table
   float cull_planes[TB_N_CULL][3];  // derived from the outline (to_kparams); they travel behind it in the same table
   unsigned long long* d_counters;     // [TB_COUNTER_SHARDS][TB_N_COUNTERS]
+  uint32_t* d_mani;                   // [TB_MANI_WORDS][n] racket<->court contact caches
+  uint8_t* d_mflag;                   // [n]
   // pipelined fast-forward
   int pipeline;            // enabled by tb_set_pipeline
   int phase, phase_valid;  // agent steps since the last full reset (SwingRacket episodes are exactly 26 steps)
@@ -946,10 +1033,14 @@ struct TbHandle {
   // its side stream). No extra streams, no extra graph edges: a mark never makes anything wait. What a mark still has
   // to wait for -- the fast-forwards enqueued before it -- is host arithmetic over these two kinds of counters.
   unsigned long long* h_marks;
-  unsigned long long snap_ff, snap_marks[TB_MAX_MARKS];  // the counters at tb_mark_begin (nothing of this handle in flight)
+  unsigned long long snap_ff[TB_FF_SLOTS], snap_marks[TB_MAX_MARKS];  // the counters at tb_mark_begin (nothing of this handle in flight)
   int marks_on;                               // tb_mark_enable: fast-forwards are followed by their counting kernel
-  long long ff_cap, ff_eager;                 // fast-forwards enqueued: inside the current / latest capture; eagerly since tb_mark_begin
-  long long mark_ff_before[TB_MAX_MARKS];     // recorded inside a capture: ff_cap at that point; eagerly: -1 - ff_eager
+  // fast-forwards enqueued PER SLOT (= per side stream: only there is "the first k have finished" the same as "k have
+  // finished" -- fast-forwards of different episodes overtake each other, one with a ball at rest on a grounded racket
+  // runs five times as long as the next): inside the current / latest capture; eagerly since tb_mark_begin
+  long long ff_cap[TB_FF_SLOTS], ff_eager[TB_FF_SLOTS];
+  long long mark_ff_before[TB_MAX_MARKS][TB_FF_SLOTS];  // recorded inside a capture: ff_cap at that point; eagerly: -1 - ff_eager
+  int mark_in_capture[TB_MAX_MARKS];
 };
 
 namespace {
@@ -958,8 +1049,8 @@ int words_of(int kind) { return kind == TB_ENV_SWING ? TB_SWING_WORDS : TB_TENNI
 
 int ensure_marks(TbHandle* h) {
   if (h->h_marks) return TB_OK;
-  HIP_TRY(hipHostMalloc((void**)&h->h_marks, sizeof(unsigned long long) * (TB_MAX_MARKS + 1), hipHostMallocDefault));
-  memset(h->h_marks, 0, sizeof(unsigned long long) * (TB_MAX_MARKS + 1));
+  HIP_TRY(hipHostMalloc((void**)&h->h_marks, sizeof(unsigned long long) * (TB_MAX_MARKS + TB_FF_SLOTS), hipHostMallocDefault));
+  memset(h->h_marks, 0, sizeof(unsigned long long) * (TB_MAX_MARKS + TB_FF_SLOTS));
   return TB_OK;
 }
 
@@ -974,6 +1065,7 @@ KArgs base_args(const TbHandle* h) {
   KArgs a;
   memset(&a, 0, sizeof a);
   a.P = h->kp; a.words = h->d_words; a.done_state = h->d_done; a.hull = h->d_hull; a.counters = h->d_counters;
+  a.mani = h->d_mani; a.mflag = h->d_mflag;
   a.seed = h->seed; a.env_id_base = h->env_id_base; a.n = h->n; a.T = 1;
   return a;
 }
@@ -1032,17 +1124,17 @@ int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const 
     }
     if (ph + 1 < phases) { k.ff_next = h->d_ff_list[slot][ph]; k.ff_next_count = h->d_ff_count[slot] + ph; }
     const bool big = h->n >= 131072;
-    if (rg) { if (big) hipLaunchKernelGGL((tb_ff_kernel<true, true>), grid, block, 0, h->side[slot], k); else hipLaunchKernelGGL((tb_ff_kernel<true, false>), grid, block, 0, h->side[slot], k); }
+    if (rg) { if (big) hipLaunchKernelGGL((tb_ff_kernel<true, true>), grid, block, TB_MANI_LDS * sizeof(float) * 64, h->side[slot], k); else hipLaunchKernelGGL((tb_ff_kernel<true, false>), grid, block, TB_MANI_LDS * sizeof(float) * 64, h->side[slot], k); }
     else { if (big) hipLaunchKernelGGL((tb_ff_kernel<false, true>), grid, block, 0, h->side[slot], k); else hipLaunchKernelGGL((tb_ff_kernel<false, false>), grid, block, 0, h->side[slot], k); }
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipGetLastError());
   if (h->h_marks && h->marks_on) {  // progress marks: count this fast-forward as finished, in stream order behind it
-    hipLaunchKernelGGL(tb_mark_kernel, dim3(1), dim3(1), 0, h->side[slot], h->h_marks + TB_MAX_MARKS);
+    hipLaunchKernelGGL(tb_mark_kernel, dim3(1), dim3(1), 0, h->side[slot], h->h_marks + TB_MAX_MARKS + slot);
     HIP_TRY(hipGetLastError());
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     HIP_TRY(hipStreamIsCapturing(s, &st));
-    if (st == hipStreamCaptureStatusActive) h->ff_cap++; else h->ff_eager++;
+    if (st == hipStreamCaptureStatusActive) h->ff_cap[slot]++; else h->ff_eager[slot]++;
   }
   HIP_TRY(hipEventRecord(h->ev_ff[slot], h->side[slot]));
   h->ff_busy[slot] = 1; h->last_slot = slot; h->last_term = term; h->last_sub = substeps;
@@ -1084,29 +1176,30 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
     if (h->ff_busy[slot]) HIP_TRY(hipStreamWaitEvent(s, h->ev_ff[slot], 0));  // slot still in use by an older fast-forward
     a.defer = 1; a.ff_rec = h->d_ff_rec[slot];
   }
-  const bool rg = extended_contacts(h->kp);  // selects the instantiation that contains racket<->court contact and rolling friction
+  const bool rg = extended_contacts(h->kp);  // selects the instantiation that contains the rolling-friction rows
+  const size_t mani_lds = rg ? TB_MANI_LDS * sizeof(float) * block.x : 0;  // the racket<->court caches' LDS columns
   (void)hipGetLastError();  // the check below is about THIS launch, not about whatever another library left behind
 #define TB_LAUNCH_STEP(KIND, LEAN, MULTI)                                                                      \
   do {                                                                                                         \
-    if (pol) hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, false, false, true>), grid, block, 0, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);        \
-    else if (rg) hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, MULTI, true>), grid, block, 0, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);           \
-    else hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, MULTI, false>), grid, block, 0, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);                  \
+    if (pol) hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, false, false, true>), grid, block, mani_lds, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);        \
+    else if (rg) hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, MULTI, true>), grid, block, mani_lds, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);           \
+    else hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, MULTI, false>), grid, block, mani_lds, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);                  \
   } while (0)
   if (T > 1) {
     if (h->kind == TB_ENV_TENNIS) {
-      if (h->reg_rows && !pol && !rg) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, true, false, false, true>), grid, block, 0, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);
+      if (h->reg_rows && !pol && !rg) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, true, false, false, true>), grid, block, mani_lds, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);
       else TB_LAUNCH_STEP(TB_ENV_TENNIS, false, true);
     } else if (piped) {
       if (!may_park) a.ff_rec = nullptr;
       TB_LAUNCH_STEP(TB_ENV_SWING, true, true);
     } else TB_LAUNCH_STEP(TB_ENV_SWING, false, true);
   } else if (h->kind == TB_ENV_TENNIS) {
-    if (h->reg_rows && !rg && pol) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, false, false, true, true>), grid, block, 0, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);
-    else if (h->reg_rows && !rg) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, false, false, false, true>), grid, block, 0, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);
+    if (h->reg_rows && !rg && pol) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, false, false, true, true>), grid, block, mani_lds, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);
+    else if (h->reg_rows && !rg) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, false, false, false, true>), grid, block, mani_lds, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);
     else TB_LAUNCH_STEP(TB_ENV_TENNIS, false, false);
   } else if (piped && h->swing_reg_rows && !pol && !rg) {
     if (!may_park) a.ff_rec = nullptr;  // (see the comment of the next branch but one)
-    hipLaunchKernelGGL((tb_step_kernel<TB_ENV_SWING, true, false, false, false, true>), grid, block, 0, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);
+    hipLaunchKernelGGL((tb_step_kernel<TB_ENV_SWING, true, false, false, false, true>), grid, block, mani_lds, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);
   } else if (may_park) TB_LAUNCH_STEP(TB_ENV_SWING, true, false);
   else if (piped) {
     // phase known and not the 26th step: every env has step_count = phase < 25 (all were reset
@@ -1213,6 +1306,9 @@ int tb_create(const TbParams* params, const TbOptions* options, int env_kind, in
   CREATE_TRY(hipHostMalloc((void**)&h->h_hull, sizeof(float4) * TB_HULL_LDS, hipHostMallocDefault));
   CREATE_TRY(hipMalloc((void**)&h->d_counters, sizeof(unsigned long long) * TB_N_COUNTERS * TB_COUNTER_SHARDS));
   CREATE_TRY(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * TB_N_COUNTERS * TB_COUNTER_SHARDS, 0));
+  CREATE_TRY(hipMalloc((void**)&h->d_mani, sizeof(uint32_t) * (size_t)TB_MANI_WORDS * n_envs));
+  CREATE_TRY(hipMalloc((void**)&h->d_mflag, (size_t)n_envs));
+  CREATE_TRY(hipMemsetAsync(h->d_mflag, 0, (size_t)n_envs, 0));
   hipLaunchKernelGGL(tb_init_kernel, dim3((unsigned)((n_envs + 255) / 256)), dim3(256), 0, 0, h->d_words, h->d_done, n_envs, nw);
   CREATE_TRY(hipGetLastError());
   if (int rc = upload_hull(h, 0)) { tb_destroy(h); return rc; }
@@ -1231,6 +1327,8 @@ int tb_destroy(TbHandle* h) {
   if (h->d_hull) (void)hipFree(h->d_hull);
   if (h->h_hull) (void)hipHostFree(h->h_hull);
   if (h->d_counters) (void)hipFree(h->d_counters);
+  if (h->d_mani) (void)hipFree(h->d_mani);
+  if (h->d_mflag) (void)hipFree(h->d_mflag);
   for (int k = 0; k < TB_FF_SLOTS; ++k) {
     if (h->d_ff_rec[k]) (void)hipFree(h->d_ff_rec[k]);
     if (h->d_ff_sorted[k]) (void)hipFree(h->d_ff_sorted[k]);
@@ -1284,7 +1382,7 @@ int tb_pipeline_sync(TbHandle* h, int host_wait) {
   }
   h->last_slot = -1;
   if (host_wait) {
-    h->ff_cap = 0;
+    memset(h->ff_cap, 0, sizeof h->ff_cap);
     h->phase_at_capture = h->phase; h->phase_valid_at_capture = h->phase_valid;
   } else {  // the captured tb_step calls advanced the host's episode phase, but none of them ran: the replays will (tb_phase_advance)
     h->phase = h->phase_at_capture; h->phase_valid = h->phase_valid_at_capture;
@@ -1311,7 +1409,7 @@ int tb_pipeline_recover(TbHandle* h) {
     HIP_TRY(hipEventCreateWithFlags(&h->ev_ff[k], hipEventDisableTiming));
   }
   h->last_slot = -1; h->last_term = nullptr; h->last_sub = nullptr;
-  h->ff_cap = 0;  // nothing of the abandoned capture will ever run
+  memset(h->ff_cap, 0, sizeof h->ff_cap);  // nothing of the abandoned capture will ever run
   return TB_OK;
 }
 
@@ -1341,7 +1439,8 @@ int tb_mark_record(TbHandle* h, int k, void* stream) {
   HIP_TRY(hipStreamIsCapturing(s, &st));
   hipLaunchKernelGGL(tb_mark_kernel, dim3(1), dim3(1), 0, s, h->h_marks + k);
   HIP_TRY(hipGetLastError());
-  h->mark_ff_before[k] = st == hipStreamCaptureStatusActive ? h->ff_cap : -1 - h->ff_eager;
+  h->mark_in_capture[k] = st == hipStreamCaptureStatusActive;
+  for (int q = 0; q < TB_FF_SLOTS; ++q) h->mark_ff_before[k][q] = h->mark_in_capture[k] ? h->ff_cap[q] : h->ff_eager[q];
   return TB_OK;
 }
 
@@ -1355,9 +1454,9 @@ int tb_mark_enable(TbHandle* h, int on) {
 int tb_mark_begin(TbHandle* h) {
   if (!h) return fail(TB_E_INVAL, "tb_mark_begin: null handle");
   if (int rc = ensure_marks(h)) return rc;
-  h->snap_ff = __atomic_load_n(h->h_marks + TB_MAX_MARKS, __ATOMIC_ACQUIRE);
+  for (int q = 0; q < TB_FF_SLOTS; ++q) h->snap_ff[q] = __atomic_load_n(h->h_marks + TB_MAX_MARKS + q, __ATOMIC_ACQUIRE);
   for (int k = 0; k < TB_MAX_MARKS; ++k) h->snap_marks[k] = __atomic_load_n(h->h_marks + k, __ATOMIC_ACQUIRE);
-  h->ff_eager = 0;
+  memset(h->ff_eager, 0, sizeof h->ff_eager);
   return TB_OK;
 }
 
@@ -1371,13 +1470,15 @@ int tb_mark_host_wait(TbHandle* h, int k, int timeout_ms) {
   if (!h || k < 0 || k >= TB_MAX_MARKS || !h->h_marks) return fail(TB_E_INVAL, "tb_mark_host_wait: bad handle, mark index, or no mark recorded yet");
   // fired once more than at tb_mark_begin, and every fast-forward enqueued before the mark has finished: those of the
   // graph that holds it (counted at capture time) plus whatever was launched eagerly since (over-waiting at worst)
-  const long long before = h->mark_ff_before[k];
-  const unsigned long long ff_target = h->snap_ff + (unsigned long long)(before >= 0 ? before + h->ff_eager : -1 - before);
+  unsigned long long ff_target[TB_FF_SLOTS];
+  for (int q = 0; q < TB_FF_SLOTS; ++q)
+    ff_target[q] = h->snap_ff[q] + (unsigned long long)(h->mark_in_capture[k] ? h->mark_ff_before[k][q] + h->ff_eager[q] : h->mark_ff_before[k][q]);
   const unsigned long long count = h->snap_marks[k] + 1;
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned spins = 0;; ++spins) {
-    if (__atomic_load_n(h->h_marks + k, __ATOMIC_ACQUIRE) >= count && __atomic_load_n(h->h_marks + TB_MAX_MARKS, __ATOMIC_ACQUIRE) >= ff_target)
-      return TB_OK;
+    bool ok = __atomic_load_n(h->h_marks + k, __ATOMIC_ACQUIRE) >= count;
+    for (int q = 0; ok && q < TB_FF_SLOTS; ++q) ok = __atomic_load_n(h->h_marks + TB_MAX_MARKS + q, __ATOMIC_ACQUIRE) >= ff_target[q];
+    if (ok) return TB_OK;
     if ((spins & 1023u) == 1023u &&
         std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_ms)
       return fail(TB_E_TIMEOUT, "tb_mark_host_wait: the mark did not fire in time");
@@ -1553,6 +1654,7 @@ int tb_set_state(TbHandle* h, const uint32_t* words, const uint8_t* done, int on
   HIP_TRY(hipMemcpyAsync(h->d_words, words, wb, k, s));
   if (done) HIP_TRY(hipMemcpyAsync(h->d_done, done, (size_t)h->n, k, s));
   else HIP_TRY(hipMemsetAsync(h->d_done, 0, (size_t)h->n, s));
+  HIP_TRY(hipMemsetAsync(h->d_mflag, 0, (size_t)h->n, s));  // the racket<->court contact caches are not part of the state words
   if (h->kind == TB_ENV_SWING) {
     // the pipelined kernels need to know which launch ends the episodes: the injected envs are in lockstep again
     // when every one is running (done = 0) at the same step count s < 26 -- then the phase is s (e.g. a checkpoint

@@ -21,7 +21,7 @@ ENV_TENNIS = 1  # Tennisbot-v0,   tennisbot/__init__.py:3-6
 F_AUTO_RESET = 0x1
 F_NET = 0x2
 F_RACKET_BALL = 0x4
-F_RACKET_GROUND = 0x8  # opt-in racket<->court contact (row f3)
+F_RACKET_GROUND = 0x8  # racket<->court contact (row f3; court.urdf:19-24 collides with everything): opt-in, DESIGN.md section 3
 F_DEFAULT = F_NET | F_RACKET_BALL
 
 DONE_NO, DONE_PENDING_FORCE, DONE_YES = 0, 1, 2

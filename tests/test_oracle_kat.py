@@ -655,44 +655,61 @@ def test_contact_off_bench_mode_keeps_racket_dynamics():
 
 
 # ---------------------------------------------------------------- racket <-> court (row f3, opt-in)
-def test_racket_ground_manifold_selection():
-    p = default_params(flags=F_DEFAULT | F_RACKET_GROUND)
+RG_FLAGS = F_DEFAULT | F_RACKET_GROUND
+
+
+def test_racket_ground_support_query():
+    """one narrowphase query = ONE point, the deepest hull vertex (Bullet's convex-convex pair finds one point per frame and
+    lets the persistent manifold collect them): where it is, how far, and when there is none"""
+    p = default_params(flags=RG_FLAGS)
+    assert not default_params().flags & F_RACKET_GROUND
     hx, m, top = p.racket_half_thick, 0.001, 0.005
-    # upright racket (handle down): the handle end, 2 outline vertices x 2 faces, is the support
-    z = 0.5 + top + m + 0.002                       # COM 0.5 above the handle end; 2 mm gap
+    # upright racket (handle down), 2 mm above the court: a corner of the handle end
+    z = 0.5 + top + m + 0.002                       # COM 0.5 above the handle end
     pts = query_racket_ground(p, (8, 0, z), (0, 0, 0, 1))
-    assert len(pts) == 4
-    for d, rr in pts:
-        assert d == pytest.approx(0.002, abs=1e-6) and rr[2] == pytest.approx(-0.5 - m, abs=1e-6)
-        assert abs(rr[0]) == pytest.approx(hx, abs=1e-7) and abs(rr[1]) == pytest.approx(0.019010, abs=1e-5)
-    assert len({(round(rr[0], 4), round(rr[1], 4)) for _, rr in pts}) == 4     # four distinct corners
-    # too high: culled / no candidates
+    assert len(pts) == 1
+    d, rr = pts[0]
+    assert d == pytest.approx(0.002, abs=1e-6) and rr[2] == pytest.approx(-0.5 - m, abs=1e-6)
+    assert abs(rr[0]) == pytest.approx(hx, abs=1e-7) and abs(rr[1]) == pytest.approx(0.019010, abs=1e-5)
+    # tilted by 0.3 rad about x: the lower of the two handle corners, found by walking the outline downhill from vertex 0
+    q = (math.sin(0.15), 0, 0, math.cos(0.15))
+    (d, rr), = query_racket_ground(p, (8, 0, 0.49), q)
+    verts = p.hull_vertices()
+    heights = [math.cos(0.3) * vz + math.sin(0.3) * vy for vy, vz in verts]
+    vy, vz = verts[int(np.argmin(heights))]
+    assert rr[1] == pytest.approx(math.cos(0.3) * vy - math.sin(0.3) * vz, abs=1e-6) and d == pytest.approx(0.49 + min(heights) - m - top, abs=1e-6)
+    # too high: culled
     assert query_racket_ground(p, (8, 0, 0.5 + top + m + 0.02), (0, 0, 0, 1)) == []
-    # lying flat on its -x face (rotate +90 deg about y: local -x -> world -z): a spread-out support quad
+    # lying flat on its -x face (rotate +90 deg about y: local -x -> world -z), 1 mm into the ground: a vertex of that face
     q = (0, math.sin(math.pi / 4), 0, math.cos(math.pi / 4))
-    pts = query_racket_ground(p, (8, 0, hx + top + m - 0.001), q)
-    assert len(pts) == 4 and all(d == pytest.approx(-0.001, abs=2e-6) for d, _ in pts)
-    arms = np.array([rr for _, rr in pts])
-    assert np.ptp(arms[:, 0]) > 0.5 and np.ptp(arms[:, 1]) > 0.25              # spans handle..head and the head's width
-    # beyond the court's edge there is nothing to stand on
+    (d, rr), = query_racket_ground(p, (8, 0, hx + top + m - 0.001), q)
+    assert d == pytest.approx(-0.001, abs=2e-6) and rr[2] == pytest.approx(-hx - m, abs=1e-6)
+    # deep in the ground (a tumbling racket's tip moves 3 cm per substep, the ground box is 1 cm thick): still a contact ...
+    (d, rr), = query_racket_ground(p, (8, 0, 0.5 + top + m - 0.04), (0, 0, 0, 1))
+    assert d == pytest.approx(-0.04, abs=2e-6)
+    # ... unless the racket's COM is below the court, or it is beyond the court's edge
+    assert query_racket_ground(p, (8, 0, -0.2), q) == []
     assert query_racket_ground(p, (14.5, 0, z), (0, 0, 0, 1)) == []
     # scaled racket: the handle end is 2.3 x 0.5 below the COM
-    p3 = default_params(racket_scale=2.3, flags=F_DEFAULT | F_RACKET_GROUND)
-    pts = query_racket_ground(p3, (8, 0, 2.3 * 0.5 + top + m + 0.001), (0, 0, 0, 1))
-    assert len(pts) == 4 and all(d == pytest.approx(0.001, abs=2e-6) for d, _ in pts)
+    p3 = default_params(racket_scale=2.3, flags=RG_FLAGS)
+    (d, rr), = query_racket_ground(p3, (8, 0, 2.3 * 0.5 + top + m + 0.001), (0, 0, 0, 1))
+    assert d == pytest.approx(0.001, abs=2e-6)
 
 
-def test_racket_ground_contact_dynamics():
-    """dropped upright racket: bounces (restitution .9*.9) on the first impact, never tunnels, comes to rest
-    on the ground; with the flag off it falls through (the reference's court would stop it)"""
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_racket_ground_contact_dynamics(prec):
+    """dropped upright racket: bounces (restitution .9*.9) on the first impact, tumbles, never tunnels -- its tip moves
+    faster than the ground box is thick -- and comes to rest lying on a face, on a persistent manifold of four points that
+    spans the face, whose warm-started impulses carry exactly its weight; with the flag off it falls through the court"""
     FARB = (0.0, 3.0, 50.0)
-    for flag, lands in ((F_DEFAULT | F_RACKET_GROUND, True), (F_DEFAULT, False)):
-        b = OracleBatch(default_params(flags=flag, lin_damp=0.0, ang_damp=0.0), ENV_SWING, 1, precision="f64")
+    for flag, lands in ((RG_FLAGS, True), (F_DEFAULT, False)):
+        p = default_params(flags=flag, lin_damp=0.0, ang_damp=0.0)
+        b = OracleBatch(p, ENV_SWING, 1, precision=prec)
         w, d = make_words(ENV_SWING, 1, racket_pos=(8, 0, 0.9), ball_pos=FARB, goal=(-6, 0), spawn_pos=(8, 0, 0.4), init_dist=10.0, step_count=30, done=2)
         b.set_state_words(w, d)
-        zmin, vz_prev, bounce = 1e9, 0.0, None
+        zmin, vz_prev, bounce, most = 1e9, 0.0, None, 0
         a = np.array([[0, 0, -0.0981, 0, 0, 0]], np.float32)   # cancels the hover force: free fall
-        for t in range(400):
+        for t in range(900 if lands else 300):
             b.step(a)
             s = b.get_state()
             vz = s["racket_vel"][0, 2]
@@ -700,17 +717,54 @@ def test_racket_ground_contact_dynamics():
                 bounce = (vz_prev, vz)
             vz_prev = vz
             zmin = min(zmin, s["racket_pos"][0, 2])
+            most = max(most, len(b.manifold()[0]))
         if lands:
             # rebound = e |v| minus the speculative allowance d/dt of a contact caught up to 1 cm early
             assert bounce is not None and 0.0 < bounce[1] <= -0.81 * bounce[0] + 1e-9
             assert bounce[1] >= -0.81 * bounce[0] - 0.0101 * 240
-            # it settles on the handle end (COM ~0.506), then -- an inverted pendulum on a 4 x 3 cm base --
-            # tips over and ends up lying on a face; at no time does the COM sink below what a racket
-            # lying flat allows (half thickness + ground top), i.e. nothing tunnels
+            # at no time does the COM sink below what a racket lying flat allows (half thickness + ground top): nothing tunnels
             assert zmin > 0.0145 + 0.005 - 0.01
             assert np.isfinite(s["racket_quat"]).all() and abs(np.linalg.norm(s["racket_quat"][0]) - 1) < 1e-6
+            # at rest, flat: COM at half thickness + margin + ground top, on four vertices of the lower face
+            assert s["racket_pos"][0, 2] == pytest.approx(0.0145 + 0.001 + 0.005, abs=2e-4) and abs(s["racket_vel"][0, 2]) < 1e-3
+            ids, imp = b.manifold()
+            assert len(ids) == 4 and len(set(ids % 2)) == 1 and most == 4
+            assert imp[:, 0].sum() == pytest.approx(4.0 * 9.81 * DT, rel=2e-3) and np.all(imp[:, 0] >= 0)
+            verts = p.hull_vertices()[ids // 2]
+            assert np.ptp(verts[:, 1]) > 0.4 and np.ptp(verts[:, 0]) > 0.15   # spans handle .. head and the head's width
+            assert np.all(np.abs(imp[:, 1:]) <= 0.04 * imp[:, :1] + 1e-12)     # friction boxed by mu * normal impulse
         else:
             assert zmin < -1.0
+
+
+def test_racket_ground_cache_is_warm_and_not_part_of_the_state_words():
+    """the contact cache makes a resting racket cheap (the solve starts from the last impulses: the counter of solver sweeps
+    is not exposed, so the check is on what warm starting guarantees -- impulses that do not change from substep to substep)
+    and it is deliberately NOT in the state words: a restored state starts with an empty cache and rebuilds it"""
+    FARB = (0.0, 3.0, 50.0)
+    p = default_params(flags=RG_FLAGS, lin_damp=0.0, ang_damp=0.0)
+    b = OracleBatch(p, ENV_SWING, 1, precision="f32")
+    q = (0, math.sin(math.pi / 4), 0, math.cos(math.pi / 4))
+    w, d = make_words(ENV_SWING, 1, racket_pos=(8, 0, 0.0145 + 0.006 + 0.01), racket_quat=q, ball_pos=FARB, goal=(-6, 0), spawn_pos=(8, 0, 0.4), init_dist=10.0, step_count=30, done=2)
+    b.set_state_words(w, d)
+    a = np.array([[0, 0, -0.0981, 0, 0, 0]], np.float32)
+    for t in range(400):
+        b.step(a)
+    ids0, imp0 = b.manifold()
+    b.step(a)
+    ids1, imp1 = b.manifold()
+    # (a redundant four-point manifold keeps shifting a little load between its points; the total is the racket's weight)
+    assert len(ids0) >= 3 and np.array_equal(ids0, ids1) and np.allclose(imp0, imp1, rtol=5e-3, atol=2e-4)
+    assert imp1[:, 0].sum() == pytest.approx(4.0 * 9.81 * DT, rel=1e-3)
+    w2, d2 = b.get_state_words()
+    b2 = OracleBatch(p, ENV_SWING, 1, precision="f32")
+    b2.set_state_words(w2, d2)
+    assert len(b2.manifold()[0]) == 0
+    for t in range(60):
+        b.step(a); b2.step(a)
+    s, s2 = b.get_state(), b2.get_state()
+    assert len(b2.manifold()[0]) >= 3
+    assert np.allclose(s["racket_pos"], s2["racket_pos"], atol=2e-3) and abs(s2["racket_vel"][0, 2]) < 5e-3
 
 
 @pytest.mark.parametrize("scale", [1.0, 2.0, 3.0])

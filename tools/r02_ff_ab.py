@@ -45,29 +45,25 @@ def measure(n, T, opts, reps=5, flags=None):
 
 
 def main():
+    """usage: r02_ff_ab.py <small|large|all> [old] [norg]   old = build tools/diag/old_csrc (the library before racket<->court
+    contact became default) into /tmp and measure that; norg = clear TB_F_RACKET_GROUND"""
+    from tennisbot_rl_amd.params import F_NET, F_RACKET_BALL, F_DEFAULT
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
-    if len(sys.argv) > 2:  # extra hipcc flags: build that variant of the library into /tmp and measure it instead (same-box A/B)
+    flags = (F_NET | F_RACKET_BALL) if ("norg" in sys.argv or "old" in sys.argv) else F_DEFAULT
+    if "old" in sys.argv:
         import subprocess
         from tennisbot_rl_amd import stepper
-        from tennisbot_rl_amd.build import HIPCC_FLAGS, SOURCES, hipcc
-        lib = "/tmp/libtb_variant.so"
-        subprocess.check_call([hipcc()] + HIPCC_FLAGS + sys.argv[2:] + ["-o", lib] + SOURCES)
+        from tennisbot_rl_amd.build import HIPCC_FLAGS, hipcc
+        lib = "/tmp/libtb_old.so"
+        subprocess.check_call([hipcc()] + HIPCC_FLAGS + ["-o", lib, os.path.join(ROOT, "tools", "diag", "old_csrc", "tennisbot_rl_amd", "csrc", "tb_stepper.hip")])
         stepper.use_library(lib)
-        print("variant", sys.argv[2:], flush=True)
+    print("variant", sys.argv[2:], "flags", hex(flags), flush=True)
     out = []
     if which in ("all", "small"):
-        for o in (dict(ff_phases=1), dict(ff_phases=3)):
-            out.append(measure(4096, 1040, o))
-            print(json.dumps(out[-1]), flush=True)
-        for o in (dict(ff_phases=1), dict(ff_phases=3)):
-            out.append(measure(32768, 520, o))
-            print(json.dumps(out[-1]), flush=True)
+        out.append(measure(4096, 1040, {}, flags=flags)); print(json.dumps(out[-1]), flush=True)
+        out.append(measure(32768, 520, {}, flags=flags)); print(json.dumps(out[-1]), flush=True)
     if which in ("all", "large"):
-        for n in (262144, 1048576):
-            for o in (dict(ff_phases=1), dict(ff_phases=3)):
-                out.append(measure(n, 104, o, reps=3))
-                print(json.dumps(out[-1]), flush=True)
-    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r02_ff_ab_%s.json" % which), "w"), indent=1)
+        out.append(measure(1048576, 104, {}, reps=3, flags=flags)); print(json.dumps(out[-1]), flush=True)
 
 
 if __name__ == "__main__":
