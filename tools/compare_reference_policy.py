@@ -20,18 +20,19 @@ def bullet_recomputed_inertia():
     return bullet_shape_inertia()
 
 
-def rollout_rewards(num_envs=4096, episodes=4, seed=0, **overrides):
+def rollout_rewards(num_envs=4096, episodes=4, seed=0, racket_ground=False, **overrides):
     import torch
-    from tennisbot_rl_amd.params import ENV_SWING, default_params
+    from tennisbot_rl_amd.params import ENV_SWING, F_DEFAULT, F_RACKET_GROUND, default_params
     from tennisbot_rl_amd.ppo import build_actor_critic, pack_policy
     from tennisbot_rl_amd.stepper import BatchedEnv
     policy = build_actor_critic(6, 6, (32, 64, 32)).to("cuda:0")
     policy.load_sb3_arrays(dict(np.load(os.path.join(ROOT, "tests", "golden", "ppo_swing_policy.npz"))))
     blob = pack_policy(policy)
-    env = BatchedEnv(ENV_SWING, num_envs, device="cuda:0", seed=seed, pipeline=True, track_terminal_obs=False, params=default_params(**overrides))
+    flags = F_DEFAULT | (F_RACKET_GROUND if racket_ground else 0)
+    env = BatchedEnv(ENV_SWING, num_envs, device="cuda:0", seed=seed, pipeline=True, track_terminal_obs=False, params=default_params(flags=flags, **overrides))
     obs = env.reset()
     # the fused policy kernels are built without the extended contact set: roll the torch module out instead
-    fused = not any(k.startswith("roll_") and v > 0 for k, v in overrides.items())
+    fused = not racket_ground and not any(k.startswith("roll_") and v > 0 for k, v in overrides.items())
     torch.manual_seed(seed + 17)
     out = []
     for ep in range(episodes):
@@ -95,6 +96,8 @@ def main():
                 "ball recomputed, racket as in the URDF": dict(racket_inertia=(0.04, 0.08, 0.12), ball_inertia=bullet_recomputed_inertia()["ball_inertia"])}
     if len(sys.argv) > 1 and sys.argv[1] == "--default-only":
         variants = {"default parameters": {}}
+    if len(sys.argv) > 1 and sys.argv[1] == "--racket-ground":
+        variants = {"default parameters (racket falls through the court)": {}, "racket<->court contact on": dict(racket_ground=True)}
     if len(sys.argv) > 1 and sys.argv[1] == "--rolling":
         from tennisbot_rl_amd.params import reference_rolling_friction
         variants = {"default parameters": {}, "rolling-friction rows on": reference_rolling_friction(),

@@ -49,7 +49,8 @@ def main():
     contact became default) into /tmp and measure that; norg = clear TB_F_RACKET_GROUND"""
     from tennisbot_rl_amd.params import F_NET, F_RACKET_BALL, F_DEFAULT
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
-    flags = (F_NET | F_RACKET_BALL) if ("norg" in sys.argv or "old" in sys.argv) else F_DEFAULT
+    from tennisbot_rl_amd.params import F_RACKET_GROUND
+    flags = F_DEFAULT | (F_RACKET_GROUND if "rg" in sys.argv else 0)
     if "old" in sys.argv:
         import subprocess
         from tennisbot_rl_amd import stepper
@@ -60,10 +61,11 @@ def main():
     print("variant", sys.argv[2:], "flags", hex(flags), flush=True)
     out = []
     if which in ("all", "small"):
-        out.append(measure(4096, 1040, {}, flags=flags)); print(json.dumps(out[-1]), flush=True)
-        out.append(measure(32768, 520, {}, flags=flags)); print(json.dumps(out[-1]), flush=True)
+        for o in ({}, dict(ff_phases=3)):
+            out.append(measure(4096, 1040, o, flags=flags)); print(json.dumps(out[-1]), flush=True)
     if which in ("all", "large"):
-        out.append(measure(1048576, 104, {}, reps=3, flags=flags)); print(json.dumps(out[-1]), flush=True)
+        for o in (dict(ff_phases=1), dict(ff_phases=3)):
+            out.append(measure(1048576, 104, o, reps=3, flags=flags)); print(json.dumps(out[-1]), flush=True)
 
 
 if __name__ == "__main__":
