@@ -9,7 +9,7 @@ import socket
 import numpy as np
 import pytest
 
-N_LOCAL, T, WORLD = 24, 30, 2
+N_LOCAL, T, WORLD = 24, 32, 2
 
 
 def _free_port():
@@ -48,12 +48,19 @@ def _worker(rank, port, kind, out_dir):
     shards = buf.all_gather()
     assert len(shards) == WORLD
     obs, act, rew, done = buf.concatenated(shards)
-    # the chunked / overlapped variant moves the same bytes
-    buf.begin_gather(3)
-    for c in range(3):
-        buf.gather_chunk(c)
-    chunked = buf.concatenated(buf.concatenated_chunks(buf.finish_gather()))
-    assert all(torch.equal(a, b) for a, b in zip(chunked, (obs, act, rew, done)))
+    assert buf.check_gathered()
+    # the default exchange of bench.py -- 8 step-chunks, each all-gathered as soon as it is final -- moves the same bytes: chunk c of
+    # rank r lands at [r * chunk bytes, (r + 1) * chunk bytes) of chunk c's gather buffer, whatever order the chunks are issued in
+    for order in (range(8), (3, 0, 7, 1, 6, 2, 5, 4)):
+        buf.begin_gather(8)
+        for c in order:
+            buf.gather_chunk(c)
+        shards8 = buf.finish_gather()
+        assert buf.check_gathered() and len(shards8) == WORLD and all(len(parts) == 8 for parts in shards8)
+        chunked = buf.concatenated(buf.concatenated_chunks(shards8))
+        assert all(torch.equal(a, b) for a, b in zip(chunked, (obs, act, rew, done)))
+    with pytest.raises(ValueError):
+        buf.begin_gather(5)   # 32 steps do not cut into 5 chunks
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), obs=obs.numpy(), act=act.numpy(), rew=rew.numpy(), done=done.numpy())
     dist.barrier()
     dist.destroy_process_group()

@@ -45,15 +45,19 @@ def main(d, out):
                 "launches": nf[n], "FETCH_SIZE_KiB_raw": f[n], "WRITE_SIZE_KiB_raw": w[n],
                 "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "traffic_bytes_per_launch": fb + wb,
                 "traffic_bytes_per_env_step": (fb + wb) / n, "algorithmic_bytes_per_env_step": 267 if env == "swing" else 263}
-        # pipelined runs: the fast-forward is its own kernel (one launch per 26 agent steps)
+        # pipelined runs: the fast-forward is its own kernel chain (per 26 agent steps: one launch over all parked envs and, from
+        # 512 K envs on, two launches over the compacted survivors of the budgeted phases, on a smaller fixed grid)
         ff, nff = per_kernel(os.path.join(d, "%s_FETCH_SIZE_counter_collection.csv" % tag), "FETCH_SIZE", "tb_ff_kernel")
         fw, _ = per_kernel(os.path.join(d, "%s_WRITE_SIZE_counter_collection.csv" % tag), "WRITE_SIZE", "tb_ff_kernel")
-        for n in ff:
-            fb, wb = ff[n] * 1024.0 / fetch_ratio, fw[n] * 1024.0 / write_ratio
+        for n in f:
+            if n not in ff:
+                continue
+            fb = sum(ff[g] * nff[g] for g in ff) / nff[n] * 1024.0 / fetch_ratio   # all phase kernels, per episode end
+            wb = sum(fw[g] * nff[g] for g in fw) / nff[n] * 1024.0 / write_ratio
             res["workloads"]["%s_%d" % (env, n)]["ff_kernel"] = {
-                "launches": nff[n], "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
-                "traffic_bytes_per_env_per_launch": (fb + wb) / n,
-                "note": "one tb_ff_kernel launch per 26 tb_step_kernel launches; reads the parked state (121 B/env), writes reward (4 B/env)"}
+                "launches": {str(g): nff[g] for g in nff}, "fetch_bytes_per_episode_end": fb, "write_bytes_per_episode_end": wb,
+                "traffic_bytes_per_env_per_episode_end": (fb + wb) / n, "algorithmic_bytes_per_env_per_episode_end": 200,
+                "note": "per episode end (26 tb_step_kernel launches): reads each parked env's 192-byte record (state + racket<->court cache), writes its reward and clears its parked flag (4 + 4 B); survivors of a budgeted phase are written and read once more (192 B each way, ~10 % of the envs)"}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
