@@ -319,6 +319,26 @@ struct RowS {  // ball vs static shape
   vec3 n, t1, t2;
   float mu, target, jn, jt1, jt2;
 };
+// a static row in its lane's LDS column (word w of row i at st[(14 i + w) * stride])
+template <typename MANI> TB_DEV RowS load_row(const MANI& M, int i) {
+  const float* p = M.st + 14 * i * M.stride;
+  const int s = M.stride;
+  RowS c;
+  c.n = mk(p[0], p[s], p[2 * s]); c.t1 = mk(p[3 * s], p[4 * s], p[5 * s]); c.t2 = mk(p[6 * s], p[7 * s], p[8 * s]);
+  c.mu = p[9 * s]; c.target = p[10 * s]; c.jn = p[11 * s]; c.jt1 = p[12 * s]; c.jt2 = p[13 * s];
+  return c;
+}
+template <typename MANI> TB_DEV void store_row(const MANI& M, int i, const RowS& c) {
+  float* p = M.st + 14 * i * M.stride;
+  const int s = M.stride;
+  p[0] = c.n.x; p[s] = c.n.y; p[2 * s] = c.n.z; p[3 * s] = c.t1.x; p[4 * s] = c.t1.y; p[5 * s] = c.t1.z; p[6 * s] = c.t2.x; p[7 * s] = c.t2.y; p[8 * s] = c.t2.z;
+  p[9 * s] = c.mu; p[10 * s] = c.target; p[11 * s] = c.jn; p[12 * s] = c.jt1; p[13 * s] = c.jt2;
+}
+template <typename MANI> TB_DEV void store_row_impulses(const MANI& M, int i, const RowS& c) {
+  float* p = M.st + 14 * i * M.stride;
+  const int s = M.stride;
+  p[11 * s] = c.jn; p[12 * s] = c.jt1; p[13 * s] = c.jt2;
+}
 struct RowR {  // ball vs racket
   vec3 n, t1, t2, rr;
   vec3 an, at1, at2;  // I_w^-1 (rr x n), I_w^-1 (rr x t1), I_w^-1 (rr x t2)
@@ -519,7 +539,11 @@ struct Manifold {
   int n, deep;     // cached points; outline vertex the last support walk ended at
   float* m;        // this lane's column of the workgroup's LDS scratchpad
   int stride;      // lanes per workgroup
+  float* st;       // (rides along: this lane's column for the three static contact rows of the instantiations that do not keep
+                   //  them in registers, TB_ROWS_LDS words -- LDS for the reason given above: as scratch they were 292 B per lane
+                   //  and made the fast-forward kernel move 3 x its algorithmic bytes)
 };
+constexpr int TB_ROWS_LDS = 14 * 3;  // words per lane
 TB_DEV float& mw(const Manifold& M, int j, int w) { return M.m[(12 * j + w) * M.stride]; }
 TB_DEV vec3 hull_vertex(const KParams& P, const float4* hull, int k, float s) {
   float hx = P.racket_half_thick * s;
@@ -702,8 +726,8 @@ TB_DEV bool friction_ground(const KParams& P, const Manifold& M, int j, const Sy
 // The default kernels carry neither: measured with both compiled in but switched off, the step kernels lost 3.5 % at 4096
 // envs and SwingRacket 18 % at 1 M (195 instead of 166 VGPRs in the fast-forward loop: a wave per SIMD less).
 template <bool RG> struct Rows;
-template <> struct Rows<false> { RowR rk; RowS st[3]; bool on[4]; };
-template <> struct Rows<true> { RowR rk; RowS st[3]; bool on[4]; RollR qrk; RollS qst[3]; };
+template <> struct Rows<false> { RowR rk; RowS st[3]; int on; };  // on: bit k = row k is active (a dynamically indexed bool array would put the whole struct in scratch)
+template <> struct Rows<true> { RowR rk; RowS st[3]; int on; RollR qrk; RollS qst[3]; };
 
 // REGROWS: the three static rows statically indexed too, i.e. in registers (~40 VGPRs more): the right
 // trade where balls bounce on the court all the time -- Tennisbot at every batch size (+8 ... +28 % in
@@ -719,35 +743,38 @@ TB_DEV void solve_contacts(const KParams& P, Rows<RG>& R, const Manifold& M, int
   }
   for (int it = 0; it < P.solver_iters; ++it) {
     bool moved = false;
-    if (R.on[0]) moved |= normal_racket(P, R.rk, rk, b, jref);
+    if ((R.on & 1)) moved |= normal_racket(P, R.rk, rk, b, jref);
     if constexpr (REGROWS) {
 #pragma unroll
       for (int i = 0; i < 3; ++i)
-        if (R.on[i + 1]) moved |= normal_static(P, R.st[i], b, jref);
+        if (((R.on >> (i + 1)) & 1)) moved |= normal_static(P, R.st[i], b, jref);
     } else {
 #pragma unroll 1
       for (int i = 0; i < 3; ++i)
-        if (R.on[i + 1]) moved |= normal_static(P, R.st[i], b, jref);
+        if (((R.on >> (i + 1)) & 1)) { RowS c = load_row(M, i); moved |= normal_static(P, c, b, jref); store_row_impulses(M, i, c); }
     }
     if constexpr (RG) {
 #pragma unroll 1
       for (int j = 0; j < nrg; ++j) moved |= normal_ground(P, M, j, W, rk, jref);
     }
     if constexpr (RG) {  // rolling rows: after the normals, before sliding friction
-      if (R.on[0]) moved |= rolling_racket(P, R.rk, R.qrk, rk, b, jref);
+      if ((R.on & 1)) moved |= rolling_racket(P, R.rk, R.qrk, rk, b, jref);
 #pragma unroll 1
       for (int i = 0; i < 3; ++i)
-        if (R.on[i + 1]) moved |= rolling_static(P, R.st[i], R.qst[i], b, jref);
+        if (((R.on >> (i + 1)) & 1)) {
+          if constexpr (REGROWS) moved |= rolling_static(P, R.st[i], R.qst[i], b, jref);
+          else { RowS c = load_row(M, i); moved |= rolling_static(P, c, R.qst[i], b, jref); }
+        }
     }
-    if (R.on[0]) moved |= friction_racket(P, R.rk, rk, b, jref);
+    if ((R.on & 1)) moved |= friction_racket(P, R.rk, rk, b, jref);
     if constexpr (REGROWS) {
 #pragma unroll
       for (int i = 0; i < 3; ++i)
-        if (R.on[i + 1]) moved |= friction_static(P, R.st[i], b, jref);
+        if (((R.on >> (i + 1)) & 1)) moved |= friction_static(P, R.st[i], b, jref);
     } else {
 #pragma unroll 1
       for (int i = 0; i < 3; ++i)
-        if (R.on[i + 1]) moved |= friction_static(P, R.st[i], b, jref);
+        if (((R.on >> (i + 1)) & 1)) { RowS c = load_row(M, i); moved |= friction_static(P, c, b, jref); store_row_impulses(M, i, c); }
     }
     if constexpr (RG) {
 #pragma unroll 1
@@ -906,16 +933,23 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
           for (int j = 0; j < nrg; ++j) setup_ground_row(PC, M, j, W, rk);
         }
       }
-      R.on[0] = bits & CT_RACKET; R.on[1] = bits & CT_GROUND; R.on[2] = bits & CT_NET; R.on[3] = bits & CT_GOAL;
-      if (R.on[0]) setup_racket<KIND == TB_ENV_TENNIS>(PC, R.rk, hr, rk, b, scale);
-      if (R.on[1]) setup_static(PC, R.st[0], hg, PC.rest_court, PC.fric_court, b);
-      if (R.on[2]) setup_static(PC, R.st[1], hn, PC.rest_court, PC.fric_court, b);
-      if (R.on[3]) setup_static(PC, R.st[2], hc, PC.rest_goal, PC.fric_goal, b);
+      R.on = bits & (CT_RACKET | CT_GROUND | CT_NET | CT_GOAL);  // CT_* = 1 << row
+      if ((R.on & 1)) setup_racket<KIND == TB_ENV_TENNIS>(PC, R.rk, hr, rk, b, scale);
+      if constexpr (REGROWS) {
+        if ((R.on & 2)) setup_static(PC, R.st[0], hg, PC.rest_court, PC.fric_court, b);
+        if ((R.on & 4)) setup_static(PC, R.st[1], hn, PC.rest_court, PC.fric_court, b);
+        if ((R.on & 8)) setup_static(PC, R.st[2], hc, PC.rest_goal, PC.fric_goal, b);
+      } else {  // the rows go to the lane's LDS column, one at a time through registers
+        RowS c;
+        if ((R.on & 2)) { setup_static(PC, c, hg, PC.rest_court, PC.fric_court, b); store_row(M, 0, c); }
+        if ((R.on & 4)) { setup_static(PC, c, hn, PC.rest_court, PC.fric_court, b); store_row(M, 1, c); }
+        if ((R.on & 8)) { setup_static(PC, c, hc, PC.rest_goal, PC.fric_goal, b); store_row(M, 2, c); }
+      }
       if constexpr (RG) {
-        if (R.on[0]) setup_roll_racket<KIND == TB_ENV_TENNIS>(PC, R.qrk, R.rk, rk, scale);
-        if (R.on[1]) setup_roll_static(PC, R.qst[0], PC.roll_court);
-        if (R.on[2]) setup_roll_static(PC, R.qst[1], PC.roll_court);
-        if (R.on[3]) setup_roll_static(PC, R.qst[2], PC.roll_goal);
+        if ((R.on & 1)) setup_roll_racket<KIND == TB_ENV_TENNIS>(PC, R.qrk, R.rk, rk, scale);
+        if ((R.on & 2)) setup_roll_static(PC, R.qst[0], PC.roll_court);
+        if ((R.on & 4)) setup_roll_static(PC, R.qst[1], PC.roll_court);
+        if ((R.on & 8)) setup_roll_static(PC, R.qst[2], PC.roll_goal);
       }
       solve_contacts<RG, REGROWS>(PC, R, M, nrg, W, rk, b);
     }

@@ -49,7 +49,8 @@ struct KArgs {
   int n, T;
   // pipelined fast-forward (tb_set_pipeline): a step that starts a SwingRacket fast-forward parks
   // the env's pre-loop state in a slot and resets the env; tb_ff_kernel finishes it on a side stream
-  float4* ff_rec;         // [n][TB_FF_REC] slot: one 128-byte record per env (park_env), word 30 = 1 while parked
+  float4* ff_rec;         // [n][TB_FF_REC] slot: one record per env (park_env)
+  uint8_t* ff_flag;       // [n] 1 = env i is parked in the slot (null for the compacted / sorted lists: their records' own tag says so)
   int ff_lanes;           // tb_ff_kernel: parked envs per wave (a few per wave at small batch sizes)
   float4* ff_next;        // tb_ff_kernel: where envs still running when their budget is spent are compacted to (null = last phase: no budget)
   int* ff_next_count;     // ... and how many there are so far
@@ -123,9 +124,14 @@ TB_DEV void store_env(uint32_t* w, uint8_t* done_state, int n, int i, const EnvR
 // restored state starts with an empty cache, like the oracle's). One flag byte per env is read by every launch; the 14 words
 // behind it only by lanes that have cached points -- a racket on the ground.
 #define TB_MANI_WORDS 14
-// every kernel that steps envs gets TB_MANI_LDS words of dynamic LDS per thread for the caches (tb_device.hpp, Manifold)
+// dynamic LDS of every kernel that steps envs, one column per lane: [TB_ROWS_LDS words: the static contact rows, unless the
+// instantiation keeps them in registers (REGROWS)] [TB_MANI_LDS words: the racket<->court cache, RG instantiations only]
 extern __shared__ float s_mani[];
-TB_DEV void init_manifold(Manifold& M, int lane_in_block, int lanes) { M.n = 0; M.deep = 0; M.m = s_mani + lane_in_block; M.stride = lanes; }
+TB_DEV void init_manifold(Manifold& M, int lane_in_block, int lanes, bool rows_in_lds) {
+  M.n = 0; M.deep = 0; M.stride = lanes;
+  M.st = s_mani + lane_in_block;
+  M.m = s_mani + (rows_in_lds ? TB_ROWS_LDS * lanes : 0) + lane_in_block;
+}
 TB_DEV void load_manifold(const KArgs& A, int i, Manifold& M) {
   const uint32_t w0 = A.mani[i], w1 = A.mani[(size_t)A.n + i];
   M.n = (int)(w0 & 255u); M.deep = (int)(w0 >> 8);
@@ -487,7 +493,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
     if (!POLICY) load_actions<KIND>(w_actions, (size_t)i, a);
   }
   Manifold M;
-  init_manifold(M, POLICY ? (int)(threadIdx.x & 63) : (int)threadIdx.x, POLICY ? 64 : (int)blockDim.x);
+  init_manifold(M, POLICY ? (int)(threadIdx.x & 63) : (int)threadIdx.x, POLICY ? 64 : (int)blockDim.x, !REGROWS);
   bool had_contacts = false;
   if constexpr (RG) {
     if (live && !(POLICY && threadIdx.x >= 64)) { had_contacts = A.mflag[i] != 0; if (had_contacts) load_manifold(A, i, M); }
@@ -546,6 +552,8 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
           // later by tb_ff_kernel from the parked state. The env itself restarts immediately.
           if (A.ff_rec) {
             park_env(A.ff_rec, i, e, M);
+            A.ff_flag[i] = 1;  // (a byte array of its own: cleared by the fast-forward with one coalesced store per wave, where a 4-byte
+                               //  store into each 192-byte record cost a 64-byte memory write per env)
           } else {
             cnt[8]++;  // lockstep invariant broken (see launch_step): reported, never silent
           }
@@ -650,7 +658,7 @@ __global__ void __launch_bounds__(320) tb_policy_rollout_kernel(KArgs A) {
   EnvRegs e;
   if (live) load_env<KIND>(A.words, A.done_state, A.n, i, e);
   Manifold M;
-  init_manifold(M, lane, 64);  // (never touched: this kernel is not instantiated with the extended contact set)
+  init_manifold(M, lane, 64, KIND == TB_ENV_SWING);  // (the cache part is never touched: no extended contact set in this kernel)
   uint32_t cnt[TB_N_COUNTERS];
 #pragma unroll
   for (int k = 0; k < TB_N_COUNTERS; ++k) cnt[k] = 0u;
@@ -681,6 +689,7 @@ __global__ void __launch_bounds__(320) tb_policy_rollout_kernel(KArgs A) {
         if (parked) {
           if (A.ff_rec) {
             park_env(A.ff_rec, i, e, M);
+            A.ff_flag[i] = 1;
           } else {
             cnt[8]++;  // lockstep invariant broken (see launch_policy_rollout): reported, never silent
           }
@@ -747,8 +756,10 @@ __global__ void __launch_bounds__(TB_FF_SORT_BLOCK) tb_ff_sort_kernel(KArgs A, f
     float4* g = A.ff_rec + (size_t)src * TB_FF_REC;
 #pragma unroll
     for (int k = 0; k < TB_FF_REC; ++k) r[k] = g[k];
-    if (__float_as_uint(r[7].z) == 1u) {
-      reinterpret_cast<uint32_t*>(g + 7)[2] = 0u;  // the copy in `sorted` is the parked one from here on
+    const bool parked = A.ff_flag[src] != 0;
+    r[7].z = __uint_as_float(parked ? 1u : 0u);  // in `sorted` the record's own tag says whether it is parked
+    if (parked) {
+      A.ff_flag[src] = 0;  // the copy in `sorted` is the parked one from here on
       const int it = predict_flight(A.P, mk(r[3].y, r[3].z, r[3].w), mk(r[4].x, r[4].y, r[4].z));
       key = it < 254 ? it : 254;
     }
@@ -808,12 +819,12 @@ __global__ void __launch_bounds__(64) tb_ff_kernel(KArgs A) {
       const float4* g = A.ff_rec + (size_t)src * TB_FF_REC;
 #pragma unroll
       for (int k = 0; k < TB_FF_REC; ++k) r[k] = g[k];
-      live = (__float_as_uint(r[7].z) & 255u) != 0u;
+      live = A.ff_flag ? A.ff_flag[src] != 0 : (__float_as_uint(r[7].z) & 255u) != 0u;
     }
     bool unfinished = false;
     EnvRegs e;
     Manifold M;
-    init_manifold(M, lane, 64);
+    init_manifold(M, lane, 64, true);
     int i = 0, ns = 1;  // fresh from the step kernel: it ran the first substep of this agent step
     if (live) {
       unpark_env(r, e, M, i);
@@ -837,7 +848,7 @@ __global__ void __launch_bounds__(64) tb_ff_kernel(KArgs A) {
         A.reward[i] = rew;  // (a survivor has earned nothing yet: every reward of the loop is paid in its last substep)
         if (A.substeps) A.substeps[i] = ns;
       }
-      reinterpret_cast<uint32_t*>(A.ff_rec + (size_t)src * TB_FF_REC + 7)[2] = 0u;  // the record is free again
+      if (A.ff_flag) A.ff_flag[src] = 0;  // the record is free again (lists and sorted copies are rewritten whole before their next use)
     }
     if (A.ff_next) {  // survivors: one atomic per wave reserves their places in the next phase's list
       const unsigned long long m = __ballot(unfinished);
@@ -1021,6 +1032,7 @@ struct TbHandle {
   const void *last_term, *last_sub;  // shared late-written buffers force ordering between fast-forwards
   int last_slot;
   float4* d_ff_rec[TB_FF_SLOTS];  // [n][TB_FF_REC] parked records (park_env)
+  uint8_t* d_ff_flag[TB_FF_SLOTS];  // [n] parked flags
   float4* d_ff_sorted[TB_FF_SLOTS];  // ff_sort: the slot's records in the order tb_ff_sort_kernel gives them, padded to whole sort groups
   float4* d_ff_list[TB_FF_SLOTS][2];  // survivors of fast-forward phases 1 and 2 (worst case: every env), compacted
   int* d_ff_count[TB_FF_SLOTS];       // [2] their numbers
@@ -1046,6 +1058,9 @@ struct TbHandle {
 namespace {
 
 int words_of(int kind) { return kind == TB_ENV_SWING ? TB_SWING_WORDS : TB_TENNIS_WORDS; }
+
+// dynamic LDS of a stepping kernel (see init_manifold): per lane, the static rows unless in registers + the cache if RG
+size_t dyn_lds(bool regrows, bool rg, unsigned lanes) { return sizeof(float) * lanes * ((regrows ? 0 : TB_ROWS_LDS) + (rg ? TB_MANI_LDS : 0)); }
 
 int ensure_marks(TbHandle* h) {
   if (h->h_marks) return TB_OK;
@@ -1107,7 +1122,7 @@ int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const 
   if (sort) {
     hipLaunchKernelGGL(tb_ff_sort_kernel, dim3((unsigned)groups), dim3(TB_FF_SORT_BLOCK), 0, h->side[slot], a, h->d_ff_sorted[slot]);
     HIP_TRY(hipGetLastError());
-    a.ff_rec = h->d_ff_sorted[slot]; a.n = groups * TB_FF_SORT_BLOCK;  // (outputs are addressed by the env index each record carries)
+    a.ff_rec = h->d_ff_sorted[slot]; a.ff_flag = nullptr; a.n = groups * TB_FF_SORT_BLOCK;  // (outputs are addressed by the env index each record carries)
   }
   // phases: budgeted loop + survivor kernels (see tb_ff_kernel). Without the host knowing the episode phase nearly every
   // record is idle: one plain kernel.
@@ -1118,14 +1133,15 @@ int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const 
     KArgs k = a;
     dim3 grid((unsigned)((a.n + a.ff_lanes - 1) / a.ff_lanes)), block(64);
     if (ph > 0) {  // survivors of phase ph: a compacted list of unknown length, walked by a fixed grid
-      k.ff_rec = h->d_ff_list[slot][ph - 1]; k.ff_src_count = h->d_ff_count[slot] + (ph - 1); k.ff_lanes = 64;
+      k.ff_rec = h->d_ff_list[slot][ph - 1]; k.ff_flag = nullptr; k.ff_src_count = h->d_ff_count[slot] + (ph - 1); k.ff_lanes = 64;
       int g = h->n / 512; g = g < 64 ? 64 : g;
       grid = dim3((unsigned)g);
     }
     if (ph + 1 < phases) { k.ff_next = h->d_ff_list[slot][ph]; k.ff_next_count = h->d_ff_count[slot] + ph; }
     const bool big = h->n >= 131072;
-    if (rg) { if (big) hipLaunchKernelGGL((tb_ff_kernel<true, true>), grid, block, TB_MANI_LDS * sizeof(float) * 64, h->side[slot], k); else hipLaunchKernelGGL((tb_ff_kernel<true, false>), grid, block, TB_MANI_LDS * sizeof(float) * 64, h->side[slot], k); }
-    else { if (big) hipLaunchKernelGGL((tb_ff_kernel<false, true>), grid, block, 0, h->side[slot], k); else hipLaunchKernelGGL((tb_ff_kernel<false, false>), grid, block, 0, h->side[slot], k); }
+    const size_t lds = dyn_lds(false, rg, 64);
+    if (rg) { if (big) hipLaunchKernelGGL((tb_ff_kernel<true, true>), grid, block, lds, h->side[slot], k); else hipLaunchKernelGGL((tb_ff_kernel<true, false>), grid, block, lds, h->side[slot], k); }
+    else { if (big) hipLaunchKernelGGL((tb_ff_kernel<false, true>), grid, block, lds, h->side[slot], k); else hipLaunchKernelGGL((tb_ff_kernel<false, false>), grid, block, lds, h->side[slot], k); }
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipGetLastError());
@@ -1174,32 +1190,33 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
     slot = h->next_slot;
     h->next_slot = (slot + 1) % TB_FF_SLOTS;
     if (h->ff_busy[slot]) HIP_TRY(hipStreamWaitEvent(s, h->ev_ff[slot], 0));  // slot still in use by an older fast-forward
-    a.defer = 1; a.ff_rec = h->d_ff_rec[slot];
+    a.defer = 1; a.ff_rec = h->d_ff_rec[slot]; a.ff_flag = h->d_ff_flag[slot];
   }
   const bool rg = extended_contacts(h->kp);  // selects the instantiation that contains the rolling-friction rows
-  const size_t mani_lds = rg ? TB_MANI_LDS * sizeof(float) * block.x : 0;  // the racket<->court caches' LDS columns
+  const unsigned lanes = pol ? 64u : block.x;
+  const size_t lds_rows = dyn_lds(false, rg && !pol, lanes), lds_regs = dyn_lds(true, false, lanes);  // instantiations with the static rows in LDS / in registers
   (void)hipGetLastError();  // the check below is about THIS launch, not about whatever another library left behind
 #define TB_LAUNCH_STEP(KIND, LEAN, MULTI)                                                                      \
   do {                                                                                                         \
-    if (pol) hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, false, false, true>), grid, block, mani_lds, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);        \
-    else if (rg) hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, MULTI, true>), grid, block, mani_lds, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);           \
-    else hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, MULTI, false>), grid, block, mani_lds, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);                  \
+    if (pol) hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, false, false, true>), grid, block, lds_rows, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);        \
+    else if (rg) hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, MULTI, true>), grid, block, lds_rows, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);           \
+    else hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, MULTI, false>), grid, block, lds_rows, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);                  \
   } while (0)
   if (T > 1) {
     if (h->kind == TB_ENV_TENNIS) {
-      if (h->reg_rows && !pol && !rg) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, true, false, false, true>), grid, block, mani_lds, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);
+      if (h->reg_rows && !pol && !rg) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, true, false, false, true>), grid, block, lds_regs, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);
       else TB_LAUNCH_STEP(TB_ENV_TENNIS, false, true);
     } else if (piped) {
       if (!may_park) a.ff_rec = nullptr;
       TB_LAUNCH_STEP(TB_ENV_SWING, true, true);
     } else TB_LAUNCH_STEP(TB_ENV_SWING, false, true);
   } else if (h->kind == TB_ENV_TENNIS) {
-    if (h->reg_rows && !rg && pol) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, false, false, true, true>), grid, block, mani_lds, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);
-    else if (h->reg_rows && !rg) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, false, false, false, true>), grid, block, mani_lds, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);
+    if (h->reg_rows && !rg && pol) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, false, false, true, true>), grid, block, lds_regs, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);
+    else if (h->reg_rows && !rg) hipLaunchKernelGGL((tb_step_kernel<TB_ENV_TENNIS, false, false, false, false, true>), grid, block, lds_regs, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);
     else TB_LAUNCH_STEP(TB_ENV_TENNIS, false, false);
   } else if (piped && h->swing_reg_rows && !pol && !rg) {
     if (!may_park) a.ff_rec = nullptr;  // (see the comment of the next branch but one)
-    hipLaunchKernelGGL((tb_step_kernel<TB_ENV_SWING, true, false, false, false, true>), grid, block, mani_lds, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);
+    hipLaunchKernelGGL((tb_step_kernel<TB_ENV_SWING, true, false, false, false, true>), grid, block, lds_regs, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);
   } else if (may_park) TB_LAUNCH_STEP(TB_ENV_SWING, true, false);
   else if (piped) {
     // phase known and not the 26th step: every env has step_count = phase < 25 (all were reset
@@ -1234,11 +1251,11 @@ int launch_policy_rollout(TbHandle* h, int T, const PolicyIO& pol, float* obs, f
     slot = h->next_slot;
     h->next_slot = (slot + 1) % TB_FF_SLOTS;
     if (h->ff_busy[slot]) HIP_TRY(hipStreamWaitEvent(s, h->ev_ff[slot], 0));
-    a.defer = 1; a.ff_rec = h->d_ff_rec[slot];
+    a.defer = 1; a.ff_rec = h->d_ff_rec[slot]; a.ff_flag = h->d_ff_flag[slot];
   }
   dim3 grid((unsigned)((h->n + 63) / 64)), block(320);
   (void)hipGetLastError();
-  if (swing) hipLaunchKernelGGL(tb_policy_rollout_kernel<TB_ENV_SWING>, grid, block, 0, s, a);
+  if (swing) hipLaunchKernelGGL(tb_policy_rollout_kernel<TB_ENV_SWING>, grid, block, dyn_lds(false, false, 64), s, a);
   else hipLaunchKernelGGL(tb_policy_rollout_kernel<TB_ENV_TENNIS>, grid, block, 0, s, a);
   HIP_TRY(hipGetLastError());
   if (may_park) {
@@ -1331,6 +1348,7 @@ int tb_destroy(TbHandle* h) {
   if (h->d_mflag) (void)hipFree(h->d_mflag);
   for (int k = 0; k < TB_FF_SLOTS; ++k) {
     if (h->d_ff_rec[k]) (void)hipFree(h->d_ff_rec[k]);
+    if (h->d_ff_flag[k]) (void)hipFree(h->d_ff_flag[k]);
     if (h->d_ff_sorted[k]) (void)hipFree(h->d_ff_sorted[k]);
     if (h->d_ff_list[k][0]) (void)hipFree(h->d_ff_list[k][0]);
     if (h->d_ff_list[k][1]) (void)hipFree(h->d_ff_list[k][1]);
@@ -1355,7 +1373,9 @@ int tb_set_pipeline(TbHandle* h, int enable) {
     for (int k = 0; k < TB_FF_SLOTS; ++k) {
       HIP_TRY(hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
       HIP_TRY(hipMalloc((void**)&h->d_ff_rec[k], wb));
-      HIP_TRY(hipMemset(h->d_ff_rec[k], 0, wb));  // word 30 of a record = 1 while an env is parked in it
+      HIP_TRY(hipMemset(h->d_ff_rec[k], 0, wb));
+      HIP_TRY(hipMalloc((void**)&h->d_ff_flag[k], (size_t)h->n));
+      HIP_TRY(hipMemset(h->d_ff_flag[k], 0, (size_t)h->n));
       for (int ph = 0; ph + 1 < h->ff_phases; ++ph) HIP_TRY(hipMalloc((void**)&h->d_ff_list[k][ph], wb));
       HIP_TRY(hipMalloc((void**)&h->d_ff_count[k], 2 * sizeof(int)));
       HIP_TRY(hipMemset(h->d_ff_count[k], 0, 2 * sizeof(int)));
