@@ -166,14 +166,16 @@ TB_DEV bool racket_in_reach(const KParams& P, vec3 d, float s) {
 // RELOAD: read the cull planes from LDS at every call instead of letting the compiler hoist the loop-invariant reads
 // out of the fast-forward loop, where they occupy 36 VGPRs for the whole kernel (183 -> 166: a third wave per SIMD;
 // +15 % SwingRacket at 1 M envs, same box; at 4096 envs, one wave per SIMD, the reads only lengthen the loop)
+// The test is in three parts so that the expensive middle one can be shared by the wave:
+//   racket_cull       per lane: local-frame culls; true = this lane's query needs the exact outline sweep
+//   outline_sweep     WAVE-COOPERATIVE: must be reached by all active lanes together (the caller branches on __any)
+//   racket_finish     per lane: distance, normal and arm from the sweep's result
 template <bool SCALED, bool RELOAD = false>
-TB_DEV Hit sphere_vs_racket_sweep(const KParams& P, const float4* hull, const Racket& rk, vec3 d, float s) {
-  Hit h;
-  h.hit = false; h.dist = 0.0f; h.n = mk(0, 0, 0); h.rr = mk(0, 0, 0);
+TB_DEV bool racket_cull(const KParams& P, const float4* hull, const Racket& rk, vec3 d, float s, vec3& l, float& ax) {
   const float r = P.ball_radius, thr = P.contact_threshold;
-  vec3 l = rotate_inv(rk.q, d);
+  l = rotate_inv(rk.q, d);
   if (SCALED) l = (1.0f / s) * l;
-  float ax = fabsf(l.x) - P.racket_half_thick;
+  ax = fabsf(l.x) - P.racket_half_thick;
   // Local-frame culls before the 38-edge sweep. In a SwingRacket episode the ball starts
   // 0.47 m in FRONT of the face, inside the bounding sphere, and falls alongside the racket:
   // without these every substep of every lane would sweep the outline.
@@ -183,7 +185,7 @@ TB_DEV Hit sphere_vs_racket_sweep(const KParams& P, const float4* hull, const Ra
   //      separation; 0.1 mm of slack covers all rounding, lanes inside the slack just run the
   //      exact sweep. (A plain bounding box is too loose next to the handle, where the outline
   //      is a narrow wedge: a tumbling racket's ball spends many substeps there.)
-  if (((SCALED ? ax * s : ax) - P.hull_margin) - r >= thr) return h;
+  if (((SCALED ? ax * s : ax) - P.hull_margin) - r >= thr) return false;
   float sep = -3.0e38f;
   const float4* cpl = hull + TB_HULL_PLANES;
   if (RELOAD) asm volatile("" : "+v"(cpl));  // an address the compiler cannot see through: the reads stay here
@@ -192,7 +194,7 @@ TB_DEV Hit sphere_vs_racket_sweep(const KParams& P, const float4* hull, const Ra
   for (int k = 0; k < 9; ++k) { float4 t = cpl[k]; cp[4 * k] = t.x; cp[4 * k + 1] = t.y; cp[4 * k + 2] = t.z; cp[4 * k + 3] = t.w; }
 #pragma unroll
   for (int k = 0; k < TB_N_CULL; ++k) sep = fmaxf(sep, FMA(cp[3 * k + 1], l.z, cp[3 * k] * l.y) - cp[3 * k + 2]);
-  if (((SCALED ? sep * s : sep) - P.hull_margin) - r >= thr + 1.0e-4f) return h;
+  if (((SCALED ? sep * s : sep) - P.hull_margin) - r >= thr + 1.0e-4f) return false;
 #ifdef TB_DIAG_STAMPS
   {
     unsigned long long m = __ballot(1);
@@ -200,43 +202,113 @@ TB_DEV Hit sphere_vs_racket_sweep(const KParams& P, const float4* hull, const Ra
     if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)m) - 1u) atomicAdd(&g_diag_cycles[11], 1ull);  // wave-sweeps
   }
 #endif
-  float sx = l.x < 0.0f ? -1.0f : 1.0f;
-  bool inside = true;
-  int deep_edge = 0;
-  float best_d2 = 3.0e38f, best_ry = 0.0f, best_rz = 0.0f, max_sd = -3.0e38f;
-  for (int i = 0; i < P.n_hull; ++i) {
-    float4 e0 = hull[2 * i];
-    float4 e1 = hull[2 * i + 1];
-    float wy = l.y - e0.x, wz = l.z - e0.y;
+  return true;
+}
+
+// The outline sweep of one query point = n_hull dependent trips (two 16-byte LDS reads, ~25 branchy VALU each): ~12 k cycles
+// by in-kernel stamps, and ONE lane in 64 doing it charges the whole wave (0.15 racket contacts per episode = 8 % of a
+// wave's fast-forward substeps, a quarter of its time). So the wave does it together: for each lane that needs a sweep (one at
+// a time, wave-uniform loop) the query point is broadcast, up to TB_SWEEP_HELPERS active lanes evaluate every
+// TB_SWEEP_HELPERS-th edge each -- the very same arithmetic per edge -- and the asking lane combines their partial results by
+// the sequential loop's own rule (smallest distance / largest signed distance, lowest edge index on ties), read from the
+// helpers by cross-lane shuffles. Bit-identical to the one-lane loop; ~6 x shorter.
+constexpr int TB_SWEEP_HELPERS = 8;
+struct SweepOut { float best_d2, best_ry, best_rz, max_sd; int deep_edge; bool inside; };
+TB_DEV SweepOut outline_sweep(const float4* hull, int n_hull, bool need, float qy, float qz) {
+  const int lane = (int)(threadIdx.x & 63);
+  const unsigned long long act = __ballot(1);
+  const int rank = __popcll(act & ((1ull << lane) - 1ull));
+  const int na = __popcll(act), G = na < TB_SWEEP_HELPERS ? na : TB_SWEEP_HELPERS;
+  SweepOut mine;
+  mine.best_d2 = 3.0e38f; mine.best_ry = 0.0f; mine.best_rz = 0.0f; mine.max_sd = -3.0e38f; mine.deep_edge = 0; mine.inside = true;
+  for (unsigned long long todo = __ballot(need); todo; todo &= todo - 1ull) {
+    const int src = __ffsll((long long)todo) - 1;
+    const float py = __shfl(qy, src, 64), pz = __shfl(qz, src, 64);
+    // my share of the edges, in increasing order (helpers: the first G active lanes)
+    float bd2 = 3.0e38f, bry = 0.0f, brz = 0.0f, msd = -3.0e38f;
+    int bi = 0x7fffffff, di = 0x7fffffff, ins = 1;
+    if (rank < G) {
+      for (int i = rank; i < n_hull; i += G) {
+        const float4 e0 = hull[2 * i], e1 = hull[2 * i + 1];
+        float wy = py - e0.x, wz = pz - e0.y;
+        float cr = FMA(e0.z, wz, -(e0.w * wy));
+        float sd = -(cr * e1.y);
+        if (sd > msd) { msd = sd; di = i; }
+        // the closest boundary point of a convex outline lies on an edge that faces the point
+        // (cr < 0); edges seen from behind cannot hold it and are skipped
+        if (cr < 0.0f) {
+          ins = 0;
+          float t = FMA(wy, e0.z, wz * e0.w) * e1.x;
+          t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+          float ry = FMA(-t, e0.z, wy), rz = FMA(-t, e0.w, wz);
+          float d2 = FMA(ry, ry, rz * rz);
+          if (d2 < bd2) { bd2 = d2; bry = ry; brz = rz; bi = i; }
+        }
+      }
+    }
+    // combine the helpers' partials (every lane runs the shuffles; only lane `src` keeps the result)
+    float cd2 = 3.0e38f, csd = -3.0e38f;
+    int cbi = 0x7fffffff, cdi = 0x7fffffff, cins = 1, win = src;
+    unsigned long long m = act;
+    for (int g = 0; g < G; ++g) {
+      const int pl = __ffsll((long long)m) - 1;  // physical lane of helper g (wave-uniform)
+      m &= m - 1ull;
+      const float od2 = __shfl(bd2, pl, 64), osd = __shfl(msd, pl, 64);
+      const int obi = __shfl(bi, pl, 64), odi = __shfl(di, pl, 64), oins = __shfl(ins, pl, 64);
+      if (od2 < cd2 || (od2 == cd2 && obi < cbi)) { cd2 = od2; cbi = obi; win = pl; }
+      if (osd > csd || (osd == csd && odi < cdi)) { csd = osd; cdi = odi; }
+      cins &= oins;
+    }
+    const float wry = __shfl(bry, win, 64), wrz = __shfl(brz, win, 64);
+    if (lane == src) {
+      mine.best_d2 = cd2; mine.best_ry = wry; mine.best_rz = wrz; mine.max_sd = csd; mine.deep_edge = cdi == 0x7fffffff ? 0 : cdi; mine.inside = cins != 0;
+    }
+  }
+  return mine;
+}
+
+// the same sweep by one lane for itself (every instantiation but the large-batch fast-forward, see substep)
+TB_DEV SweepOut outline_sweep_serial(const float4* hull, int n_hull, float py, float pz) {
+  SweepOut o;
+  o.best_d2 = 3.0e38f; o.best_ry = 0.0f; o.best_rz = 0.0f; o.max_sd = -3.0e38f; o.deep_edge = 0; o.inside = true;
+  for (int i = 0; i < n_hull; ++i) {
+    const float4 e0 = hull[2 * i], e1 = hull[2 * i + 1];
+    float wy = py - e0.x, wz = pz - e0.y;
     float cr = FMA(e0.z, wz, -(e0.w * wy));
     float sd = -(cr * e1.y);
-    if (sd > max_sd) { max_sd = sd; deep_edge = i; }
-    // the closest boundary point of a convex outline lies on an edge that faces the point
-    // (cr < 0); edges seen from behind cannot hold it and are skipped
+    if (sd > o.max_sd) { o.max_sd = sd; o.deep_edge = i; }
     if (cr < 0.0f) {
-      inside = false;
+      o.inside = false;
       float t = FMA(wy, e0.z, wz * e0.w) * e1.x;
       t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
       float ry = FMA(-t, e0.z, wy), rz = FMA(-t, e0.w, wz);
       float d2 = FMA(ry, ry, rz * rz);
-      if (d2 < best_d2) { best_d2 = d2; best_ry = ry; best_rz = rz; }
+      if (d2 < o.best_d2) { o.best_d2 = d2; o.best_ry = ry; o.best_rz = rz; }
     }
   }
+  return o;
+}
+
+template <bool SCALED>
+TB_DEV Hit racket_finish(const KParams& P, const float4* hull, const Racket& rk, vec3 d, float s, vec3 l, float ax, const SweepOut& so) {
+  Hit h;
+  const float r = P.ball_radius, thr = P.contact_threshold;
+  const float sx = l.x < 0.0f ? -1.0f : 1.0f;
   float dist_hull; vec3 nl;
-  if (inside) {
-    if (ax > 0.0f || ax >= max_sd) { dist_hull = ax; nl = mk(sx, 0.0f, 0.0f); }
+  if (so.inside) {
+    if (ax > 0.0f || ax >= so.max_sd) { dist_hull = ax; nl = mk(sx, 0.0f, 0.0f); }
     else {
-      float4 e0 = hull[2 * deep_edge];
-      float4 e1 = hull[2 * deep_edge + 1];
-      dist_hull = max_sd;
+      float4 e0 = hull[2 * so.deep_edge];
+      float4 e1 = hull[2 * so.deep_edge + 1];
+      dist_hull = so.max_sd;
       nl = mk(0.0f, e0.w * e1.y, -(e0.z * e1.y));
     }
   } else {
     float dx = ax > 0.0f ? sx * ax : 0.0f;
-    float dd = FMA(dx, dx, best_d2);
+    float dd = FMA(dx, dx, so.best_d2);
     dist_hull = sqrtf(dd);
     float inv = 1.0f / dist_hull;
-    nl = mk(dx * inv, best_ry * inv, best_rz * inv);
+    nl = mk(dx * inv, so.best_ry * inv, so.best_rz * inv);
   }
   h.dist = ((SCALED ? dist_hull * s : dist_hull) - P.hull_margin) - r;
   h.hit = h.dist < thr;
@@ -894,7 +966,20 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
 #ifdef TB_DIAG_STAMPS
     if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)__ballot(1)) - 1u) atomicAdd(&g_diag_cycles[12], 1ull);  // wave-substeps with a lane in reach
 #endif
-    if (near_racket) hr = sphere_vs_racket_sweep<KIND == TB_ENV_TENNIS, RELOAD>(P, hull, rk, d, scale);
+    vec3 ql = mk(0.0f, 0.0f, 0.0f);
+    float qax = 0.0f;
+    bool need = false;
+    if (near_racket) need = racket_cull<KIND == TB_ENV_TENNIS, RELOAD>(P, hull, rk, d, scale, ql, qax);
+    // the cooperative form where throughput counts (the large-batch fast-forward instantiation, RELOAD): +4.7 % at 1 M envs, same
+    // box; at 4096 envs it shortens the fast-forward (0.47 -> 0.44 ms per lone episode) but its busier waves take more from the
+    // step kernels beside them than that gives back (702 -> 655 M env steps/s), and in the loop-free step kernels its ballot masks
+    // cost SGPR spills at kernel start (-10 %)
+    if constexpr (!RELOAD) {  // each lane for itself
+      if (need) hr = racket_finish<KIND == TB_ENV_TENNIS>(P, hull, rk, d, scale, ql, qax, outline_sweep_serial(hull, P.n_hull, ql.y, ql.z));
+    } else if (__any(need)) {  // the sweep is shared by the wave: every active lane goes in
+      const SweepOut so = outline_sweep(hull, P.n_hull, need, ql.y, ql.z);
+      if (need) hr = racket_finish<KIND == TB_ENV_TENNIS>(P, hull, rk, d, scale, ql, qax, so);
+    }
   }
 #ifdef TB_DIAG_STAMPS
   if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)__ballot(1)) - 1u) atomicAdd(&g_diag_cycles[13], 1ull);  // wave-substeps

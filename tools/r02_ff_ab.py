@@ -58,6 +58,14 @@ def main():
         lib = "/tmp/libtb_old.so"
         subprocess.check_call([hipcc()] + HIPCC_FLAGS + ["-o", lib, os.path.join(ROOT, "tools", "diag", "old_csrc", "tennisbot_rl_amd", "csrc", "tb_stepper.hip")])
         stepper.use_library(lib)
+    extra = [x for x in sys.argv[2:] if x.startswith("-D")]
+    if extra:  # extra hipcc flags: build that variant of the library into /tmp and measure it instead (same-box A/B)
+        import subprocess
+        from tennisbot_rl_amd import stepper
+        from tennisbot_rl_amd.build import HIPCC_FLAGS, SOURCES, hipcc
+        lib = "/tmp/libtb_variant.so"
+        subprocess.check_call([hipcc()] + HIPCC_FLAGS + extra + ["-o", lib] + SOURCES)
+        stepper.use_library(lib)
     print("variant", sys.argv[2:], "flags", hex(flags), flush=True)
     out = []
     if which in ("all", "small"):
