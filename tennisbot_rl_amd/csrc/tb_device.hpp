@@ -212,7 +212,10 @@ TB_DEV bool racket_cull(const KParams& P, const float4* hull, const Racket& rk, 
 // TB_SWEEP_HELPERS-th edge each -- the very same arithmetic per edge -- and the asking lane combines their partial results by
 // the sequential loop's own rule (smallest distance / largest signed distance, lowest edge index on ties), read from the
 // helpers by cross-lane shuffles. Bit-identical to the one-lane loop; ~6 x shorter.
-constexpr int TB_SWEEP_HELPERS = 8;
+#ifndef TB_DIAG_SWEEP_HELPERS
+#define TB_DIAG_SWEEP_HELPERS 8
+#endif
+constexpr int TB_SWEEP_HELPERS = TB_DIAG_SWEEP_HELPERS;
 struct SweepOut { float best_d2, best_ry, best_rz, max_sd; int deep_edge; bool inside; };
 TB_DEV SweepOut outline_sweep(const float4* hull, int n_hull, bool need, float qy, float qz) {
   const int lane = (int)(threadIdx.x & 63);

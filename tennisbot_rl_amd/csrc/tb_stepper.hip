@@ -1069,11 +1069,12 @@ int ensure_marks(TbHandle* h) {
   return TB_OK;
 }
 
-// small batches: one wave per workgroup so the waves spread over as many CUs as possible
-// (4096 envs = 64 waves -> 64 CUs); large batches: 256-thread workgroups amortise the LDS staging
+// small batches: one wave per workgroup so the waves spread over as many CUs as possible (4096 envs = 64 waves -> 64 CUs);
+// large batches: 128-thread workgroups (1 M envs, same box: SwingRacket 9.00 G env steps/s with 128, 8.98 with 64, 8.83 with
+// 256; Tennisbot 18.9 / 18.4 / 18.1-18.4 G)
 int pick_block(int n, const TbOptions& o) {
   if (o.block == 64 || o.block == 128 || o.block == 256) return o.block;
-  return n <= 131072 ? 64 : 256;
+  return n <= 131072 ? 64 : 128;
 }
 
 KArgs base_args(const TbHandle* h) {

@@ -12,18 +12,19 @@ sys.path.insert(0, ROOT)
 import torch
 
 
-def measure(n, T, opts, reps=5, flags=None):
-    from tennisbot_rl_amd.params import ENV_SWING, F_DEFAULT, default_params
+def measure(n, T, opts, reps=5, flags=None, kind=None):
+    from tennisbot_rl_amd.params import ENV_SWING, ENV_TENNIS, F_DEFAULT, default_params
+    ENV_SWING = ENV_SWING if kind is None else kind
     from tennisbot_rl_amd.rollout import RolloutBuffer
     from tennisbot_rl_amd.stepper import BatchedEnv
     dev = torch.device("cuda", 0)
-    env = BatchedEnv(ENV_SWING, n, device=dev, seed=0, params=default_params(flags=F_DEFAULT if flags is None else flags), track_terminal_obs=False, pipeline=True, options=opts)
+    env = BatchedEnv(ENV_SWING, n, device=dev, seed=0, params=default_params(flags=F_DEFAULT if flags is None else flags), track_terminal_obs=False, pipeline=kind is None, options=opts)
     buf = RolloutBuffer(ENV_SWING, T, n, dev)
     buf.actions.uniform_(-1.0, 1.0)
     buf.bind(env)
     env.reset()
-    for t in range(26):
-        buf.step_into(env, t)
+    for t in range(26 if kind is None else 1040):
+        buf.step_into(env, t % T)
     env.flush()
     g = env.capture(lambda: buf.step_range(env, 0, T))
     g.replay(); torch.cuda.synchronize()
@@ -71,6 +72,13 @@ def main():
     if which in ("all", "small"):
         for o in ({}, dict(ff_phases=3)):
             out.append(measure(4096, 1040, o, flags=flags)); print(json.dumps(out[-1]), flush=True)
+    if which == "tennis1m":
+        from tennisbot_rl_amd.params import ENV_TENNIS
+        for o in (dict(), dict(block=128), dict(block=64), dict(block=256)):
+            out.append(measure(1048576, 104, o, reps=3, flags=flags, kind=ENV_TENNIS)); print(json.dumps(out[-1]), flush=True)
+    if which == "opts1m":
+        for o in (dict(), dict(swing_reg_rows=True), dict(block=128), dict(block=64), dict(swing_reg_rows=True, block=128)):
+            out.append(measure(1048576, 104, o, reps=3, flags=flags)); print(json.dumps(out[-1]), flush=True)
     if which in ("all", "large"):
         for o in (dict(ff_phases=1), dict(ff_phases=3)):
             out.append(measure(1048576, 104, o, reps=3, flags=flags)); print(json.dumps(out[-1]), flush=True)
