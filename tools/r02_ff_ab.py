@@ -59,6 +59,9 @@ def main():
         lib = "/tmp/libtb_old.so"
         subprocess.check_call([hipcc()] + HIPCC_FLAGS + ["-o", lib, os.path.join(ROOT, "tools", "diag", "old_csrc", "tennisbot_rl_amd", "csrc", "tb_stepper.hip")])
         stepper.use_library(lib)
+    if "prev" in sys.argv:  # a library built from the previous commit, shipped with the snapshot (tools/diag/prev/, untracked)
+        from tennisbot_rl_amd import stepper
+        stepper.use_library(os.path.join(ROOT, "tools", "diag", "prev", "libtb_prev.so"))
     extra = [x for x in sys.argv[2:] if x.startswith("-D")]
     if extra:  # extra hipcc flags: build that variant of the library into /tmp and measure it instead (same-box A/B)
         import subprocess
