@@ -72,3 +72,25 @@ def test_bench_exchange_forms_with_one_rank(chunks):
     assert d["value"] > 0 and "invalid" not in d and "all-gather" in w
     assert x["ranks_seen"] == 1 and x["bytes_per_rank"] >= 208 * 4096 * 53 and x["rollout_ms"] > 0 and x["exchange_ms"] > 0.9 and x["exposed_exchange_ms"] >= 0
     assert ("step-chunks" in x["form"]) == (chunks == "8") and not x["note"]
+
+
+def test_bench_workload_constants_match_the_oracle():
+    """what bench.py refuses a value against: the random-action SwingRacket workload's substeps per agent step (whole episodes),
+    re-measured here on the CPU oracle; and the reference's own wall-clock record it quotes next to the CPU baseline"""
+    import importlib.util
+    import numpy as np
+    from oracle import OracleBatch
+    from tennisbot_rl_amd.params import ENV_SWING, F_AUTO_RESET, F_DEFAULT, default_params
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n, rng = 2048, np.random.Generator(np.random.PCG64(0))
+    b = OracleBatch(default_params(flags=F_DEFAULT | F_AUTO_RESET), ENV_SWING, n, seed=0, precision="f32", threads=4)
+    b.reset()
+    for t in range(26 * 3):
+        b.step(rng.uniform(-1.0, 1.0, (n, 6)).astype(np.float32))
+    sps = b.counters()[6] / (n * 26 * 3)
+    assert abs(sps / bench.EXPECTED_SUBSTEPS[("swing", False)] - 1.0) < 0.02, sps
+    assert bench.ALGO_BYTES["swing"] == {"read": 145, "write": 122} and bench.ALGO_BYTES["tennis"] == {"read": 117, "write": 146}  # SURVEY.md 8d
+    rr = bench.reference_record()
+    assert rr["episodes"] == 100 and 150 < rr["agent_steps_per_s_overall"] < rr["agent_steps_per_s_collect"] < 200
