@@ -172,7 +172,7 @@ typedef struct TbOptions {
   int32_t ff_lanes_per_wave; /* parked envs per wave in the first fast-forward phase, 1..64 (auto: 64 from 4096 envs on, fewer below) */
   int32_t ff_sort;          /* order parked envs by their ball's ballistic flight estimate before the fast-forward: 1 on (auto: off --
                              * with random actions the flight lengths are decided by events inside the loop, not by the parked state) */
-  int32_t ff_phases;        /* the fast-forward as 1, 2 or 3 kernels: budgeted loop, then its compacted survivors (auto: 3 from 524288 envs on, else 1) */
+  int32_t ff_phases;        /* the fast-forward as 1, 2 or 3 kernels: budgeted loop, then its compacted survivors (auto: 3 from 262144 envs on, else 1; from 131072 envs on the first of several also hands over every env whose ball reaches the racket) */
   int32_t reserved;
 } TbOptions;
 

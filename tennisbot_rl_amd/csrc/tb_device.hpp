@@ -127,9 +127,17 @@ struct Hit {
 };
 
 constexpr int CT_RACKET = 1, CT_GROUND = 2, CT_NET = 4, CT_GOAL = 8, CT_RACKET_COURT = 16;
+constexpr int CT_ESCAPE = 32;  // not a contact: substep<ESC> left the env untouched, see there
 
 // In-kernel stamps for the diagnostic build only (-DTB_DIAG_STAMPS, tools/diag_stamps.py):
 // cycles per substep segment, summed per wave into g_diag_cycles. Never compiled into the product.
+#ifdef TB_DIAG_LANES  // lane census of the substep's wave votes (diagnostic builds only): how many lanes ask for what a whole wave then runs
+__device__ unsigned long long g_diag_lanes[16];
+#define TB_LANES(k, pred) do { const unsigned long long m_ = __ballot(pred), a_ = __ballot(1); \
+  if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)a_) - 1u) { atomicAdd(&g_diag_lanes[k], (unsigned long long)__popcll(m_)); if (m_) atomicAdd(&g_diag_lanes[(k) + 1], 1ull); } } while (0)
+#else
+#define TB_LANES(k, pred)
+#endif
 #ifdef TB_DIAG_STAMPS
 __device__ unsigned long long g_diag_cycles[16];
 struct Stamps { unsigned long long t; unsigned int acc[8]; };
@@ -170,8 +178,8 @@ TB_DEV bool racket_in_reach(const KParams& P, vec3 d, float s) {
 //   racket_cull       per lane: local-frame culls; true = this lane's query needs the exact outline sweep
 //   outline_sweep     WAVE-COOPERATIVE: must be reached by all active lanes together (the caller branches on __any)
 //   racket_finish     per lane: distance, normal and arm from the sweep's result
-template <bool SCALED, bool RELOAD = false>
-TB_DEV bool racket_cull(const KParams& P, const float4* hull, const Racket& rk, vec3 d, float s, vec3& l, float& ax) {
+template <bool SCALED>
+TB_DEV bool racket_slab(const KParams& P, const Racket& rk, vec3 d, float s, vec3& l, float& ax) {
   const float r = P.ball_radius, thr = P.contact_threshold;
   l = rotate_inv(rk.q, d);
   if (SCALED) l = (1.0f / s) * l;
@@ -185,7 +193,12 @@ TB_DEV bool racket_cull(const KParams& P, const float4* hull, const Racket& rk, 
   //      separation; 0.1 mm of slack covers all rounding, lanes inside the slack just run the
   //      exact sweep. (A plain bounding box is too loose next to the handle, where the outline
   //      is a narrow wedge: a tumbling racket's ball spends many substeps there.)
-  if (((SCALED ? ax * s : ax) - P.hull_margin) - r >= thr) return false;
+  return !(((SCALED ? ax * s : ax) - P.hull_margin) - r >= thr);
+}
+// (2), each lane for itself; true = still not separated
+template <bool SCALED, bool RELOAD>
+TB_DEV bool racket_planes(const KParams& P, const float4* hull, vec3 l, float s) {
+  const float r = P.ball_radius, thr = P.contact_threshold;
   float sep = -3.0e38f;
   const float4* cpl = hull + TB_HULL_PLANES;
   if (RELOAD) asm volatile("" : "+v"(cpl));  // an address the compiler cannot see through: the reads stay here
@@ -194,7 +207,19 @@ TB_DEV bool racket_cull(const KParams& P, const float4* hull, const Racket& rk, 
   for (int k = 0; k < 9; ++k) { float4 t = cpl[k]; cp[4 * k] = t.x; cp[4 * k + 1] = t.y; cp[4 * k + 2] = t.z; cp[4 * k + 3] = t.w; }
 #pragma unroll
   for (int k = 0; k < TB_N_CULL; ++k) sep = fmaxf(sep, FMA(cp[3 * k + 1], l.z, cp[3 * k] * l.y) - cp[3 * k + 2]);
-  if (((SCALED ? sep * s : sep) - P.hull_margin) - r >= thr + 1.0e-4f) return false;
+  return !(((SCALED ? sep * s : sep) - P.hull_margin) - r >= thr + 1.0e-4f);
+}
+// (Measured and dropped: testing the outline's bounding box -- four of the planes -- first and fetching the other eight only for lanes
+//  it lets through: no difference at 1 M envs. And sharing (2) by the wave -- each past-the-slab lane's point broadcast, 12 lanes testing one plane each, the same
+//  verdict bit for bit. 3 % of the lanes get past the slab, so four wave-substeps in five walk the 12 planes for one or two lanes;
+//  still the shared form was 7 % slower at 1 M envs, same box: its per-lane trips serialise on LDS latency.)
+template <bool SCALED, bool RELOAD = false>
+TB_DEV bool racket_cull(const KParams& P, const float4* hull, const Racket& rk, vec3 d, float s, vec3& l, float& ax) {
+  if (!racket_slab<SCALED>(P, rk, d, s, l, ax)) return false;
+#ifdef TB_DIAG_LANES
+  atomicAdd(&g_diag_lanes[12], 1ull);  // lanes past the slab test
+#endif
+  if (!racket_planes<SCALED, RELOAD>(P, hull, l, s)) return false;
 #ifdef TB_DIAG_STAMPS
   {
     unsigned long long m = __ballot(1);
@@ -204,7 +229,6 @@ TB_DEV bool racket_cull(const KParams& P, const float4* hull, const Racket& rk, 
 #endif
   return true;
 }
-
 // The outline sweep of one query point = n_hull dependent trips (two 16-byte LDS reads, ~25 branchy VALU each): ~12 k cycles
 // by in-kernel stamps, and ONE lane in 64 doing it charges the whole wave (0.15 racket contacts per episode = 8 % of a
 // wave's fast-forward substeps, a quarter of its time). So the wave does it together: for each lane that needs a sweep (one at
@@ -394,23 +418,27 @@ struct RowS {  // ball vs static shape
   vec3 n, t1, t2;
   float mu, target, jn, jt1, jt2;
 };
-// a static row in its lane's LDS column (word w of row i at st[(14 i + w) * stride])
-template <typename MANI> TB_DEV RowS load_row(const MANI& M, int i) {
-  const float* p = M.st + 14 * i * M.stride;
+// a static row in its lane's LDS column (word w of row i at st[(14 i + w) * stride]).
+// TWO: two slots instead of three -- the net's row and the goal's share the second (substep<ESC> hands an env that is near both
+// to the next phase kernel before anything is stored): 28 words per lane instead of 42, a fourth wave per SIMD for the kernel
+// that runs nearly all of a large batch's fast-forward substeps.
+template <bool TWO> TB_DEV constexpr int row_slot(int i) { return TWO && i == 2 ? 1 : i; }
+template <bool TWO = false, typename MANI> TB_DEV RowS load_row(const MANI& M, int i) {
+  const float* p = M.st + 14 * row_slot<TWO>(i) * M.stride;
   const int s = M.stride;
   RowS c;
   c.n = mk(p[0], p[s], p[2 * s]); c.t1 = mk(p[3 * s], p[4 * s], p[5 * s]); c.t2 = mk(p[6 * s], p[7 * s], p[8 * s]);
   c.mu = p[9 * s]; c.target = p[10 * s]; c.jn = p[11 * s]; c.jt1 = p[12 * s]; c.jt2 = p[13 * s];
   return c;
 }
-template <typename MANI> TB_DEV void store_row(const MANI& M, int i, const RowS& c) {
-  float* p = M.st + 14 * i * M.stride;
+template <bool TWO = false, typename MANI> TB_DEV void store_row(const MANI& M, int i, const RowS& c) {
+  float* p = M.st + 14 * row_slot<TWO>(i) * M.stride;
   const int s = M.stride;
   p[0] = c.n.x; p[s] = c.n.y; p[2 * s] = c.n.z; p[3 * s] = c.t1.x; p[4 * s] = c.t1.y; p[5 * s] = c.t1.z; p[6 * s] = c.t2.x; p[7 * s] = c.t2.y; p[8 * s] = c.t2.z;
   p[9 * s] = c.mu; p[10 * s] = c.target; p[11 * s] = c.jn; p[12 * s] = c.jt1; p[13 * s] = c.jt2;
 }
-template <typename MANI> TB_DEV void store_row_impulses(const MANI& M, int i, const RowS& c) {
-  float* p = M.st + 14 * i * M.stride;
+template <bool TWO = false, typename MANI> TB_DEV void store_row_impulses(const MANI& M, int i, const RowS& c) {
+  float* p = M.st + 14 * row_slot<TWO>(i) * M.stride;
   const int s = M.stride;
   p[11 * s] = c.jn; p[12 * s] = c.jt1; p[13 * s] = c.jt2;
 }
@@ -809,7 +837,7 @@ template <> struct Rows<true> { RowR rk; RowS st[3]; int on; RollR qrk; RollS qs
 // the steady state; tb_create decides) and SwingRacket's loop-free pipelined step kernel up to 131072
 // envs (+2.7 % at 4096); in SwingRacket's fast-forward loop the registers cost more than they give
 // (-6 % at 4096 envs, -17 % at 1 M). Same arithmetic either way.
-template <bool RG, bool REGROWS>
+template <bool RG, bool REGROWS, bool TWO = false>
 TB_DEV void solve_contacts(const KParams& P, Rows<RG>& R, const Manifold& M, int nrg, const Sym3& W, Racket& rk, Ball& b) {
   float jref = 0.0f;
   if constexpr (RG) {
@@ -826,7 +854,7 @@ TB_DEV void solve_contacts(const KParams& P, Rows<RG>& R, const Manifold& M, int
     } else {
 #pragma unroll 1
       for (int i = 0; i < 3; ++i)
-        if (((R.on >> (i + 1)) & 1)) { RowS c = load_row(M, i); moved |= normal_static(P, c, b, jref); store_row_impulses(M, i, c); }
+        if (((R.on >> (i + 1)) & 1)) { RowS c = load_row<TWO>(M, i); moved |= normal_static(P, c, b, jref); store_row_impulses<TWO>(M, i, c); }
     }
     if constexpr (RG) {
 #pragma unroll 1
@@ -838,7 +866,7 @@ TB_DEV void solve_contacts(const KParams& P, Rows<RG>& R, const Manifold& M, int
       for (int i = 0; i < 3; ++i)
         if (((R.on >> (i + 1)) & 1)) {
           if constexpr (REGROWS) moved |= rolling_static(P, R.st[i], R.qst[i], b, jref);
-          else { RowS c = load_row(M, i); moved |= rolling_static(P, c, R.qst[i], b, jref); }
+          else { RowS c = load_row<TWO>(M, i); moved |= rolling_static(P, c, R.qst[i], b, jref); }
         }
     }
     if ((R.on & 1)) moved |= friction_racket(P, R.rk, rk, b, jref);
@@ -849,7 +877,7 @@ TB_DEV void solve_contacts(const KParams& P, Rows<RG>& R, const Manifold& M, int
     } else {
 #pragma unroll 1
       for (int i = 0; i < 3; ++i)
-        if (((R.on >> (i + 1)) & 1)) { RowS c = load_row(M, i); moved |= friction_static(P, c, b, jref); store_row_impulses(M, i, c); }
+        if (((R.on >> (i + 1)) & 1)) { RowS c = load_row<TWO>(M, i); moved |= friction_static(P, c, b, jref); store_row_impulses<TWO>(M, i, c); }
     }
     if constexpr (RG) {
 #pragma unroll 1
@@ -940,10 +968,33 @@ TB_DEV void integrate_pose(const KParams& P, Racket& rk, Ball& b) {
 // COLD: the contact path reads its constants from the LDS copy of the parameter block instead of holding them in SGPRs all the
 // time. Pays where SGPRs are scarce and contacts rare (the policy rollout kernel: 97 -> 70 spill writes, collect +10 %); costs VGPRs and
 // LDS reads where throughput counts (SwingRacket at 1 M envs -15 %, Tennisbot -4 %), so only that kernel asks for it.
-template <int KIND, bool RG, bool REGROWS = false, bool COLD = false, bool RELOAD = false>
+// ESC (first phase of the large-batch fast-forward): a lane whose ball gets past the racket's culls -- it needs the exact outline
+// sweep, and probably a racket row in the solver next -- does not run them here, where 63 other lanes would wait for it (0.2 % of
+// the lanes ask, but every ninth wave-substep has one: sweep + racket row + its solve are ~15 % of the loop's instructions).
+// It returns CT_ESCAPE with the env UNTOUCHED (the culls read poses only and come first), the caller hands the env to the next
+// phase kernel as a survivor, and that kernel repeats this substep with everything compiled in -- among lanes that mostly want
+// the same. Same arithmetic, same order per env: bit-identical.
+template <int KIND, bool RG, bool REGROWS = false, bool COLD = false, bool RELOAD = false, bool ESC = false>
 TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Manifold& M, vec3 Fr, vec3 Tr, vec3 Fb, float goal_x, float goal_y, float scale TB_STAMP_ARG) {
   int bits = 0;
   TB_STAMP(st, 0);  // everything between two substeps (loop control, env logic)
+  constexpr bool TWO = ESC && !RG && !REGROWS;  // the static rows in two LDS slots, see load_row
+  if constexpr (TWO) {  // (poses only, like the racket's culls: the very tests the static narrowphase below starts with)
+    const float zl = (b.p.z - P.ball_radius) - P.contact_threshold;
+    const bool nn = (P.flags & TB_F_NET) && !(zl >= P.net_half[2] + 1.0e-3f) && !(((fabsf(b.p.x) - P.net_half[0]) - P.ball_radius) >= P.contact_threshold + 1.0e-3f);
+    const bool nc = KIND == TB_ENV_SWING && !(zl >= P.goal_half_len + 1.0e-3f);
+    if (nn && nc) return CT_ESCAPE;  // both rows of the shared slot could be wanted
+  }
+  if constexpr (ESC) {
+    const vec3 d0 = b.p - rk.p;
+    const bool reach = (P.flags & TB_F_RACKET_BALL) && racket_in_reach(P, d0, scale);
+    if (__any(reach)) {
+      vec3 ql = mk(0.0f, 0.0f, 0.0f);
+      float qax = 0.0f;
+      if (reach && racket_cull<KIND == TB_ENV_TENNIS, RELOAD>(P, hull, rk, d0, scale, ql, qax)) return CT_ESCAPE;
+    }
+    TB_STAMP(st, 1);
+  }
   // the velocity update touches velocities only and the narrowphase reads poses only: their order
   // is free, and running it first keeps the Hit records from staying live across it
   // racket <-> court: poses only, like every narrowphase, so it may run before the velocity update as well; the common case
@@ -961,10 +1012,12 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
   hr.hit = false; hg.hit = false; hn.hit = false; hc.hit = false;
 
   vec3 d = b.p - rk.p;
-  bool near_racket = (P.flags & TB_F_RACKET_BALL) && racket_in_reach(P, d, scale);
+  bool near_racket = !ESC && (P.flags & TB_F_RACKET_BALL) && racket_in_reach(P, d, scale);
 #ifdef TB_DIAG_NO_NARROW
   near_racket = false;
 #endif
+  TB_LANES(0, true);          // [0] active lanes, [1] wave-substeps
+  TB_LANES(2, near_racket);   // [2] lanes inside the racket's bounding sphere, [3] wave-substeps with one
   if (__any(near_racket)) {
 #ifdef TB_DIAG_STAMPS
     if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)__ballot(1)) - 1u) atomicAdd(&g_diag_cycles[12], 1ull);  // wave-substeps with a lane in reach
@@ -977,6 +1030,7 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
     // box; at 4096 envs it shortens the fast-forward (0.47 -> 0.44 ms per lone episode) but its busier waves take more from the
     // step kernels beside them than that gives back (702 -> 655 M env steps/s), and in the loop-free step kernels its ballot masks
     // cost SGPR spills at kernel start (-10 %)
+    TB_LANES(4, need);        // [4] lanes that need the outline sweep, [5] wave-substeps with one
     if constexpr (!RELOAD) {  // each lane for itself
       if (need) hr = racket_finish<KIND == TB_ENV_TENNIS>(P, hull, rk, d, scale, ql, qax, outline_sweep_serial(hull, P.n_hull, ql.y, ql.z));
     } else if (__any(need)) {  // the sweep is shared by the wave: every active lane goes in
@@ -999,6 +1053,7 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
 #ifdef TB_DIAG_NO_NARROW
   near_g = false; near_n = false; near_c = false;
 #endif
+  TB_LANES(6, near_g | near_n | near_c);  // [6] lanes near a static shape, [7] wave-substeps with one
   if (__any(near_g | near_n | near_c)) {
     if (near_g) hg = sphere_vs_box(P, P.ground_half[0], P.ground_half[1], P.ground_half[2], b.p);
     if (near_n) hn = sphere_vs_box(P, P.net_half[0], P.net_half[1], P.net_half[2], b.p);
@@ -1011,6 +1066,8 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
   if (hc.hit) bits |= CT_GOAL;
   if (nrg) bits |= CT_RACKET_COURT;
 
+  TB_LANES(8, bits != 0);     // [8] lanes with a contact, [9] wave-substeps with one
+  TB_LANES(10, hr.hit);       // [10] lanes with a racket contact, [11] wave-substeps with one
   if (__any(bits != 0)) {
     if (bits) {  // only lanes that touch something enter the solver
       const KParams& PC = COLD ? *reinterpret_cast<const KParams*>(hull + TB_HULL_KP) : P;
@@ -1032,9 +1089,9 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
         if ((R.on & 8)) setup_static(PC, R.st[2], hc, PC.rest_goal, PC.fric_goal, b);
       } else {  // the rows go to the lane's LDS column, one at a time through registers
         RowS c;
-        if ((R.on & 2)) { setup_static(PC, c, hg, PC.rest_court, PC.fric_court, b); store_row(M, 0, c); }
-        if ((R.on & 4)) { setup_static(PC, c, hn, PC.rest_court, PC.fric_court, b); store_row(M, 1, c); }
-        if ((R.on & 8)) { setup_static(PC, c, hc, PC.rest_goal, PC.fric_goal, b); store_row(M, 2, c); }
+        if ((R.on & 2)) { setup_static(PC, c, hg, PC.rest_court, PC.fric_court, b); store_row<TWO>(M, 0, c); }
+        if ((R.on & 4)) { setup_static(PC, c, hn, PC.rest_court, PC.fric_court, b); store_row<TWO>(M, 1, c); }
+        if ((R.on & 8)) { setup_static(PC, c, hc, PC.rest_goal, PC.fric_goal, b); store_row<TWO>(M, 2, c); }
       }
       if constexpr (RG) {
         if ((R.on & 1)) setup_roll_racket<KIND == TB_ENV_TENNIS>(PC, R.qrk, R.rk, rk, scale);
@@ -1042,7 +1099,7 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
         if ((R.on & 4)) setup_roll_static(PC, R.qst[1], PC.roll_court);
         if ((R.on & 8)) setup_roll_static(PC, R.qst[2], PC.roll_goal);
       }
-      solve_contacts<RG, REGROWS>(PC, R, M, nrg, W, rk, b);
+      solve_contacts<RG, REGROWS, TWO>(PC, R, M, nrg, W, rk, b);
     }
   }
   TB_STAMP(st, 4);  // contact solve

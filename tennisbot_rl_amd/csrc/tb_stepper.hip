@@ -346,13 +346,16 @@ TB_DEV vec3 restoring_force(const EnvRegs& e) {  // swingracket_env.py:135-141
 // `defer`  = leave the fast-forward to tb_ff_kernel: sets `parked` instead of looping.
 // BUDGET  = tb_ff_kernel only: leave the loop after `budget` substeps with the env still running (`parked` again): the
 //           next phase kernel resumes it from the saved state, with the restoring force recomputed from that state.
-template <bool RG, bool REGROWS = false, bool COLD = false, bool BUDGET = false, bool RELOAD = false>
+// ESC     = first phase of the large-batch tb_ff_kernel: a lane that needs the racket's exact narrowphase leaves the loop BEFORE
+//           that substep (`parked` again, nothing of the substep applied); see substep<ESC>.
+template <bool RG, bool REGROWS = false, bool COLD = false, bool BUDGET = false, bool RELOAD = false, bool ESC = false>
 TB_DEV float swing_loop(const KParams& P, const float4* hull, EnvRegs& e, Manifold& M, vec3 F, vec3 T, bool in_ff, bool defer, bool& parked,
                         int& ns, uint32_t* cnt TB_STAMP_ARG, int budget = 0) {
   const vec3 zero = mk(0.0f, 0.0f, 0.0f);
   float reward = 0.0f;
   for (;;) {
-    int bits = substep<TB_ENV_SWING, RG, REGROWS, COLD, RELOAD>(P, hull, e.r, e.b, M, F, T, zero, e.aux[0], e.aux[1], 1.0f TB_STAMP_PASS);  // :82 / :107
+    int bits = substep<TB_ENV_SWING, RG, REGROWS, COLD, RELOAD, ESC>(P, hull, e.r, e.b, M, F, T, zero, e.aux[0], e.aux[1], 1.0f TB_STAMP_PASS);  // :82 / :107
+    if (ESC && (bits & CT_ESCAPE)) { parked = true; break; }
     e.step_count += 1; ns++;                                                                                   // :83 / :108
     if (bits & CT_RACKET) cnt[0]++;
     if (!in_ff) {
@@ -797,8 +800,12 @@ __global__ void __launch_bounds__(TB_FF_SORT_BLOCK) tb_ff_sort_kernel(KArgs A, f
 //   phases 2+: grid-stride over the *A.ff_src_count survivors of the previous phase, 64 per wave.
 // BIG: the instantiation for batches that fill the chip several times over (occupancy counts: cull planes re-read from
 // LDS, see sphere_vs_racket_sweep); below that the loop's latency counts and the planes stay in registers.
-template <bool RG, bool BIG>
-__global__ void __launch_bounds__(64) tb_ff_kernel(KArgs A) {
+// ESC: the first phase of a BIG fast-forward with a phase behind it also hands over every env whose ball reaches the racket (substep<ESC>).
+// (ESC without the extended contact set is also built for four waves per SIMD: 125 VGPRs -- no spills -- and, with the
+//  two-slot static rows of substep<ESC>, 9.5 KB of LDS per wave: 16 waves per CU instead of 12; 1 M envs, same box: 9.3-9.4 ->
+//  10.0 G env steps/s)
+template <bool RG, bool BIG, bool ESC = false>
+__global__ void __launch_bounds__(64, (ESC && !RG) ? 4 : 1) tb_ff_kernel(KArgs A) {
   __shared__ float4 s_hull[TB_HULL_LDS];
   const int lane = threadIdx.x & 63;
   stage_hull(s_hull, A);
@@ -836,7 +843,7 @@ __global__ void __launch_bounds__(64) tb_ff_kernel(KArgs A) {
       const vec3 F0 = e.step_count > 26 ? restoring_force(e) : zero;
       const int budget = A.ff_next ? 4 * predict_flight(A.P, e.b.p, e.b.v) + 8 : 0x7fffffff;
       const int ns0 = ns;
-      float rew = swing_loop<RG, false, false, true, BIG>(A.P, s_hull, e, M, F0, zero, true, false, unfinished, ns, cnt TB_STAMP_PASS, budget);
+      float rew = swing_loop<RG, false, false, true, BIG, ESC>(A.P, s_hull, e, M, F0, zero, true, false, unfinished, ns, cnt TB_STAMP_PASS, budget);
       cnt[6] += (uint32_t)(ns - ns0);
       if (!unfinished) {
         if (!(finite3(e.r.p) && finite3(e.r.v) && finite3(e.r.w) && finite3(e.b.p) && finite3(e.b.v) && finite3(e.b.w) &&
@@ -1110,18 +1117,19 @@ bool extended_contacts(const KParams& kp) {
 // finish the lanes parked in `slot` on that slot's side stream, ordered after everything issued to `s` so far
 int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const void* substeps, hipStream_t s) {
   KArgs a = a_in;
+  hipStream_t side = h->side[slot];
   // lockstep episodes (every env parks in the same launch): sorted, or a few envs per wave; without the host knowing the
   // phase every step is followed by this kernel and nearly every record is idle: plain 64 per wave, one flag test each
   const bool sort = h->ff_sort && h->phase_valid;
   a.ff_lanes = sort || !h->phase_valid ? 64 : h->ff_lanes;
   const int groups = (h->n + TB_FF_SORT_BLOCK - 1) / TB_FF_SORT_BLOCK;
   HIP_TRY(hipEventRecord(h->ev_step[slot], s));
-  HIP_TRY(hipStreamWaitEvent(h->side[slot], h->ev_step[slot], 0));
+  HIP_TRY(hipStreamWaitEvent(side, h->ev_step[slot], 0));
   // two fast-forwards that write the same terminal-obs / substeps buffer must finish in order
   if (h->last_slot >= 0 && h->last_slot != slot && ((term && term == h->last_term) || (substeps && substeps == h->last_sub)))
-    HIP_TRY(hipStreamWaitEvent(h->side[slot], h->ev_ff[h->last_slot], 0));
+    HIP_TRY(hipStreamWaitEvent(side, h->ev_ff[h->last_slot], 0));
   if (sort) {
-    hipLaunchKernelGGL(tb_ff_sort_kernel, dim3((unsigned)groups), dim3(TB_FF_SORT_BLOCK), 0, h->side[slot], a, h->d_ff_sorted[slot]);
+    hipLaunchKernelGGL(tb_ff_sort_kernel, dim3((unsigned)groups), dim3(TB_FF_SORT_BLOCK), 0, side, a, h->d_ff_sorted[slot]);
     HIP_TRY(hipGetLastError());
     a.ff_rec = h->d_ff_sorted[slot]; a.ff_flag = nullptr; a.n = groups * TB_FF_SORT_BLOCK;  // (outputs are addressed by the env index each record carries)
   }
@@ -1129,31 +1137,33 @@ int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const 
   // record is idle: one plain kernel.
   const int phases = h->phase_valid ? h->ff_phases : 1;
   const bool rg = extended_contacts(h->kp);
-  if (phases > 1) HIP_TRY(hipMemsetAsync(h->d_ff_count[slot], 0, 2 * sizeof(int), h->side[slot]));
+  if (phases > 1) HIP_TRY(hipMemsetAsync(h->d_ff_count[slot], 0, 2 * sizeof(int), side));
   for (int ph = 0; ph < phases; ++ph) {
     KArgs k = a;
     dim3 grid((unsigned)((a.n + a.ff_lanes - 1) / a.ff_lanes)), block(64);
     if (ph > 0) {  // survivors of phase ph: a compacted list of unknown length, walked by a fixed grid
       k.ff_rec = h->d_ff_list[slot][ph - 1]; k.ff_flag = nullptr; k.ff_src_count = h->d_ff_count[slot] + (ph - 1); k.ff_lanes = 64;
-      int g = h->n / 512; g = g < 64 ? 64 : g;
+      int g = h->n / 256; g = g < 64 ? 64 : g;  // (1 M envs, same box: / 512 9.37, / 256 9.56, / 128 9.41, / 1024 9.19 G env steps/s)
       grid = dim3((unsigned)g);
     }
     if (ph + 1 < phases) { k.ff_next = h->d_ff_list[slot][ph]; k.ff_next_count = h->d_ff_count[slot] + ph; }
     const bool big = h->n >= 131072;
-    const size_t lds = dyn_lds(false, rg, 64);
-    if (rg) { if (big) hipLaunchKernelGGL((tb_ff_kernel<true, true>), grid, block, lds, h->side[slot], k); else hipLaunchKernelGGL((tb_ff_kernel<true, false>), grid, block, lds, h->side[slot], k); }
-    else { if (big) hipLaunchKernelGGL((tb_ff_kernel<false, true>), grid, block, lds, h->side[slot], k); else hipLaunchKernelGGL((tb_ff_kernel<false, false>), grid, block, lds, h->side[slot], k); }
+    const bool esc = big && ph == 0 && phases > 1;
+    const size_t lds = esc && !rg ? sizeof(float) * 64 * 28 : dyn_lds(false, rg, 64);  // (two row slots: load_row<TWO>)
+    if (esc) { if (rg) hipLaunchKernelGGL((tb_ff_kernel<true, true, true>), grid, block, lds, side, k); else hipLaunchKernelGGL((tb_ff_kernel<false, true, true>), grid, block, lds, side, k); }
+    else if (rg) { if (big) hipLaunchKernelGGL((tb_ff_kernel<true, true>), grid, block, lds, side, k); else hipLaunchKernelGGL((tb_ff_kernel<true, false>), grid, block, lds, side, k); }
+    else { if (big) hipLaunchKernelGGL((tb_ff_kernel<false, true>), grid, block, lds, side, k); else hipLaunchKernelGGL((tb_ff_kernel<false, false>), grid, block, lds, side, k); }
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipGetLastError());
   if (h->h_marks && h->marks_on) {  // progress marks: count this fast-forward as finished, in stream order behind it
-    hipLaunchKernelGGL(tb_mark_kernel, dim3(1), dim3(1), 0, h->side[slot], h->h_marks + TB_MAX_MARKS + slot);
+    hipLaunchKernelGGL(tb_mark_kernel, dim3(1), dim3(1), 0, side, h->h_marks + TB_MAX_MARKS + slot);
     HIP_TRY(hipGetLastError());
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     HIP_TRY(hipStreamIsCapturing(s, &st));
     if (st == hipStreamCaptureStatusActive) h->ff_cap[slot]++; else h->ff_eager[slot]++;
   }
-  HIP_TRY(hipEventRecord(h->ev_ff[slot], h->side[slot]));
+  HIP_TRY(hipEventRecord(h->ev_ff[slot], side));
   h->ff_busy[slot] = 1; h->last_slot = slot; h->last_term = term; h->last_sub = substeps;
   return TB_OK;
 }
@@ -1312,7 +1322,7 @@ int tb_create(const TbParams* params, const TbOptions* options, int env_kind, in
   // fast-forward: sort the lanes of large batches by predicted flight length; below 4096 envs a few envs per wave
   h->ff_sort = opt.ff_sort > 0;  // opt-in: pays when flight lengths can be told from the parked state (a trained policy's struck balls)
   // measured on one box: 3 phases +11 % at 1 M envs, +-0 at 256 K, -16 % at 32 K and 4096 (two more kernels in every episode's chain)
-  h->ff_phases = opt.ff_phases >= 1 && opt.ff_phases <= 3 ? opt.ff_phases : (n_envs >= 524288 ? 3 : 1);
+  h->ff_phases = opt.ff_phases >= 1 && opt.ff_phases <= 3 ? opt.ff_phases : (n_envs >= 262144 ? 3 : 1);
   h->ff_lanes = opt.ff_lanes_per_wave;
   if (!h->ff_lanes) { h->ff_lanes = 4; while (h->ff_lanes < 64 && (long long)h->ff_lanes * 64 < n_envs) h->ff_lanes <<= 1; }
   const int nw = words_of(env_kind);
@@ -1728,6 +1738,15 @@ int tb_diag_read_stamps(unsigned long long* out16, int reset) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_diag_cycles), sizeof(unsigned long long) * 16));
   if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_diag_cycles), z, sizeof z)); }
+  return TB_OK;
+}
+#endif
+
+#ifdef TB_DIAG_LANES
+int tb_diag_read_lanes(unsigned long long* out16, int reset) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_diag_lanes), sizeof(unsigned long long) * 16));
+  if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_diag_lanes), z, sizeof z)); }
   return TB_OK;
 }
 #endif

@@ -481,16 +481,21 @@ def test_randomised_engine_parameters_stay_bit_exact(torch, kind):
         env.close()
 
 
-@pytest.mark.parametrize("kind,steps,piped", [(ENV_SWING, 30, False), (ENV_SWING, 30, True), (ENV_TENNIS, 120, False)])
-def test_large_batch_instantiations_in_lockstep_with_the_oracle(torch, kind, steps, piped):
-    """above 131 072 envs tb_create picks other launch shapes and kernel variants (256-thread workgroups, SwingRacket's
-    contact rows back in scratch): 200 003 envs -- ragged against every workgroup size -- against the oracle, through a
-    whole SwingRacket episode end (in-kernel and side-stream fast-forward) and Tennisbot's first arrivals at the racket"""
+@pytest.mark.parametrize("kind,steps,piped,options,flags", [
+    (ENV_SWING, 30, False, None, F_DEFAULT), (ENV_SWING, 30, True, None, F_DEFAULT), (ENV_TENNIS, 120, False, None, F_DEFAULT),
+    (ENV_SWING, 30, True, dict(ff_phases=3), F_DEFAULT), (ENV_SWING, 30, True, dict(ff_phases=2), F_DEFAULT | F_RACKET_GROUND)])
+def test_large_batch_instantiations_in_lockstep_with_the_oracle(torch, kind, steps, piped, options, flags):
+    """above 131 072 envs tb_create picks other launch shapes and kernel variants (128-thread workgroups, the fast-forward
+    instantiation that re-reads its cull planes and shares the outline sweep): 200 003 envs -- ragged against every workgroup
+    size -- against the oracle, through a whole SwingRacket episode end (in-kernel and side-stream fast-forward) and
+    Tennisbot's first arrivals at the racket. With ff_phases > 1 (the default from 512 K envs on) the first phase kernel also
+    hands every env whose ball reaches the racket to the next one BEFORE that substep (substep<ESC>), with and without
+    racket<->court contact."""
     from tennisbot_rl_amd.rollout import RolloutBuffer
     from tennisbot_rl_amd.stepper import BatchedEnv
     n = 200003
-    p = default_params()
-    env = BatchedEnv(kind, n, device="cuda:0", seed=21, params=p, pipeline=piped, track_terminal_obs=False)
+    p = default_params(flags=flags)
+    env = BatchedEnv(kind, n, device="cuda:0", seed=21, params=p, pipeline=piped, track_terminal_obs=False, options=options)
     pf = p.copy(); pf.flags |= F_AUTO_RESET
     ref = OracleBatch(pf, kind, n, seed=21, precision="f32")
     ref.L.tbo_set_threads(ref.h, 16)
@@ -514,6 +519,58 @@ def test_large_batch_instantiations_in_lockstep_with_the_oracle(torch, kind, ste
     got, want = env.counters(), ref.counters()
     assert list(got.values()) == [int(x) for x in want], (got, want)
     assert got["nonfinite_states"] == 0 and got["substeps"] >= n * steps
+    env.close()
+
+
+def test_first_phase_hands_over_what_it_cannot_hold(torch):
+    """the large-batch fast-forward's first phase kernel (substep<ESC>) keeps only two static contact rows (ground; net OR goal) and
+    no racket row at all: an env whose ball is near both the net and a goal, or reaches the racket, must leave for the next phase
+    kernel BEFORE that substep. 131 075 envs one agent step before their episode end, the balls low beside the net with the goal
+    disc right there, on the ground, on goals elsewhere, and next to the falling racket: rewards, obs and the states after the
+    restart bit-exact against the oracle."""
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    n = 131075
+    rng = np.random.default_rng(31)
+    p = default_params()
+    env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=3, params=p, pipeline=True, track_terminal_obs=False, options=dict(ff_phases=2))
+    pf = p.copy(); pf.flags |= F_AUTO_RESET
+    ref = OracleBatch(pf, ENV_SWING, n, seed=3, precision="f32")
+    ref.L.tbo_set_threads(ref.h, 16)
+    env.reset(); ref.reset()
+    r = float(p.ball_radius)
+    which = rng.integers(0, 4, n)
+    side = np.where(rng.random(n) < 0.5, -1.0, 1.0)
+    at_net = np.stack([side * (p.net_half[0] + r + rng.uniform(0.0, 0.08, n)), rng.uniform(-6, 6, n), r + rng.uniform(0.0, 0.2, n)], 1)
+    goal_at_net = np.stack([at_net[:, 0] + rng.uniform(-0.6, 0.6, n), at_net[:, 1] + rng.uniform(-0.6, 0.6, n)], 1)
+    goal_far = np.stack([rng.uniform(-11, -4, n), rng.uniform(-4, 4, n)], 1)
+    ground = np.stack([rng.uniform(-13, 13), rng.uniform(-6, 6), 0.0])[None, :] + np.stack([rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), r + rng.uniform(0.0, 0.3, n)], 1)
+    ang = rng.uniform(0, 2 * np.pi, n); rad = rng.uniform(0, 1.4, n)
+    on_goal = np.stack([goal_far[:, 0] + rad * np.cos(ang), goal_far[:, 1] + rad * np.sin(ang), 0.125 + r + rng.uniform(0.0, 0.3, n)], 1)
+    rp = np.stack([rng.uniform(7, 12, n), rng.uniform(-4, 4, n), rng.uniform(0.8, 1.6, n)], 1)
+    by_racket = rp + np.stack([rng.uniform(-0.08, 0.08, n), rng.uniform(-0.15, 0.15, n), rng.uniform(-0.1, 0.6, n)], 1)
+    bp = np.where(which[:, None] == 0, at_net, np.where(which[:, None] == 1, ground, np.where(which[:, None] == 2, on_goal, by_racket)))
+    goal = np.where(which[:, None] == 0, goal_at_net, goal_far)
+    bv = np.stack([rng.uniform(-3, 3, n) - 2.0 * side * (which == 0), rng.uniform(-2, 2, n), rng.uniform(-3, 0.5, n)], 1)
+    q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    w, d = make_words(ENV_SWING, n, racket_pos=rp, racket_quat=q, racket_vel=rng.uniform(-2, 2, (n, 3)), racket_angvel=rng.uniform(-4, 4, (n, 3)),
+                      ball_pos=bp, ball_vel=bv, ball_angvel=rng.uniform(-20, 20, (n, 3)), goal=goal, spawn_pos=rp, init_dist=rng.uniform(8, 20, n), step_count=25)
+    env.set_state_words(w.view(np.int32), d); ref.set_state_words(w, d)
+    assert env.phase() == 25  # the host still knows the episode phase: the phased fast-forward is the one that runs
+    outs = []
+    for t in range(3):
+        a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
+        obs, rew, done = env.step(torch.from_numpy(a).cuda())
+        o2, r2, d2, s2 = ref.step(a)
+        same(obs.cpu().numpy(), o2, "hand-over obs %d" % t)
+        same(done.cpu().numpy(), d2, "hand-over done %d" % t)
+        outs.append((rew, r2))
+    env.flush()
+    for t, (rew, r2) in enumerate(outs):
+        same(rew.cpu().numpy(), r2, "hand-over reward %d" % t)
+    compare_state(env, ref, "hand-over final state")
+    got, want = env.counters(), ref.counters()
+    assert list(got.values()) == [int(x) for x in want], (got, want)
+    assert got["goal_hits"] > 1000 and got["ball_court_terminations"] > 1000 and got["racket_ball_contact_substeps"] > 1000
     env.close()
 
 
@@ -925,7 +982,8 @@ def test_progress_marks_release_each_chunk_of_one_graph(torch, kind, n_chunks):
             assert torch.equal(ref.raw, buf.raw), "round %d" % rnd
             bad = [c for c in range(n_chunks) if not torch.equal(shadow[c * cb:(c + 1) * cb], buf.raw[c * cb:(c + 1) * cb])]
             assert not bad, "round %d: chunks %s were copied before they were final" % (rnd, bad)
-        assert early == 3
+        # (`early` = rounds in which the host got here before the last mark fired: normally all 3, but a host thread descheduled for a
+        #  millisecond misses it -- timing, not semantics, so it is not asserted)
         assert env.counters() == ref_env.counters()
         env.mark_begin()
         with pytest.raises(StepperError):  # a mark that nobody fires: the wait gives up

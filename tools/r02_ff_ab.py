@@ -59,9 +59,6 @@ def main():
         lib = "/tmp/libtb_old.so"
         subprocess.check_call([hipcc()] + HIPCC_FLAGS + ["-o", lib, os.path.join(ROOT, "tools", "diag", "old_csrc", "tennisbot_rl_amd", "csrc", "tb_stepper.hip")])
         stepper.use_library(lib)
-    if "prev" in sys.argv:  # a library built from the previous commit, shipped with the snapshot (tools/diag/prev/, untracked)
-        from tennisbot_rl_amd import stepper
-        stepper.use_library(os.path.join(ROOT, "tools", "diag", "prev", "libtb_prev.so"))
     extra = [x for x in sys.argv[2:] if x.startswith("-D")]
     if extra:  # extra hipcc flags: build that variant of the library into /tmp and measure it instead (same-box A/B)
         import subprocess
@@ -82,6 +79,10 @@ def main():
     if which == "opts1m":
         for o in (dict(), dict(swing_reg_rows=True), dict(block=128), dict(block=64), dict(swing_reg_rows=True, block=128)):
             out.append(measure(1048576, 104, o, reps=3, flags=flags)); print(json.dumps(out[-1]), flush=True)
+    if which.startswith("n="):  # any batch size, one phase against three
+        n = int(which[2:])
+        for o in (dict(ff_phases=1), dict(ff_phases=3), dict(ff_phases=2)):
+            out.append(measure(n, 104 if n > 32768 else 1040, o, reps=3, flags=flags)); print(json.dumps(out[-1]), flush=True)
     if which in ("all", "large"):
         for o in (dict(ff_phases=1), dict(ff_phases=3)):
             out.append(measure(1048576, 104, o, reps=3, flags=flags)); print(json.dumps(out[-1]), flush=True)
