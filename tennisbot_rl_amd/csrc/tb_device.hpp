@@ -200,8 +200,10 @@ template <bool SCALED, bool RELOAD>
 TB_DEV bool racket_planes(const KParams& P, const float4* hull, vec3 l, float s) {
   const float r = P.ball_radius, thr = P.contact_threshold;
   float sep = -3.0e38f;
-  const float4* cpl = hull + TB_HULL_PLANES;
-  if (RELOAD) asm volatile("" : "+v"(cpl));  // an address the compiler cannot see through: the reads stay here
+  int first = TB_HULL_PLANES;
+  if (RELOAD) asm volatile("" : "+v"(first));  // a row index the compiler cannot see through: the reads stay here (the index, not the
+                                              // pointer: laundering the pointer loses its address space and the reads become flat loads)
+  const float4* cpl = hull + first;
   float cp[3 * TB_N_CULL];
 #pragma unroll
   for (int k = 0; k < 9; ++k) { float4 t = cpl[k]; cp[4 * k] = t.x; cp[4 * k + 1] = t.y; cp[4 * k + 2] = t.z; cp[4 * k + 3] = t.w; }
