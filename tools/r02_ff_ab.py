@@ -80,9 +80,10 @@ def main():
         for o in (dict(), dict(swing_reg_rows=True), dict(block=128), dict(block=64), dict(swing_reg_rows=True, block=128)):
             out.append(measure(1048576, 104, o, reps=3, flags=flags)); print(json.dumps(out[-1]), flush=True)
     if which.startswith("n="):  # any batch size, one phase against three
-        n = int(which[2:])
-        for o in (dict(ff_phases=1), dict(ff_phases=3), dict(ff_phases=2)):
-            out.append(measure(n, 104 if n > 32768 else 1040, o, reps=3, flags=flags)); print(json.dumps(out[-1]), flush=True)
+        n, _, T = which[2:].partition(":")  # n=<envs>[:<rollout steps>]
+        n = int(n)
+        for o in ((dict(),) if T else (dict(ff_phases=1), dict(ff_phases=3), dict(ff_phases=2))):
+            out.append(measure(n, int(T) if T else (104 if n > 32768 else 1040), o, reps=3, flags=flags)); print(json.dumps(out[-1]), flush=True)
     if which in ("all", "large"):
         for o in (dict(ff_phases=1), dict(ff_phases=3)):
             out.append(measure(1048576, 104, o, reps=3, flags=flags)); print(json.dumps(out[-1]), flush=True)
