@@ -74,7 +74,7 @@ def main():
             out.append(measure(4096, 1040, o, flags=flags)); print(json.dumps(out[-1]), flush=True)
     if which == "tennis1m":
         from tennisbot_rl_amd.params import ENV_TENNIS
-        for o in (dict(), dict()):
+        for o in (dict(), dict(tennis_reg_rows=False), dict(), dict(tennis_reg_rows=False), dict(block=256), dict(block=256, tennis_reg_rows=False), dict(block=64, tennis_reg_rows=False)):
             out.append(measure(1048576, 104, o, reps=3, flags=flags, kind=ENV_TENNIS)); print(json.dumps(out[-1]), flush=True)
     if which == "opts1m":
         for o in (dict(), dict(swing_reg_rows=True), dict(block=128), dict(block=64), dict(swing_reg_rows=True, block=128)):
