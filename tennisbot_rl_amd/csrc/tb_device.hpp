@@ -57,6 +57,25 @@ TB_DEV vec3 rotate_inv(quat q, vec3 v) {
   quat c; c.x = -q.x; c.y = -q.y; c.z = -q.z; c.w = q.w;
   return rotate(c, v);
 }
+// Two vectors rotated by the same (inverse) quaternion side by side, as 2-wide packed fp32 (v_pk_mul_f32 / v_pk_fma_f32: two
+// IEEE operations per instruction): component for component the very operations of rotate_inv, in the same order -- same bits.
+// 21 packed instructions for what were 42; +1.1 % at 1 M envs. (The compiler packs much of the rest on its own -- 120 v_pk_* in the
+// large-batch fast-forward. Hand-packing more lost: racket and ball linear updates side by side -4 %, the quaternion product as
+// 8 packed instructions -20 % -- pair moves, and 40 bytes of scratch per lane that throttle the launch.)
+typedef float f2 __attribute__((ext_vector_type(2)));
+TB_DEV f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+TB_DEV void rotate_inv2(quat q, vec3 a, vec3 b, vec3& ra, vec3& rb) {
+  const float ux = -q.x, uy = -q.y, uz = -q.z;
+  const f2 vx = {a.x, b.x}, vy = {a.y, b.y}, vz = {a.z, b.z};
+  const f2 UX = {ux, ux}, UY = {uy, uy}, UZ = {uz, uz}, W = {q.w, q.w}, two = {2.0f, 2.0f};
+  // t = 2 cross(u, v)
+  const f2 tx = two * fma2(UY, vz, -(UZ * vy)), ty = two * fma2(UZ, vx, -(UX * vz)), tz = two * fma2(UX, vy, -(UY * vx));
+  // fma3(w, t, v) + cross(u, t)
+  const f2 rx = fma2(W, tx, vx) + fma2(UY, tz, -(UZ * ty));
+  const f2 ry = fma2(W, ty, vy) + fma2(UZ, tx, -(UX * tz));
+  const f2 rz = fma2(W, tz, vz) + fma2(UX, ty, -(UY * tx));
+  ra = mk(rx.x, ry.x, rz.x); rb = mk(rx.y, ry.y, rz.y);
+}
 TB_DEV quat qmul(quat a, quat b) {
   quat r;
   r.w = FMA(-a.z, b.z, FMA(-a.y, b.y, FMA(-a.x, b.x, a.w * b.w)));
@@ -178,10 +197,10 @@ TB_DEV bool racket_in_reach(const KParams& P, vec3 d, float s) {
 //   racket_cull       per lane: local-frame culls; true = this lane's query needs the exact outline sweep
 //   outline_sweep     WAVE-COOPERATIVE: must be reached by all active lanes together (the caller branches on __any)
 //   racket_finish     per lane: distance, normal and arm from the sweep's result
-template <bool SCALED>
+template <bool SCALED, bool PRE = false>  // PRE: `d` is already rotate_inv(rk.q, ball - racket) (substep<ESC> rotates it together with the spin)
 TB_DEV bool racket_slab(const KParams& P, const Racket& rk, vec3 d, float s, vec3& l, float& ax) {
   const float r = P.ball_radius, thr = P.contact_threshold;
-  l = rotate_inv(rk.q, d);
+  l = PRE ? d : rotate_inv(rk.q, d);
   if (SCALED) l = (1.0f / s) * l;
   ax = fabsf(l.x) - P.racket_half_thick;
   // Local-frame culls before the 38-edge sweep. In a SwingRacket episode the ball starts
@@ -215,9 +234,9 @@ TB_DEV bool racket_planes(const KParams& P, const float4* hull, vec3 l, float s)
 //  it lets through: no difference at 1 M envs. And sharing (2) by the wave -- each past-the-slab lane's point broadcast, 12 lanes testing one plane each, the same
 //  verdict bit for bit. 3 % of the lanes get past the slab, so four wave-substeps in five walk the 12 planes for one or two lanes;
 //  still the shared form was 7 % slower at 1 M envs, same box: its per-lane trips serialise on LDS latency.)
-template <bool SCALED, bool RELOAD = false>
+template <bool SCALED, bool RELOAD = false, bool PRE = false>
 TB_DEV bool racket_cull(const KParams& P, const float4* hull, const Racket& rk, vec3 d, float s, vec3& l, float& ax) {
-  if (!racket_slab<SCALED>(P, rk, d, s, l, ax)) return false;
+  if (!racket_slab<SCALED, PRE>(P, rk, d, s, l, ax)) return false;
 #ifdef TB_DIAG_LANES
   atomicAdd(&g_diag_lanes[12], 1ull);  // lanes past the slab test
 #endif
@@ -890,7 +909,8 @@ TB_DEV void solve_contacts(const KParams& P, Rows<RG>& R, const Manifold& M, int
 }
 
 // ---------------------------------------------------------------- one 1/240 s substep
-TB_DEV void integrate_velocities(const KParams& P, Racket& rk, Ball& b, vec3 Fr, vec3 Tr, vec3 Fb) {
+template <bool PRE = false>  // PRE: wb_pre = rotate_inv(rk.q, rk.w), computed by the caller
+TB_DEV void integrate_velocities(const KParams& P, Racket& rk, Ball& b, vec3 Fr, vec3 Tr, vec3 Fb, vec3 wb_pre = vec3{0.0f, 0.0f, 0.0f}) {
   const float dt = P.dt, g = P.gravity;
   // the three speeds that do not wait for anything are taken first, side by side: a correctly rounded sqrtf is a
   // ~16-instruction dependent chain, and three independent chains in one block interleave where three chains behind
@@ -910,7 +930,7 @@ TB_DEV void integrate_velocities(const KParams& P, Racket& rk, Ball& b, vec3 Fr,
 #endif
     if (active) {
       bool torqued = (Tr.x != 0.0f) | (Tr.y != 0.0f) | (Tr.z != 0.0f);
-      vec3 wb = rotate_inv(rk.q, rk.w), Tb = mk(0.0f, 0.0f, 0.0f);
+      vec3 wb = PRE ? wb_pre : rotate_inv(rk.q, rk.w), Tb = mk(0.0f, 0.0f, 0.0f);
       if (torqued) Tb = rotate_inv(rk.q, Tr);
       vec3 L = mk(P.racket_inertia[0] * wb.x, P.racket_inertia[1] * wb.y, P.racket_inertia[2] * wb.z);
       vec3 gy = cross(wb, L);
@@ -987,13 +1007,18 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
     const bool nc = KIND == TB_ENV_SWING && !(zl >= P.goal_half_len + 1.0e-3f);
     if (nn && nc) return CT_ESCAPE;  // both rows of the shared slot could be wanted
   }
+  vec3 wb0 = mk(0.0f, 0.0f, 0.0f);
   if constexpr (ESC) {
     const vec3 d0 = b.p - rk.p;
     const bool reach = (P.flags & TB_F_RACKET_BALL) && racket_in_reach(P, d0, scale);
+    // the racket-frame ball offset (for the culls) and the body-frame spin (for the velocity update below) are rotations by the
+    // same quaternion: done together, two per packed instruction
+    vec3 l0;
+    rotate_inv2(rk.q, d0, rk.w, l0, wb0);
     if (__any(reach)) {
       vec3 ql = mk(0.0f, 0.0f, 0.0f);
       float qax = 0.0f;
-      if (reach && racket_cull<KIND == TB_ENV_TENNIS, RELOAD>(P, hull, rk, d0, scale, ql, qax)) return CT_ESCAPE;
+      if (reach && racket_cull<KIND == TB_ENV_TENNIS, RELOAD, true>(P, hull, rk, l0, scale, ql, qax)) return CT_ESCAPE;
     }
     TB_STAMP(st, 1);
   }
@@ -1008,7 +1033,8 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
       else nrg = racket_vs_ground(P, hull, rk, scale, M);
     }
   }
-  integrate_velocities(P, rk, b, Fr, Tr, Fb);
+  if constexpr (ESC) integrate_velocities<true>(P, rk, b, Fr, Tr, Fb, wb0);
+  else integrate_velocities(P, rk, b, Fr, Tr, Fb);
   TB_STAMP(st, 3);  // velocity update
   Hit hr, hg, hn, hc;
   hr.hit = false; hg.hit = false; hn.hit = false; hc.hit = false;
