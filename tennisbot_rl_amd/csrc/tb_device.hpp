@@ -197,10 +197,10 @@ TB_DEV bool racket_in_reach(const KParams& P, vec3 d, float s) {
 //   racket_cull       per lane: local-frame culls; true = this lane's query needs the exact outline sweep
 //   outline_sweep     WAVE-COOPERATIVE: must be reached by all active lanes together (the caller branches on __any)
 //   racket_finish     per lane: distance, normal and arm from the sweep's result
-template <bool SCALED, bool PRE = false>  // PRE: `d` is already rotate_inv(rk.q, ball - racket) (substep<ESC> rotates it together with the spin)
-TB_DEV bool racket_slab(const KParams& P, const Racket& rk, vec3 d, float s, vec3& l, float& ax) {
+template <bool SCALED>  // `dl` = rotate_inv(rk.q, ball - racket): substep rotates it together with the racket's spin (rotate_inv2)
+TB_DEV bool racket_slab(const KParams& P, vec3 dl, float s, vec3& l, float& ax) {
   const float r = P.ball_radius, thr = P.contact_threshold;
-  l = PRE ? d : rotate_inv(rk.q, d);
+  l = dl;
   if (SCALED) l = (1.0f / s) * l;
   ax = fabsf(l.x) - P.racket_half_thick;
   // Local-frame culls before the 38-edge sweep. In a SwingRacket episode the ball starts
@@ -234,9 +234,9 @@ TB_DEV bool racket_planes(const KParams& P, const float4* hull, vec3 l, float s)
 //  it lets through: no difference at 1 M envs. And sharing (2) by the wave -- each past-the-slab lane's point broadcast, 12 lanes testing one plane each, the same
 //  verdict bit for bit. 3 % of the lanes get past the slab, so four wave-substeps in five walk the 12 planes for one or two lanes;
 //  still the shared form was 7 % slower at 1 M envs, same box: its per-lane trips serialise on LDS latency.)
-template <bool SCALED, bool RELOAD = false, bool PRE = false>
-TB_DEV bool racket_cull(const KParams& P, const float4* hull, const Racket& rk, vec3 d, float s, vec3& l, float& ax) {
-  if (!racket_slab<SCALED, PRE>(P, rk, d, s, l, ax)) return false;
+template <bool SCALED, bool RELOAD = false>
+TB_DEV bool racket_cull(const KParams& P, const float4* hull, vec3 dl, float s, vec3& l, float& ax) {
+  if (!racket_slab<SCALED>(P, dl, s, l, ax)) return false;
 #ifdef TB_DIAG_LANES
   atomicAdd(&g_diag_lanes[12], 1ull);  // lanes past the slab test
 #endif
@@ -909,8 +909,8 @@ TB_DEV void solve_contacts(const KParams& P, Rows<RG>& R, const Manifold& M, int
 }
 
 // ---------------------------------------------------------------- one 1/240 s substep
-template <bool PRE = false>  // PRE: wb_pre = rotate_inv(rk.q, rk.w), computed by the caller
-TB_DEV void integrate_velocities(const KParams& P, Racket& rk, Ball& b, vec3 Fr, vec3 Tr, vec3 Fb, vec3 wb_pre = vec3{0.0f, 0.0f, 0.0f}) {
+// wb_pre = rotate_inv(rk.q, rk.w), computed by the caller (rotate_inv2)
+TB_DEV void integrate_velocities(const KParams& P, Racket& rk, Ball& b, vec3 Fr, vec3 Tr, vec3 Fb, vec3 wb_pre) {
   const float dt = P.dt, g = P.gravity;
   // the three speeds that do not wait for anything are taken first, side by side: a correctly rounded sqrtf is a
   // ~16-instruction dependent chain, and three independent chains in one block interleave where three chains behind
@@ -930,7 +930,7 @@ TB_DEV void integrate_velocities(const KParams& P, Racket& rk, Ball& b, vec3 Fr,
 #endif
     if (active) {
       bool torqued = (Tr.x != 0.0f) | (Tr.y != 0.0f) | (Tr.z != 0.0f);
-      vec3 wb = PRE ? wb_pre : rotate_inv(rk.q, rk.w), Tb = mk(0.0f, 0.0f, 0.0f);
+      vec3 wb = wb_pre, Tb = mk(0.0f, 0.0f, 0.0f);
       if (torqued) Tb = rotate_inv(rk.q, Tr);
       vec3 L = mk(P.racket_inertia[0] * wb.x, P.racket_inertia[1] * wb.y, P.racket_inertia[2] * wb.z);
       vec3 gy = cross(wb, L);
@@ -1018,7 +1018,7 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
     if (__any(reach)) {
       vec3 ql = mk(0.0f, 0.0f, 0.0f);
       float qax = 0.0f;
-      if (reach && racket_cull<KIND == TB_ENV_TENNIS, RELOAD, true>(P, hull, rk, l0, scale, ql, qax)) return CT_ESCAPE;
+      if (reach && racket_cull<KIND == TB_ENV_TENNIS, RELOAD>(P, hull, l0, scale, ql, qax)) return CT_ESCAPE;
     }
     TB_STAMP(st, 1);
   }
@@ -1033,8 +1033,9 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
       else nrg = racket_vs_ground(P, hull, rk, scale, M);
     }
   }
-  if constexpr (ESC) integrate_velocities<true>(P, rk, b, Fr, Tr, Fb, wb0);
-  else integrate_velocities(P, rk, b, Fr, Tr, Fb);
+  vec3 lp = mk(0.0f, 0.0f, 0.0f);
+  if constexpr (!ESC) rotate_inv2(rk.q, b.p - rk.p, rk.w, lp, wb0);  // (as above; 4096 envs, same box: 612-619 -> 660-694 M env steps/s)
+  integrate_velocities(P, rk, b, Fr, Tr, Fb, wb0);
   TB_STAMP(st, 3);  // velocity update
   Hit hr, hg, hn, hc;
   hr.hit = false; hg.hit = false; hn.hit = false; hc.hit = false;
@@ -1053,7 +1054,7 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
     vec3 ql = mk(0.0f, 0.0f, 0.0f);
     float qax = 0.0f;
     bool need = false;
-    if (near_racket) need = racket_cull<KIND == TB_ENV_TENNIS, RELOAD>(P, hull, rk, d, scale, ql, qax);
+    if (near_racket) need = racket_cull<KIND == TB_ENV_TENNIS, RELOAD>(P, hull, lp, scale, ql, qax);
     // the cooperative form where throughput counts (the large-batch fast-forward instantiation, RELOAD): +4.7 % at 1 M envs, same
     // box; at 4096 envs it shortens the fast-forward (0.47 -> 0.44 ms per lone episode) but its busier waves take more from the
     // step kernels beside them than that gives back (702 -> 655 M env steps/s), and in the loop-free step kernels its ballot masks
