@@ -69,6 +69,9 @@ def main():
         stepper.use_library(lib)
     print("variant", sys.argv[2:], "flags", hex(flags), flush=True)
     out = []
+    if which == "lanes":  # parked envs per fast-forward wave at the headline batch size
+        for o in ({}, dict(ff_lanes_per_wave=32), dict(ff_lanes_per_wave=16), {}, dict(ff_lanes_per_wave=32), dict(ff_lanes_per_wave=48)):
+            out.append(measure(4096, 1040, o, flags=flags)); print(json.dumps(out[-1]), flush=True)
     if which in ("all", "small"):
         for o in ({}, dict(ff_phases=3)):
             out.append(measure(4096, 1040, o, flags=flags)); print(json.dumps(out[-1]), flush=True)
