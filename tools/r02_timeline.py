@@ -7,9 +7,9 @@ import sys
 rows = []
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"]
-    kind = "ff" if "tb_ff_kernel" in k else "step" if "tb_step_kernel" in k else None
+    kind = "ff" if ("tb_ff_kernel" in k or "tb_ff_flight_kernel" in k) else "step" if "tb_step_kernel" in k else None
     if kind:
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), kind, int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0), k.split("tb_ff_kernel")[-1][:20] if kind == "ff" else ""))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), kind, int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0), ("flight" + k.split("tb_ff_flight_kernel")[-1][:8] if "tb_ff_flight_kernel" in k else k.split("tb_ff_kernel")[-1][:20]) if kind == "ff" else ""))
 rows.sort()
 t0 = rows[0][0]
 ffs = [r for r in rows if r[2] == "ff"]
