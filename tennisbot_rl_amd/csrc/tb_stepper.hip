@@ -430,6 +430,10 @@ TB_DEV bool finite3(vec3 v) { return isfinite(v.x) && isfinite(v.y) && isfinite(
 // 1 M-env launch, 16 K waves, spent 200 us queueing on the substep counter alone). The mandatory
 // first substep of a step is not counted per wave: one lane of the launch adds n_envs * T.
 TB_DEV void flush_counters(unsigned long long* counters, const uint32_t* cnt) {
+  uint32_t any = 0u;
+#pragma unroll
+  for (int k = 0; k < TB_N_COUNTERS; ++k) any |= cnt[k];
+  if (__ballot(any != 0u) == 0ull) return;  // nothing happened in this wave (most launches of a small batch: one test instead of nine)
   counters += (size_t)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (TB_COUNTER_SHARDS - 1)) * TB_N_COUNTERS;
 #pragma unroll
   for (int k = 0; k < TB_N_COUNTERS; ++k) {
