@@ -488,7 +488,7 @@ def test_large_batch_instantiations_in_lockstep_with_the_oracle(torch, kind, ste
     """above 131 072 envs tb_create picks other launch shapes and kernel variants (128-thread workgroups, the fast-forward
     instantiation that re-reads its cull planes and shares the outline sweep): 200 003 envs -- ragged against every workgroup
     size -- against the oracle, through a whole SwingRacket episode end (in-kernel and side-stream fast-forward) and
-    Tennisbot's first arrivals at the racket. With ff_phases > 1 (the default from 512 K envs on) the first phase kernel also
+    Tennisbot's first arrivals at the racket. With ff_phases > 1 (the default from 256 K envs on) the first phase kernel also
     hands every env whose ball reaches the racket to the next one BEFORE that substep (substep<ESC>), with and without
     racket<->court contact."""
     from tennisbot_rl_amd.rollout import RolloutBuffer

@@ -46,7 +46,7 @@ def main(d, out):
                 "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "traffic_bytes_per_launch": fb + wb,
                 "traffic_bytes_per_env_step": (fb + wb) / n, "algorithmic_bytes_per_env_step": 267 if env == "swing" else 263}
         # pipelined runs: the fast-forward is its own kernel chain (per 26 agent steps: one launch over all parked envs and, from
-        # 512 K envs on, two launches over the compacted survivors of the budgeted phases, on a smaller fixed grid)
+        # 256 K envs on, two launches over the compacted survivors of the budgeted phases, on a smaller fixed grid)
         ff, nff = per_kernel(os.path.join(d, "%s_FETCH_SIZE_counter_collection.csv" % tag), "FETCH_SIZE", "tb_ff_kernel")
         fw, _ = per_kernel(os.path.join(d, "%s_WRITE_SIZE_counter_collection.csv" % tag), "WRITE_SIZE", "tb_ff_kernel")
         for n in f:
