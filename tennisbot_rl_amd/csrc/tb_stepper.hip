@@ -803,7 +803,7 @@ __global__ void __launch_bounds__(TB_FF_SORT_BLOCK) tb_ff_sort_kernel(KArgs A, f
 //   phase 1: wave w takes the A.ff_lanes records [w L, (w+1) L) of the slot (L < 64: few envs per wave at small batches);
 //   phases 2+: grid-stride over the *A.ff_src_count survivors of the previous phase, 64 per wave.
 // BIG: the instantiation for batches that fill the chip several times over (occupancy counts: cull planes re-read from
-// LDS, see sphere_vs_racket_sweep); below that the loop's latency counts and the planes stay in registers.
+// LDS, see racket_planes, and the outline sweep shared by the wave); below that the loop's latency counts and the planes stay in registers.
 // ESC: the first phase of a BIG fast-forward with a phase behind it also hands over every env whose ball reaches the racket (substep<ESC>).
 // (ESC without the extended contact set is also built for four waves per SIMD: 125 VGPRs -- no spills -- and, with the
 //  two-slot static rows of substep<ESC>, 9.5 KB of LDS per wave: 16 waves per CU instead of 12; 1 M envs, same box: 9.3-9.4 ->
