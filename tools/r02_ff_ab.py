@@ -73,7 +73,7 @@ def main():
         for o in ({}, dict(ff_lanes_per_wave=32), dict(ff_lanes_per_wave=16), {}, dict(ff_lanes_per_wave=32), dict(ff_lanes_per_wave=48)):
             out.append(measure(4096, 1040, o, flags=flags)); print(json.dumps(out[-1]), flush=True)
     if which in ("all", "small"):
-        for o in ({}, dict(ff_phases=3)):
+        for o in ({}, dict(ff_phases=3), dict(ff_phases=2), {}):
             out.append(measure(4096, 1040, o, flags=flags)); print(json.dumps(out[-1]), flush=True)
     if which == "tennis1m":
         from tennisbot_rl_amd.params import ENV_TENNIS
