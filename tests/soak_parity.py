@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Lockstep soak at BASELINE's full batch sizes (run on the GPU box; the suite's largest lockstep case is 200 003 envs):
 N envs stepped `steps` times with random actions, every observation / done / reward / substep counter and the final state
-words compared BIT FOR BIT with the f32 CPU oracle (16 host threads). usage: soak_parity.py <swing|tennis> <n_envs> <steps> [rg]"""
+words compared BIT FOR BIT with the f32 CPU oracle (16 host threads). usage: tests/soak_parity.py <swing|tennis> <n_envs> <steps> [rg]"""
 import os
 import sys
 import time
@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from oracle import OracleBatch  # noqa: E402  (this tool IS a checker, like tests/)
+from oracle import OracleBatch  # noqa: E402  (a checker script kept with the tests: not collected by pytest, run by hand on the GPU box)
 from tennisbot_rl_amd.params import ENV_SWING, ENV_TENNIS, F_AUTO_RESET, F_DEFAULT, F_RACKET_GROUND, STATE_WORDS, default_params  # noqa: E402
 from tennisbot_rl_amd.stepper import BatchedEnv  # noqa: E402
 
