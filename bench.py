@@ -115,10 +115,10 @@ class Rollouts:
     (hipGraph replay or host-issued steps) and ONE way to exchange it (chunked + overlapped, or a single
     all-gather)."""
 
-    def __init__(self, env, buf, torch, dist_on, use_graph, chunks, force_collective=False):
+    def __init__(self, env, buf, torch, dist_on, use_graph, chunks, force_collective=False, exchange=True):
         self.env, self.buf, self.torch, self.dist_on = env, buf, torch, dist_on
         self.force = force_collective
-        self.collective = dist_on or force_collective
+        self.collective = (dist_on and exchange) or force_collective  # exchange=False: replicas only (barriers and clocks still joined)
         self.T = buf.T
         self.chunks = chunks if (self.collective and chunks > 1 and self.T % chunks == 0) else 1
         self.graph = None
@@ -206,6 +206,46 @@ class Rollouts:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
         return time.perf_counter() - t0, ev0.elapsed_time(ev1) * 1e-3
+
+
+def init_distributed(torch, dev, world, rehearsal=False, force_collective=False):
+    """One process group per run: RCCL ("nccl") over xGMI. Returns None, or -- SURVEY.md 8e's fallback, labelled, never silent -- the
+    reason why RCCL cannot be used on this node: the ranks then step their shards as replicas (no rollout exchange) and only
+    join their clocks, over gloo."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist = torch.distributed
+    if force_collective:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group(backend="nccl", device_id=dev, rank=0, world_size=1)
+        return None
+    if rehearsal:
+        dist.init_process_group(backend="gloo")
+        return "rehearsal of the fallback (TB_BENCH_FAIL_NCCL=1)" if os.environ.get("TB_BENCH_FAIL_NCCL") == "1" else None
+    try:
+        if os.environ.get("TB_BENCH_FAIL_NCCL") == "1":
+            raise RuntimeError("TB_BENCH_FAIL_NCCL=1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)  # the first collective builds the communicator: fail here, not inside the timed region
+        if int(probe.item()) != world:
+            raise RuntimeError("all-reduce of ones over %d ranks returned %d" % (world, int(probe.item())))
+        return None
+    except Exception as exc:
+        why = "%s: %s" % (type(exc).__name__, str(exc).replace("\n", " ")[:240])
+        print("RCCL is not usable here (%s): replicas only -- every rank steps its shard, no rollout exchange; the ranks' clocks are "
+              "still joined (gloo)" % why, file=sys.stderr)
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:
+            pass
+        try:
+            dist.init_process_group(backend="gloo")  # same rendezvous store (under the launcher the agent hosts it): a new group gets a new key prefix
+        except Exception:
+            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)  # rank 0 hosted the first store itself and it still holds the port
+            dist.init_process_group(backend="gloo")
+        return why
 
 
 def warm_up(env, buf, warmup, period):
@@ -359,16 +399,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if dist_on or force_collective:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if force_collective:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29531")
-            torch.distributed.init_process_group(backend="nccl", device_id=dev, rank=0, world_size=1)
-        elif rehearsal:
-            torch.distributed.init_process_group(backend="gloo")
-        else:
-            torch.distributed.init_process_group(backend="nccl", device_id=dev)
+    replicas_only = init_distributed(torch, dev, world, rehearsal, force_collective) if (dist_on or force_collective) else None
 
     kind = ENV_SWING if args.env == "swing" else ENV_TENNIS
     period = 26 if kind == ENV_SWING else 1
@@ -400,7 +431,7 @@ def main():
         e0.record(); torch.cuda._sleep(10_000_000); e1.record(); torch.cuda.synchronize(dev)
         cycles_per_us = 10_000_000 / (e0.elapsed_time(e1) * 1e3)
         buf.rehearsal_total_cycles = int(fake_us * cycles_per_us)
-    R = Rollouts(env, buf, torch, dist_on, not args.no_graph, max(1, args.gather_chunks), force_collective)
+    R = Rollouts(env, buf, torch, dist_on, not args.no_graph, max(1, args.gather_chunks), force_collective, exchange=replicas_only is None)
     R.prepare()
     exch = None
     if R.collective:  # measured apart, untimed: what the rollout and the exchange cost on their own
@@ -441,6 +472,8 @@ def main():
         if exch is not None:
             exch["exposed_exchange_ms"] = max(0.0, wall_max / rollouts * 1e3 - exch["rollout_ms"])
             exch["note"] = R.note
+        elif replicas_only is not None:
+            exch = {"ranks_seen": world, "bytes_per_rank": 0, "form": "none: REPLICAS ONLY, the sum of the ranks' own rollouts (RCCL unusable: %s)" % replicas_only}
         gather_note = ("" if not R.collective else ", rollouts all-gathered (RCCL) in %d step-chunks overlapped with the steps (one hipGraph, progress marks watched by the host)" % R.chunks
                        if R.chunks > 1 else ", 1 RCCL all-gather of the rollout at the collect boundary")
         result = {

@@ -94,3 +94,27 @@ def test_bench_workload_constants_match_the_oracle():
     assert bench.ALGO_BYTES["swing"] == {"read": 145, "write": 122} and bench.ALGO_BYTES["tennis"] == {"read": 117, "write": 146}
     rr = bench.reference_record()
     assert rr["episodes"] == 100 and 150 < rr["agent_steps_per_s_overall"] < rr["agent_steps_per_s_collect"] < 200
+
+
+def test_rccl_failure_falls_back_to_labelled_replicas(tmp_path):
+    """SURVEY.md 8e's fallback: where RCCL cannot be initialised bench.py's ranks still join their clocks (gloo, on the launcher's
+    rendezvous store) and report 'replicas only' instead of dying. Two ranks under the driver's launcher; there is no GPU in this
+    container, so the nccl group fails exactly where it would on a broken node."""
+    import subprocess
+    import sys
+    script = tmp_path / "probe.py"
+    script.write_text(
+        "import importlib.util, os, sys\n"
+        "import torch\n"
+        "spec = importlib.util.spec_from_file_location('bench', os.path.join(%r, 'bench.py'))\n"
+        "bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)\n"
+        "why = bench.init_distributed(torch, torch.device('cuda', 0), int(os.environ['WORLD_SIZE']))\n"
+        "assert why, 'an nccl group without GPUs cannot have come up'\n"
+        "t = torch.ones(1); torch.distributed.all_reduce(t); assert int(t.item()) == 2\n"
+        "torch.distributed.barrier(); torch.distributed.destroy_process_group()\n"
+        "print('rank', os.environ['RANK'], 'replicas only:', why[:60])\n" % ROOT)
+    port = 29700 + os.getpid() % 200
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count("replicas only:") == 2
