@@ -1080,12 +1080,14 @@ int ensure_marks(TbHandle* h) {
   return TB_OK;
 }
 
-// small batches: one wave per workgroup so the waves spread over as many CUs as possible (4096 envs = 64 waves -> 64 CUs);
-// large batches: 128-thread workgroups (1 M envs, same box: SwingRacket 9.00 G env steps/s with 128, 8.98 with 64, 8.83 with
-// 256; Tennisbot 18.9 / 18.4 / 18.1-18.4 G)
-int pick_block(int n, const TbOptions& o) {
+// 128-thread workgroups, measured with 64 / 128 / 256 alternated in one process (tools/diag_blocks2.py; M env steps/s):
+//   SwingRacket  4096: 662-679 / 673-684 / 657-682    32768: 4570 / 4760 / 3600    65536: 4900 / 4600 / 4250    131072: 5900 / 5760 / 5450
+//                262144: 7630 / 7630 / 7390            1 M: 8980 / 9000 / 8830
+//   Tennisbot    4096: 667 / 666 / 669    32768: 3736 / 3825 / 3800    65536: 6300 / 6350 / 6430    262144: 13250 / 13450 / 13390    1 M: 18400 / 18900 / 18300
+// i.e. 128 everywhere but for SwingRacket between 64 K and 128 K envs, where one wave per workgroup wins by 2-6 %.
+int pick_block(int kind, int n, const TbOptions& o) {
   if (o.block == 64 || o.block == 128 || o.block == 256) return o.block;
-  return n <= 131072 ? 64 : 128;
+  return kind == TB_ENV_SWING && n >= 49152 && n <= 131072 ? 64 : 128;
 }
 
 KArgs base_args(const TbHandle* h) {
@@ -1316,7 +1318,7 @@ int tb_create(const TbParams* params, const TbOptions* options, int env_kind, in
   TbHandle* h = (TbHandle*)calloc(1, sizeof(TbHandle));
   if (!h) return fail(TB_E_INVAL, "tb_create: out of host memory");
   h->device = device; h->kind = env_kind; h->n = n_envs; h->seed = seed; h->env_id_base = env_id_base;
-  h->params = *params; to_kparams(params, &h->kp, &h->cull_planes[0][0]); h->block = pick_block(n_envs, opt);
+  h->params = *params; to_kparams(params, &h->kp, &h->cull_planes[0][0]); h->block = pick_block(env_kind, n_envs, opt);
   h->opt = opt;
   // Tennisbot, measured in the steady state (envs past their first, synchronised episodes): +28 % at 4096 envs,
   // +8 % at 256 K, +16 % at 1 M, +12 % at 4 M; only the contact-free first episode after a common reset, where the
