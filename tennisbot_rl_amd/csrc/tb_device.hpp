@@ -668,6 +668,7 @@ struct Manifold {
                    //  and made the fast-forward kernel move 3 x its algorithmic bytes)
 };
 constexpr int TB_ROWS_LDS = 14 * 3;  // words per lane
+constexpr int TB_ROWS_LDS_TWO = 14 * 2;  // ... of the kernel that keeps two row slots (load_row<TWO>)
 TB_DEV float& mw(const Manifold& M, int j, int w) { return M.m[(12 * j + w) * M.stride]; }
 TB_DEV vec3 hull_vertex(const KParams& P, const float4* hull, int k, float s) {
   float hx = P.racket_half_thick * s;
@@ -981,6 +982,17 @@ TB_DEV void integrate_pose(const KParams& P, Racket& rk, Ball& b) {
   }
 }
 
+// Per-shape culls in front of the exact static tests (1 mm of slack against rounding: each is implied by the test's own early-out):
+// the ball's lowest point clears the shape's top by the manifold threshold, or -- the net, 1 m high but 19 cm thick and 15 m
+// away from where most balls fly -- its x separation alone does. One z test against the highest shape (the net: every ball
+// below 0.53 m) sent a quarter of all fast-forward substeps through the three tests; the ground's own 4 cm band is two.
+TB_DEV float ball_low_point(const KParams& P, const Ball& b) { return (b.p.z - P.ball_radius) - P.contact_threshold; }
+TB_DEV bool near_ground(const KParams& P, float zlow) { return !(zlow >= P.ground_half[2] + 1.0e-3f); }
+TB_DEV bool near_net(const KParams& P, const Ball& b, float zlow) {
+  return (P.flags & TB_F_NET) && !(zlow >= P.net_half[2] + 1.0e-3f) && !(((fabsf(b.p.x) - P.net_half[0]) - P.ball_radius) >= P.contact_threshold + 1.0e-3f);
+}
+template <int KIND> TB_DEV bool near_goal(const KParams& P, float zlow) { return KIND == TB_ENV_SWING && !(zlow >= P.goal_half_len + 1.0e-3f); }
+
 // returns the contact bits of this substep's manifold (the `len(getContactPoints) > 0` tests)
 //
 // Free flight is the common case (a SwingRacket fast-forward is <= 775 substeps of it), so
@@ -1002,10 +1014,8 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
   TB_STAMP(st, 0);  // everything between two substeps (loop control, env logic)
   constexpr bool TWO = ESC && !RG && !REGROWS;  // the static rows in two LDS slots, see load_row
   if constexpr (TWO) {  // (poses only, like the racket's culls: the very tests the static narrowphase below starts with)
-    const float zl = (b.p.z - P.ball_radius) - P.contact_threshold;
-    const bool nn = (P.flags & TB_F_NET) && !(zl >= P.net_half[2] + 1.0e-3f) && !(((fabsf(b.p.x) - P.net_half[0]) - P.ball_radius) >= P.contact_threshold + 1.0e-3f);
-    const bool nc = KIND == TB_ENV_SWING && !(zl >= P.goal_half_len + 1.0e-3f);
-    if (nn && nc) return CT_ESCAPE;  // both rows of the shared slot could be wanted
+    const float zl = ball_low_point(P, b);
+    if (near_net(P, b, zl) && near_goal<KIND>(P, zl)) return CT_ESCAPE;  // both rows of the shared slot could be wanted
   }
   vec3 wb0 = mk(0.0f, 0.0f, 0.0f);
   if constexpr (ESC) {
@@ -1071,14 +1081,8 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
   if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)__ballot(1)) - 1u) atomicAdd(&g_diag_cycles[13], 1ull);  // wave-substeps
 #endif
   TB_STAMP(st, 1);  // racket narrowphase
-  // Per-shape culls in front of the exact tests (1 mm of slack against rounding: each is implied by the test's own early-out):
-  // the ball's lowest point clears the shape's top by the manifold threshold, or -- the net, 1 m high but 19 cm thick and 15 m
-  // away from where most balls fly -- its x separation alone does. One z test against the highest shape (the net: every ball
-  // below 0.53 m) sent a quarter of all fast-forward substeps through the three tests; the ground's own 4 cm band is two.
-  const float zlow = (b.p.z - P.ball_radius) - P.contact_threshold;
-  bool near_g = !(zlow >= P.ground_half[2] + 1.0e-3f);
-  bool near_n = (P.flags & TB_F_NET) && !(zlow >= P.net_half[2] + 1.0e-3f) && !(((fabsf(b.p.x) - P.net_half[0]) - P.ball_radius) >= P.contact_threshold + 1.0e-3f);
-  bool near_c = KIND == TB_ENV_SWING && !(zlow >= P.goal_half_len + 1.0e-3f);
+  const float zlow = ball_low_point(P, b);
+  bool near_g = near_ground(P, zlow), near_n = near_net(P, b, zlow), near_c = near_goal<KIND>(P, zlow);
 #ifdef TB_DIAG_NO_NARROW
   near_g = false; near_n = false; near_c = false;
 #endif

@@ -1155,7 +1155,7 @@ int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const 
     if (ph + 1 < phases) { k.ff_next = h->d_ff_list[slot][ph]; k.ff_next_count = h->d_ff_count[slot] + ph; }
     const bool big = h->n >= 131072;
     const bool esc = big && ph == 0 && phases > 1;
-    const size_t lds = esc && !rg ? sizeof(float) * 64 * 28 : dyn_lds(false, rg, 64);  // (two row slots: load_row<TWO>)
+    const size_t lds = esc && !rg ? sizeof(float) * 64 * TB_ROWS_LDS_TWO : dyn_lds(false, rg, 64);
     if (esc) { if (rg) hipLaunchKernelGGL((tb_ff_kernel<true, true, true>), grid, block, lds, side, k); else hipLaunchKernelGGL((tb_ff_kernel<false, true, true>), grid, block, lds, side, k); }
     else if (rg) { if (big) hipLaunchKernelGGL((tb_ff_kernel<true, true>), grid, block, lds, side, k); else hipLaunchKernelGGL((tb_ff_kernel<true, false>), grid, block, lds, side, k); }
     else { if (big) hipLaunchKernelGGL((tb_ff_kernel<false, true>), grid, block, lds, side, k); else hipLaunchKernelGGL((tb_ff_kernel<false, false>), grid, block, lds, side, k); }
