@@ -791,3 +791,55 @@ def test_scaled_racket_has_s2_inertia_in_contact_response(scale):
     inertia = np.array([float(np.format_float_positional(np.float32(x), unique=True)) for x in p.racket_inertia]) * scale * scale
     assert np.allclose(inertia * s1["racket_angvel"][0], np.cross(rr, -J), rtol=1e-6, atol=1e-12)
     assert np.abs(s1["racket_angvel"][0]).max() > 1e-3                          # the hit really was off-centre
+
+
+def test_oblique_impacts_on_a_tumbling_racket_exchange_equal_and_opposite_impulses():
+    """256 random hits -- racket at a random attitude with random velocity and spin, ball with spin arriving anywhere on the face at
+    a random angle, friction and restitution acting -- checked against Newton's third law instead of against the solver's own
+    formulas: what the ball gains in linear momentum the racket loses; the racket's angular momentum about its COM (world inertia
+    R I R^T at the pre-step attitude) changes by arm x impulse with the arm the narrowphase reported; the ball's spin changes by
+    (-r n) x impulse. The racket's own free motion (hover force, gyroscopic term) is taken from a twin batch whose balls are far away."""
+    n = 256
+    rng = np.random.default_rng(2024)
+    p = default_params(lin_damp=0.0, ang_damp=0.0, gravity=0.0)
+    r, mb, mr = float(p.ball_radius), 1.0 / float(p.ball_inv_mass), 1.0 / float(p.racket_inv_mass)
+    ib = 1.0 / float(p.ball_inv_inertia)
+    inertia = np.array([float(np.format_float_positional(np.float32(x), unique=True)) for x in p.racket_inertia])  # as the f64 build reads them
+    q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+
+    def rot(q, v):  # (x, y, z, w)
+        u, w = q[:, :3], q[:, 3:4]
+        t = 2 * np.cross(u, v)
+        return v + w * t + np.cross(u, t)
+    rp = np.tile(np.array((10.0, 0.0, 3.0)), (n, 1))
+    side = np.where(rng.random(n) < 0.5, -1.0, 1.0)
+    loc = np.stack([side * (float(p.racket_half_thick) + float(p.hull_margin) + r + 0.0002), rng.uniform(-0.08, 0.08, n), rng.uniform(-0.2, 0.2, n)], 1)
+    bp = rp + rot(q, loc)
+    vin = np.stack([-side * rng.uniform(3, 12, n), rng.uniform(-4, 4, n), rng.uniform(-4, 4, n)], 1)  # racket frame: toward the face, obliquely
+    rv, rw = rng.uniform(-2, 2, (n, 3)), rng.uniform(-6, 6, (n, 3))
+    fields = dict(racket_pos=rp, racket_quat=q, racket_vel=rv, racket_angvel=rw, ball_vel=rv + rot(q, vin), ball_angvel=rng.uniform(-30, 30, (n, 3)), step_count=5)
+    hit, free = OracleBatch(p, ENV_SWING, n, precision="f64"), OracleBatch(p, ENV_SWING, n, precision="f64")
+    w, d = make_words(ENV_SWING, n, ball_pos=bp, **fields); hit.set_state_words(w, d)
+    w, d = make_words(ENV_SWING, n, ball_pos=bp + np.array((0.0, 0.0, 40.0)), **fields); free.set_state_words(w, d)
+    s0 = hit.get_state()
+    arms, normals, on = np.zeros((n, 3)), np.zeros((n, 3)), np.zeros(n, bool)
+    for i in range(n):
+        h, dist, nrm, rr = query_racket(p, s0["racket_pos"][i], s0["racket_quat"][i], s0["ball_pos"][i])
+        on[i] = h  # (points beside the handle miss the outline: those envs are the control group below)
+        if h:
+            arms[i], normals[i] = rr, nrm
+    assert on.sum() > n // 2
+    a = np.zeros((n, 6), np.float32)
+    hit.step(a); free.step(a)
+    s1, f1 = hit.get_state(), free.get_state()
+    J = mb * (s1["ball_vel"] - s0["ball_vel"])                                   # impulse the ball received (its free motion: none)
+    assert np.abs(J[~on]).max(initial=0.0) == 0.0                                 # no contact, no impulse
+    assert np.abs(J[on]).min(axis=0).max() >= 0.0 and (np.einsum("ij,ij->i", J, normals)[on] > 0).all()  # pushed away from the racket, every one
+    assert np.allclose(mr * (s1["racket_vel"] - f1["racket_vel"]), -J, rtol=1e-9, atol=1e-11)
+    R = np.stack([rot(s0["racket_quat"], np.tile(e, (n, 1))) for e in np.eye(3)], 2)  # columns = body axes in the world
+    dw = s1["racket_angvel"] - f1["racket_angvel"]
+    dL = np.einsum("nij,nj->ni", R, inertia * np.einsum("nji,nj->ni", R, dw))   # R I R^T dw
+    assert np.allclose(dL, np.cross(arms, -J), rtol=1e-5, atol=3e-7)  # (typical size 0.04; the attitude is stored as float32: 2e-6 relative)
+    assert np.allclose(ib * (s1["ball_angvel"] - s0["ball_angvel"]), np.cross(-r * normals, J), rtol=1e-5, atol=3e-7)
+    tang = J - np.einsum("ij,ij->i", J, normals)[:, None] * normals
+    assert (np.linalg.norm(tang, axis=1) > 1e-4).sum() > on.sum() // 2            # friction took part
