@@ -528,12 +528,16 @@ def main():
             result["value_refused"] = result["value"]
             result["value"] = None
     if not dist_on and not args.no_sweep and not force_collective:
-        ladder = [(args.env, n) for n in (4096, 32768, 262144, 1048576, 4194304)] if args.sweep else \
-                 [("swing", 4096), ("swing", 1048576), ("tennis", 4096), ("tennis", 1048576)]
+        ladder = [(args.env, n, None) for n in (4096, 32768, 262144, 1048576, 4194304)] if args.sweep else \
+                 [("swing", 4096, None), ("swing", 1048576, None), ("tennis", 4096, None), ("tennis", 1048576, None),
+                  ("swing", 4096, "BASELINE configs[1] as worded: racket-only dynamics, racket<->ball contact off")]
         sweep = []
-        for name, n in ladder:
+        for name, n, variant in ladder:
             k2 = ENV_SWING if name == "swing" else ENV_TENNIS
-            sweep.append(sweep_entry(k2, name, n, flags, k2 == ENV_SWING and not args.no_pipeline, dev, args.seed, not args.no_graph, torch))
+            entry = sweep_entry(k2, name, n, F_NET if variant else flags, k2 == ENV_SWING and not args.no_pipeline, dev, args.seed, not args.no_graph, torch)
+            if variant:
+                entry["variant"] = variant
+            sweep.append(entry)
         if result is not None:
             result["sweep"] = sweep
             if args.sweep:

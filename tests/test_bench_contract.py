@@ -52,8 +52,10 @@ def test_bench_json_contract(extra):
         rr = c["reference_record"]
         assert 100 < rr["agent_steps_per_s_collect"] < 400 and rr["agent_steps_per_s_overall"] < rr["agent_steps_per_s_collect"]
     if "--no-sweep" not in extra:
-        sw = {(e["env"], e["envs"]): e for e in d["sweep"]}
+        sw = {(e["env"], e["envs"]): e for e in d["sweep"] if "variant" not in e}
         assert set(sw) == {("swing", 4096), ("swing", 1048576), ("tennis", 4096), ("tennis", 1048576)}
+        lit = [e for e in d["sweep"] if "variant" in e]  # BASELINE configs[1] as worded (racket<->ball contact off), next to the full-contact headline
+        assert len(lit) == 1 and lit[0]["env"] == "swing" and lit[0]["envs"] == 4096 and "configs[1]" in lit[0]["variant"]
         assert all(0 < e["read_frac"] < e["frac"] < 1 for e in sw.values())
         assert abs(sw[("swing", 1048576)]["substeps_per_agent_step"] / 5.09 - 1) < 0.05
 
