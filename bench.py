@@ -91,6 +91,7 @@ def parse():
     ap.add_argument("--gather-chunks", type=int, default=8, help="multi-rank exchange of the rollout: C > 1 (default 8) = C step-chunks, each chunk's all-gather issued on a high-priority side stream as soon as the chunk is final, overlapped with the later chunks' steps; 1 = ONE all-gather after the rollout")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from the host instead of replaying one captured hipGraph per rollout")
     ap.add_argument("--no-pipeline", action="store_true", help="run the SwingRacket fast-forward inside the step kernel instead of a side stream")
+    ap.add_argument("--settle-seconds", type=float, default=1.5, help="untimed replays of the rollout before the clock starts, for this long: a fresh process replays the SwingRacket graph at 645-655 M env steps/s for its first 0.6-1.3 s about every second time and at 700+ M from then on (tools/diag_ramp.py); counted in warmup_run")
     args = ap.parse_args()
     if args.warmup is None:
         args.warmup = 52 if args.env == "swing" else 1040
@@ -148,6 +149,23 @@ class Rollouts:
         else:
             self.run_once()
         torch.cuda.synchronize(env.device)
+
+    def settle(self, seconds):
+        """untimed replays until `seconds` have passed (all ranks the same number: the count is agreed on through an all-reduce);
+        returns how many rollouts that were"""
+        torch = self.torch
+        if seconds <= 0:
+            return 0
+        t0, k = time.perf_counter(), 0
+        while True:
+            self.run_once()
+            torch.cuda.synchronize(self.env.device)
+            k += 1
+            go = torch.tensor([1.0 if time.perf_counter() - t0 < seconds else 0.0], device=self.env.device)
+            if self.dist_on:
+                torch.distributed.all_reduce(go, op=torch.distributed.ReduceOp.MIN)
+            if go.item() < 0.5 or k >= 10000:
+                return k
 
     def steps_only(self):
         env, buf = self.env, self.buf
@@ -272,6 +290,7 @@ def sweep_entry(kind, env_name, n, flags, pipeline, dev, seed, use_graph, torch)
     warm_up(e2, b2, 26 if kind == ENV_SWING else 1040, 26 if kind == ENV_SWING else 1)  # Tennisbot: steady state, past the first episodes
     r = Rollouts(e2, b2, torch, False, use_graph, 1)
     r.prepare()
+    r.settle(1.0 if n <= 32768 else 0.0)  # small batches: see --settle-seconds
     _, one = r.timed(r.run_once, 1)
     reps = max(1, min(64, int(5e-3 / max(one, 1e-6)) + 1))
     e2.counters_reset()
@@ -433,6 +452,7 @@ def main():
         buf.rehearsal_total_cycles = int(fake_us * cycles_per_us)
     R = Rollouts(env, buf, torch, dist_on, not args.no_graph, max(1, args.gather_chunks), force_collective, exchange=replicas_only is None)
     R.prepare()
+    warmup_run += R.settle(args.settle_seconds) * T_roll + T_roll  # (+ the one untimed rollout of prepare())
     exch = None
     if R.collective:  # measured apart, untimed: what the rollout and the exchange cost on their own
         seen = torch.ones(1, device=dev)

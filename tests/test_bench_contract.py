@@ -37,7 +37,10 @@ def test_bench_json_contract(extra):
     assert abs(d["value"] - 4096 * d["steps_timed"] / (d["ms_per_step"] * d["steps_timed"] * 1e-3)) / d["value"] < 1e-6
     swing = "tennis" not in extra
     if swing:
-        assert d["steps_timed"] % 26 == 0 and d["warmup_run"] == 26 and abs(d["substeps_per_agent_step"] / 5.09 - 1) < 0.05
+        # warm-up: the 20 asked for rounded up to an episode, then whole untimed rollouts (one from prepare(), the rest until
+        # --settle-seconds have passed): the timed rollout starts at an episode start, in the process's steady state
+        assert d["steps_timed"] % 26 == 0 and d["warmup_run"] >= 26 + T and (d["warmup_run"] - 26) % T == 0
+        assert abs(d["substeps_per_agent_step"] / 5.09 - 1) < 0.05
         assert d["timed_region_ms"] >= 5.0 or T == 104
     else:
         assert d["substeps_per_agent_step"] == 1.0
