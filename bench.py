@@ -16,7 +16,9 @@ n_steps = 1100, train_swing.py:49-50) written in place into the rank's rollout b
 of every outstanding fast-forward, and -- with N > 1 -- the exchange of the rollout shards that the PPO
 collect boundary needs (RCCL all-gather over xGMI). `--steps K` is rounded UP to whole rollouts:
 steps_timed = rollout_steps * ceil(K / rollout_steps) (so K = 20 times 1040 steps, not 20 one-substep
-steps between two episode ends); `steps` echoes K. The episode phase is aligned (warm-up rounded up to
+steps between two episode ends), and to as many more whole rollouts as it takes to time --min-timed-ms
+(50 ms: the replay rate of a process wanders by +-5 % over seconds and is 8 % lower during its first
+second about every second time -- hence also --settle-seconds of untimed replays first); `steps` echoes K. The episode phase is aligned (warm-up rounded up to
 whole episodes) and the line carries substeps_per_agent_step; a value whose substeps per step are not
 the workload's (within 5 %) is refused (value = null, "invalid" says why).
 Inputs (state, synthetic U(-1,1) actions from PCG64) are resident in HBM before the timed region.
@@ -91,6 +93,7 @@ def parse():
     ap.add_argument("--gather-chunks", type=int, default=8, help="multi-rank exchange of the rollout: C > 1 (default 8) = C step-chunks, each chunk's all-gather issued on a high-priority side stream as soon as the chunk is final, overlapped with the later chunks' steps; 1 = ONE all-gather after the rollout")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from the host instead of replaying one captured hipGraph per rollout")
     ap.add_argument("--no-pipeline", action="store_true", help="run the SwingRacket fast-forward inside the step kernel instead of a side stream")
+    ap.add_argument("--min-timed-ms", type=float, default=50.0, help="time at least this long: more whole rollouts than --steps asks for if need be (the replay rate of one process wanders by +-5 %% over seconds, tools/diag_ramp.py; one 6.5 ms rollout samples that, eight average it); steps_timed reports what was timed")
     ap.add_argument("--settle-seconds", type=float, default=1.5, help="untimed replays of the rollout before the clock starts, for this long: a fresh process replays the SwingRacket graph at 645-655 M env steps/s for its first 0.6-1.3 s about every second time and at 700+ M from then on (tools/diag_ramp.py); counted in warmup_run")
     args = ap.parse_args()
     if args.warmup is None:
@@ -453,6 +456,13 @@ def main():
     R = Rollouts(env, buf, torch, dist_on, not args.no_graph, max(1, args.gather_chunks), force_collective, exchange=replicas_only is None)
     R.prepare()
     warmup_run += R.settle(args.settle_seconds) * T_roll + T_roll  # (+ the one untimed rollout of prepare())
+    if args.min_timed_ms > 0:  # agreed on by all ranks: the slowest rank's untimed rollout decides
+        one_t = torch.tensor([R.timed(R.run_once, 1)[0]], dtype=torch.float64, device=dev)
+        if dist_on:
+            torch.distributed.all_reduce(one_t, op=torch.distributed.ReduceOp.MAX)
+        warmup_run += T_roll
+        rollouts = max(rollouts, min(256, int(args.min_timed_ms * 1e-3 / max(float(one_t.item()), 1e-6)) + 1))
+        steps_timed = rollouts * T_roll
     exch = None
     if R.collective:  # measured apart, untimed: what the rollout and the exchange cost on their own
         seen = torch.ones(1, device=dev)
