@@ -2,7 +2,10 @@
 """Headline benchmark: env steps/sec (whole node), SwingRacket-v0 @ 4096 envs/GPU.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1: either under the launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py
+  --gpus N ...: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or plain `python bench.py --gpus N`:
+  the process then IS the launcher (self_launch: it starts the N ranks as children before anything touches a GPU,
+  relays rank 0's one JSON line and exits with the children's status).
 
 A "step" is one agent-level env.step() of every env of the batch (BASELINE.json metric):
 one launch of the HIP step kernel over N envs, i.e. 1 physics substep for agent steps 1-25 of an
@@ -155,8 +158,10 @@ class Rollouts:
 
     def settle(self, seconds):
         """untimed replays until `seconds` have passed (all ranks the same number: the count is agreed on through an all-reduce);
-        returns how many rollouts that were"""
+        returns how many rollouts that were. self.first_window_s: wall-clock of the first (up to) 8 of them -- the process's
+        cold rate, reported next to the settled one."""
         torch = self.torch
+        self.first_window_s, self.first_window_rollouts = None, 0
         if seconds <= 0:
             return 0
         t0, k = time.perf_counter(), 0
@@ -164,6 +169,8 @@ class Rollouts:
             self.run_once()
             torch.cuda.synchronize(self.env.device)
             k += 1
+            if k <= 8:
+                self.first_window_s, self.first_window_rollouts = time.perf_counter() - t0, k
             go = torch.tensor([1.0 if time.perf_counter() - t0 < seconds else 0.0], device=self.env.device)
             if self.dist_on:
                 torch.distributed.all_reduce(go, op=torch.distributed.ReduceOp.MIN)
@@ -397,8 +404,99 @@ def cpu_baseline(kind_name, n_envs, seconds, seed, flags):
     return out
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` (N > 1) without a launcher's environment: become the launcher. This process never imports
+    torch and never touches a GPU (a process that has initialised the GPU must not exec or fork GPU children on this pool): it
+    starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <the same arguments>` as a CHILD, waits,
+    prints the one JSON line rank 0 wrote (anything else the ranks put on stdout goes to stderr) and returns the launcher's
+    exit status -- non-zero when any rank failed, and non-zero when no line came back."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL's peer buffers)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in p.stdout.splitlines():
+        try:
+            d = json.loads(ln)
+        except ValueError:
+            d = None
+        if isinstance(d, dict) and "metric" in d:
+            line = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    if p.returncode:
+        print("bench.py: the %d-rank run ended with status %d" % (n, p.returncode), file=sys.stderr)
+        return p.returncode
+    return 0 if line is not None else 1
+
+
+def dry_run(args):
+    """TB_BENCH_DRY_RUN=1 -- for hosts WITHOUT a GPU (the CPU test-suite): everything of an N-rank run except the envs. The ranks
+    rendezvous (gloo), count each other, and exchange a small CPU rollout buffer of the real record layout in both forms of the
+    exchange (8 step-chunks; ONE all-gather), checking the gathered bytes; rank 0 prints a line with the contract's keys whose
+    value is null ("invalid" says why): no env is stepped -- the stepper is HIP-only -- so there is nothing to rate."""
+    import torch
+    from tennisbot_rl_amd.params import ENV_SWING, ENV_TENNIS
+    from tennisbot_rl_amd.rollout import RolloutBuffer
+    dist = torch.distributed
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if os.environ.get("TB_BENCH_DRY_FAIL_RANK") == str(rank):  # (the test of the launcher's exit status)
+        sys.exit(3)
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    seen = torch.ones(1)
+    if world > 1:
+        dist.all_reduce(seen)
+    kind = ENV_SWING if args.env == "swing" else ENV_TENNIS
+    T, N = 208, 64
+    buf = RolloutBuffer(kind, T, N, "cpu")
+    buf.raw.copy_(torch.arange(buf.nbytes, dtype=torch.int64).add_(7919 * (rank + 1)).remainder_(251).to(torch.uint8))
+    forms, ok = {}, True
+    for chunks in sorted({max(1, args.gather_chunks), 1}, reverse=True):
+        t0 = time.perf_counter()
+        if chunks > 1 and world > 1:
+            buf.begin_gather(chunks)
+            for c in range(chunks):
+                buf.gather_chunk(c)
+            shards = buf.finish_gather()
+        else:
+            shards = buf.all_gather()
+        forms["%d" % chunks] = (time.perf_counter() - t0) * 1e3
+        ok = ok and buf.check_gathered() and len(shards) == world
+    okt = torch.tensor([1.0 if ok else 0.0])
+    if world > 1:
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "env steps/sec (whole node), SwingRacket-v0 @4096 envs/GPU", "value": None, "unit": "env steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "dry_run": True,
+            "invalid": "dry run (TB_BENCH_DRY_RUN=1): launcher, rendezvous and rollout exchange over gloo only; no env was stepped (the stepper is HIP-only)",
+            "config": {"workload": "none (dry run): %d ranks x a %d-step x %d-env CPU rollout buffer exchanged over gloo" % (world, T, N),
+                       "parallelism": "env-sharded x%d" % world},
+            "exchange": {"ranks_seen": int(seen.item()), "bytes_per_rank": int(buf.nbytes), "gathered_ok": bool(okt.item() > 0.5),
+                         "exchange_ms_by_chunks": forms}}))
+    return 0 if okt.item() > 0.5 else 1
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))  # before torch is imported: the launcher process never touches a GPU
+    if os.environ.get("TB_BENCH_DRY_RUN") == "1":
+        sys.exit(dry_run(args))
     import torch
     from tennisbot_rl_amd.params import ENV_SWING, ENV_TENNIS, F_DEFAULT, F_NET, F_RACKET_GROUND, default_params
     from tennisbot_rl_amd.rollout import RolloutBuffer
@@ -409,8 +507,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("--gpus %d needs the torch.distributed launcher (one process per GPU)" % args.gpus)
+        print("bench.py: --gpus %d but the launcher started %d rank(s): the line reports n_gpus = %d" % (args.gpus, world, world), file=sys.stderr)
     # TB_BENCH_REHEARSAL=1: several ranks share cuda:0 over gloo -- a one-GPU rehearsal of the
     # multi-rank control flow (the numbers mean nothing; RCCL refuses two ranks on one device)
     rehearsal = os.environ.get("TB_BENCH_REHEARSAL") == "1"
@@ -483,6 +580,21 @@ def main():
         gather_ok = bool(ok.item() > 0.5)
     c = env.counters()
 
+    single = None
+    if R.collective and R.chunks > 1:
+        # north_star's wording of the exchange -- "a single RCCL all-gather at the PPO collect boundary" -- timed the same way next
+        # to the default form: the same rollouts, then ONE all-gather of the whole rollout buffer, nothing overlapped
+        R1 = Rollouts(env, buf, torch, dist_on, R.use_graph, 1, force_collective, exchange=True)
+        R1.prepare()
+        x1_wall, _ = R1.timed(R1.exchange_only, 1)
+        w1, _ = R1.timed(R1.run_once, rollouts)
+        w1_t = torch.tensor([w1, x1_wall], dtype=torch.float64, device=dev)
+        if dist_on:
+            torch.distributed.all_reduce(w1_t, op=torch.distributed.ReduceOp.MAX)
+        single = {"form": "ONE all-gather after the rollout (--gather-chunks 1)", "value": world * N * steps_timed / float(w1_t[0].item()),
+                  "exchange_ms": float(w1_t[1].item()) * 1e3, "ms_per_rollout": float(w1_t[0].item()) / rollouts * 1e3, "rollouts_timed": rollouts}
+        del R1
+
     wall_t = torch.tensor([wall], dtype=torch.float64, device=dev)
     sub_t = torch.tensor([float(c["substeps"]), float(c["nonfinite_states"] + c["lockstep_violations"])], dtype=torch.float64, device=dev)
     if dist_on:
@@ -502,6 +614,9 @@ def main():
         if exch is not None:
             exch["exposed_exchange_ms"] = max(0.0, wall_max / rollouts * 1e3 - exch["rollout_ms"])
             exch["note"] = R.note
+            if single is not None:
+                single["exposed_exchange_ms"] = max(0.0, single["ms_per_rollout"] - exch["rollout_ms"])
+                exch["single_all_gather"] = single
         elif replicas_only is not None:
             exch = {"ranks_seen": world, "bytes_per_rank": 0, "form": "none: REPLICAS ONLY, the sum of the ranks' own rollouts (RCCL unusable: %s)" % replicas_only}
         gather_note = ("" if not R.collective else ", rollouts all-gathered (RCCL) in %d step-chunks overlapped with the steps (one hipGraph, progress marks watched by the host)" % R.chunks
@@ -541,6 +656,13 @@ def main():
         }
         if exch is not None:
             result["exchange"] = exch
+        if replicas_only is not None:  # never to be mistaken for the metric: the rollouts were NOT exchanged
+            result["replicas_only"] = True
+            result["config"]["workload"] += "; REPLICAS ONLY: no rollout exchange (RCCL unusable on this node)"
+        if getattr(R, "first_window_s", None):  # the cold rate of this process, next to the settled one that `value` is
+            result["settle_first_rollouts"] = {"rollouts": R.first_window_rollouts, "steps_per_s": world * N * T_roll * R.first_window_rollouts / R.first_window_s,
+                                               "note": "the first untimed replays of the rollout in this process (rank 0's clock): a fresh process replays ~8 % slower "
+                                                       "for its first second about every second time (profiles/EXPERIMENTS.md); `value` is the settled rate"}
         invalid = []
         want = EXPECTED_SUBSTEPS.get((args.env, bool(args.racket_ground)))
         if args.contact_off or args.magnus or args.spin_max or args.rolling_friction:

@@ -79,6 +79,53 @@ def test_bench_exchange_forms_with_one_rank(chunks):
     assert ("step-chunks" in x["form"]) == (chunks == "8") and not x["note"]
 
 
+def test_bench_launches_its_own_ranks_dry():
+    """`python bench.py --gpus 2` with no launcher around it: the process becomes the launcher (it never imports torch), starts two
+    ranks, relays ONE line and exits with their status. Here, without a GPU, the ranks run the dry leg (TB_BENCH_DRY_RUN=1):
+    rendezvous, head count and the rollout exchange over gloo in both forms; the value is null and says why."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["TB_BENCH_DRY_RUN"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["value"] is None and d["dry_run"] is True and "dry run" in d["invalid"]
+    x = d["exchange"]
+    assert x["ranks_seen"] == 2 and x["gathered_ok"] is True and set(x["exchange_ms_by_chunks"]) == {"8", "1"}
+
+
+def test_bench_launcher_passes_a_failing_rank_on():
+    """a rank that dies must not leave a line that looks like a result: non-zero exit, nothing on stdout"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(TB_BENCH_DRY_RUN="1", TB_BENCH_DRY_FAIL_RANK="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and not out.stdout.strip() and "2-rank run ended with status" in out.stderr
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks_on_one_gpu():
+    """the same entry point with the envs: `python bench.py --gpus 2`, the two ranks sharing cuda:0 over gloo (TB_BENCH_REHEARSAL=1:
+    RCCL refuses two ranks on one device; the rate means nothing, the control flow is the multi-GPU run's): one line, two ranks
+    seen, both exchange forms timed"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["TB_BENCH_REHEARSAL"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "208", "--rollout-steps", "208", "--warmup", "26",
+                          "--settle-seconds", "0.2"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    x = d["exchange"]
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "invalid" not in d and "replicas_only" not in d
+    assert d["config"]["global_envs"] == 8192 and abs(d["substeps_per_agent_step"] / 5.09 - 1) < 0.05
+    assert x["ranks_seen"] == 2 and "step-chunks" in x["form"] and x["exchange_ms"] > 0
+    one = x["single_all_gather"]
+    assert one["value"] > 0 and one["exchange_ms"] > 0 and "ONE all-gather" in one["form"]
+    assert "cpu_baseline" not in d and "sweep" not in d  # N = 1 only
+
+
 def test_bench_workload_constants_match_the_oracle():
     """what bench.py refuses a value against: the random-action SwingRacket workload's substeps per agent step (whole episodes),
     re-measured here on the CPU oracle; and the reference's own wall-clock record it quotes next to the CPU baseline"""
