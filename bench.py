@@ -96,8 +96,8 @@ def parse():
     ap.add_argument("--gather-chunks", type=int, default=8, help="multi-rank exchange of the rollout: C > 1 (default 8) = C step-chunks, each chunk's all-gather issued on a high-priority side stream as soon as the chunk is final, overlapped with the later chunks' steps; 1 = ONE all-gather after the rollout")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from the host instead of replaying one captured hipGraph per rollout")
     ap.add_argument("--no-pipeline", action="store_true", help="run the SwingRacket fast-forward inside the step kernel instead of a side stream")
-    ap.add_argument("--min-timed-ms", type=float, default=50.0, help="time at least this long: more whole rollouts than --steps asks for if need be (the replay rate of one process wanders by +-5 %% over seconds, tools/diag_ramp.py; one 6.5 ms rollout samples that, eight average it); steps_timed reports what was timed")
-    ap.add_argument("--settle-seconds", type=float, default=1.5, help="untimed replays of the rollout before the clock starts, for this long: a fresh process replays the SwingRacket graph at 645-655 M env steps/s for its first 0.6-1.3 s about every second time and at 700+ M from then on (tools/diag_ramp.py); counted in warmup_run")
+    ap.add_argument("--min-timed-ms", type=float, default=50.0, help="time at least this long: more whole rollouts than --steps asks for if need be (the replay rate of one process wanders by +-5 %% over seconds, tools/diag/diag_ramp.py; one 6.5 ms rollout samples that, eight average it); steps_timed reports what was timed")
+    ap.add_argument("--settle-seconds", type=float, default=1.5, help="untimed replays of the rollout before the clock starts, for this long: a fresh process replays the SwingRacket graph at 645-655 M env steps/s for its first 0.6-1.3 s about every second time and at 700+ M from then on (tools/diag/diag_ramp.py); counted in warmup_run")
     args = ap.parse_args()
     if args.warmup is None:
         args.warmup = 52 if args.env == "swing" else 1040

@@ -312,6 +312,10 @@ int tb_policy_rollout(TbHandle *h, int n_steps, const float *weights_dev, const 
  * be reused until tb_flush; results are bit-identical to the unpipelined path.
  * tb_flush makes `stream` wait for all outstanding fast-forwards (tb_get_state, tb_set_state,
  * tb_counters, tb_reset, tb_set_params and tb_destroy do so themselves).
+ * Replays of captured graphs are launched by the caller, not by this library: a caller that mixes eager
+ * pipelined steps with graph replays calls tb_flush on the replaying stream first (the graph's launches bake in
+ * slot indices and cannot wait for an eager fast-forward still reading its slot; stepper.StepGraph.replay does).
+ * At most 2^24 envs per handle with the pipeline on (8 slots of parked records + survivor lists: 4.6 KB per env).
  */
 int tb_set_pipeline(TbHandle *h, int enable);
 int tb_flush(TbHandle *h, void *stream);
@@ -365,7 +369,11 @@ int tb_pipeline_recover(TbHandle *h);
 /* Snapshot / restore the persistent state (the reference never checkpoints env state;
  * SURVEY.md section 5). words: [tb_state_words][N] uint32 bit patterns, done: [N] bytes.
  * `on_device` != 0: the buffers are device memory (async on stream); 0: host memory
- * (the call synchronises the stream before returning). */
+ * (the call synchronises the stream before returning). tb_set_state on a SwingRacket handle
+ * with the pipeline ON also synchronises the stream in the on_device case (it reads the
+ * step-count row back to re-derive the episode phase, see tb_phase) and so cannot be captured
+ * into a graph; with the pipeline off an on_device restore is fully asynchronous. The racket<->court
+ * contact caches are not part of the state words: a restored state starts with empty caches. */
 int tb_get_state(TbHandle *h, uint32_t *words, uint8_t *done, int on_device, void *stream);
 int tb_set_state(TbHandle *h, const uint32_t *words, const uint8_t *done, int on_device, void *stream);
 
@@ -386,6 +394,10 @@ int tb_counters_reset(TbHandle *h, void *stream);
  * accesses. A known byte count in the kernel's own access pattern, used to calibrate the
  * rocprofv3 FETCH_SIZE / WRITE_SIZE counters (MI355X_MICROARCH.md, HBM section). */
 int tb_diag_stream_copy(const uint32_t *src_dev, uint32_t *dst_dev, int n, int rows, int device, void *stream);
+/* Test hook: the nth device allocation inside the NEXT tb_set_pipeline(h, 1) fails with hipErrorOutOfMemory
+ * (0 = off). tb_set_pipeline is all-or-nothing: after a failure the handle is as if the pipeline had never
+ * been enabled (nothing half-allocated for a later step to park into), and a second call starts over. */
+int tb_diag_fail_alloc(int nth);
 
 #ifdef __cplusplus
 }

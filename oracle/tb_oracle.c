@@ -615,12 +615,19 @@ static void setup_ground_row(const Prm *P, RowG *c, const Hit *h, const Sym3 *W,
 int g_stat_first[4096]; int g_stat_n;
 int tbo_debug_stationary(int *out) { memcpy(out, g_stat_first, sizeof(int) * g_stat_n); int n = g_stat_n; g_stat_n = 0; return n; }
 #endif
-/* diagnostics: solver sweeps and solves so far (single-threaded use) */
+/* diagnostics (-DTBO_DIAG builds only): solver sweeps and solves so far. Plain globals: single-threaded use -- they are
+ * not in the default builds, whose env loop runs under `#pragma omp parallel` (a data race, and a cache line every thread's
+ * every solve would fight over inside the cpu_baseline leg). */
+#ifdef TBO_DIAG
 static uint64_t g_sweeps, g_solves;
 void tbo_debug_solver(uint64_t out[2], int reset) { out[0] = g_sweeps; out[1] = g_solves; if (reset) { g_sweeps = 0; g_solves = 0; } }
+#define TBO_COUNT(x) ((x)++)
+#else
+#define TBO_COUNT(x) ((void)0)
+#endif
 static void solve_contacts(const Prm *P, Row *rows, int nrows, RowG *rg, int nrg, Racket *rk, Ball *b) {
   const real r = P->ball_radius;
-  g_solves++;
+  TBO_COUNT(g_solves);
   real jref = R(0); /* largest normal impulse seen in this solve: the scale updates are judged against */
   /* warm start of the racket<->court rows: the cached impulses of the last solve are applied before the first sweep */
   for (int i = 0; i < nrg; ++i) {
@@ -632,7 +639,7 @@ static void solve_contacts(const Prm *P, Row *rows, int nrows, RowG *rg, int nrg
   }
   for (int it = 0; it < P->solver_iters; ++it) {
     int moved = 0;
-    g_sweeps++;
+    TBO_COUNT(g_sweeps);
     for (int i = 0; i < nrows; ++i) {
       Row *c = &rows[i];
       v3 rb = mul3(-r, c->n);

@@ -148,34 +148,9 @@ struct Hit {
 constexpr int CT_RACKET = 1, CT_GROUND = 2, CT_NET = 4, CT_GOAL = 8, CT_RACKET_COURT = 16;
 constexpr int CT_ESCAPE = 32;  // not a contact: substep<ESC> left the env untouched, see there
 
-// In-kernel stamps for the diagnostic build only (-DTB_DIAG_STAMPS, tools/diag_stamps.py):
-// cycles per substep segment, summed per wave into g_diag_cycles. Never compiled into the product.
-#ifdef TB_DIAG_LANES  // lane census of the substep's wave votes (diagnostic builds only): how many lanes ask for what a whole wave then runs
-__device__ unsigned long long g_diag_lanes[16];
-#define TB_LANES(k, pred) do { const unsigned long long m_ = __ballot(pred), a_ = __ballot(1); \
-  if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)a_) - 1u) { atomicAdd(&g_diag_lanes[k], (unsigned long long)__popcll(m_)); if (m_) atomicAdd(&g_diag_lanes[(k) + 1], 1ull); } } while (0)
-#else
-#define TB_LANES(k, pred)
-#endif
-#ifdef TB_DIAG_STAMPS
-__device__ unsigned long long g_diag_cycles[16];
-struct Stamps { unsigned long long t; unsigned int acc[8]; };
-__device__ Stamps g_unused_stamps;
-TB_DEV unsigned long long stamp_now() {
-  unsigned long long t;
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  return t;
-}
-#define TB_STAMP(st, k) do { unsigned long long _n = stamp_now(); (st).acc[k] += (unsigned int)(_n - (st).t); (st).t = _n; } while (0)
-#define TB_STAMP_ARG , Stamps& st
-#define TB_STAMP_PASS , st
-#else
-#define TB_STAMP(st, k) do { } while (0)
-#define TB_STAMP_ARG
-#define TB_STAMP_PASS
-#endif
+// TB_STAMP / TB_LANES / TB_DIAG_*: instrumentation of the diagnostic builds only (cycle stamps, lane census, timing ablations).
+// All of it lives in tb_diag.hpp; in the product build every one of these macros expands to nothing.
+#include "tb_diag.hpp"
 
 // ---------------------------------------------------------------- narrowphase
 // sphere vs racket: prism over the convex (y, z) outline of racket.stl in the COM frame,
@@ -237,17 +212,10 @@ TB_DEV bool racket_planes(const KParams& P, const float4* hull, vec3 l, float s)
 template <bool SCALED, bool RELOAD = false>
 TB_DEV bool racket_cull(const KParams& P, const float4* hull, vec3 dl, float s, vec3& l, float& ax) {
   if (!racket_slab<SCALED>(P, dl, s, l, ax)) return false;
-#ifdef TB_DIAG_LANES
-  atomicAdd(&g_diag_lanes[12], 1ull);  // lanes past the slab test
-#endif
+  TB_LANES_ADD1(12);  // lanes past the slab test
   if (!racket_planes<SCALED, RELOAD>(P, hull, l, s)) return false;
-#ifdef TB_DIAG_STAMPS
-  {
-    unsigned long long m = __ballot(1);
-    atomicAdd(&g_diag_cycles[10], 1ull);                                              // lane-sweeps
-    if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)m) - 1u) atomicAdd(&g_diag_cycles[11], 1ull);  // wave-sweeps
-  }
-#endif
+  TB_DIAG_ADD_EACH(10, 1);    // lane-sweeps
+  TB_DIAG_ADD_LEADER(11, 1);  // wave-sweeps
   return true;
 }
 // The outline sweep of one query point = n_hull dependent trips (two 16-byte LDS reads, ~25 branchy VALU each): ~12 k cycles
@@ -257,10 +225,7 @@ TB_DEV bool racket_cull(const KParams& P, const float4* hull, vec3 dl, float s, 
 // TB_SWEEP_HELPERS-th edge each -- the very same arithmetic per edge -- and the asking lane combines their partial results by
 // the sequential loop's own rule (smallest distance / largest signed distance, lowest edge index on ties), read from the
 // helpers by cross-lane shuffles. Bit-identical to the one-lane loop; ~6 x shorter.
-#ifndef TB_DIAG_SWEEP_HELPERS
-#define TB_DIAG_SWEEP_HELPERS 8
-#endif
-constexpr int TB_SWEEP_HELPERS = TB_DIAG_SWEEP_HELPERS;
+constexpr int TB_SWEEP_HELPERS = TB_DIAG_SWEEP_HELPERS;  // 8 (tb_diag.hpp; 4 / 16 measured: 8.81 / 8.57 G vs 8.80 G env steps/s at 1 M envs)
 struct SweepOut { float best_d2, best_ry, best_rz, max_sd; int deep_edge; bool inside; };
 TB_DEV SweepOut outline_sweep(const float4* hull, int n_hull, bool need, float qy, float qz) {
   const int lane = (int)(threadIdx.x & 63);
@@ -926,9 +891,7 @@ TB_DEV void integrate_velocities(const KParams& P, Racket& rk, Ball& b, vec3 Fr,
     // body-frame round trip (Tennisbot rackets until they are hit; every fast-forward substep
     // of a racket that was never torqued)
     bool active = (rk.w.x != 0.0f) | (rk.w.y != 0.0f) | (rk.w.z != 0.0f) | (Tr.x != 0.0f) | (Tr.y != 0.0f) | (Tr.z != 0.0f);
-#ifdef TB_DIAG_NO_ANGULAR  // timing-only ablation builds (tools/diag_substep.py); results are wrong
-    active = false;
-#endif
+    TB_DIAG_ABLATE_ANGULAR(active);
     if (active) {
       bool torqued = (Tr.x != 0.0f) | (Tr.y != 0.0f) | (Tr.z != 0.0f);
       vec3 wb = wb_pre, Tb = mk(0.0f, 0.0f, 0.0f);
@@ -963,9 +926,7 @@ TB_DEV void integrate_pose(const KParams& P, Racket& rk, Ball& b) {
   rk.p = fma3(dt, rk.v, rk.p);
   b.p = fma3(dt, b.v, b.p);
   float w2 = dot(rk.w, rk.w);
-#ifdef TB_DIAG_NO_ORIENT
-  w2 = 0.0f;
-#endif
+  TB_DIAG_ABLATE_ORIENT(w2);
   if (w2 > 0.0f) {
     float h = 0.5f * dt, hm = 0.5f * P.max_ang_step;
     float z = (h * h) * w2, zc = hm * hm;
@@ -1052,15 +1013,11 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
 
   vec3 d = b.p - rk.p;
   bool near_racket = !ESC && (P.flags & TB_F_RACKET_BALL) && racket_in_reach(P, d, scale);
-#ifdef TB_DIAG_NO_NARROW
-  near_racket = false;
-#endif
+  TB_DIAG_ABLATE_NARROW(near_racket);
   TB_LANES(0, true);          // [0] active lanes, [1] wave-substeps
   TB_LANES(2, near_racket);   // [2] lanes inside the racket's bounding sphere, [3] wave-substeps with one
   if (__any(near_racket)) {
-#ifdef TB_DIAG_STAMPS
-    if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)__ballot(1)) - 1u) atomicAdd(&g_diag_cycles[12], 1ull);  // wave-substeps with a lane in reach
-#endif
+    TB_DIAG_ADD_LEADER(12, 1);  // wave-substeps with a lane in reach
     vec3 ql = mk(0.0f, 0.0f, 0.0f);
     float qax = 0.0f;
     bool need = false;
@@ -1077,15 +1034,11 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
       if (need) hr = racket_finish<KIND == TB_ENV_TENNIS>(P, hull, rk, d, scale, ql, qax, so);
     }
   }
-#ifdef TB_DIAG_STAMPS
-  if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)__ballot(1)) - 1u) atomicAdd(&g_diag_cycles[13], 1ull);  // wave-substeps
-#endif
+  TB_DIAG_ADD_LEADER(13, 1);  // wave-substeps
   TB_STAMP(st, 1);  // racket narrowphase
   const float zlow = ball_low_point(P, b);
   bool near_g = near_ground(P, zlow), near_n = near_net(P, b, zlow), near_c = near_goal<KIND>(P, zlow);
-#ifdef TB_DIAG_NO_NARROW
-  near_g = false; near_n = false; near_c = false;
-#endif
+  TB_DIAG_ABLATE_NARROW(near_g); TB_DIAG_ABLATE_NARROW(near_n); TB_DIAG_ABLATE_NARROW(near_c);
   TB_LANES(6, near_g | near_n | near_c);  // [6] lanes near a static shape, [7] wave-substeps with one
   if (__any(near_g | near_n | near_c)) {
     if (near_g) hg = sphere_vs_box(P, P.ground_half[0], P.ground_half[1], P.ground_half[2], b.p);

@@ -1,0 +1,124 @@
+// tb_diag.hpp -- everything the DIAGNOSTIC builds add to the kernels, behind one include.
+//
+// The product build (tennisbot_rl_amd/build.py) defines none of the TB_DIAG_* macros: every macro
+// below then expands to nothing and the kernels in tb_device.hpp / tb_stepper.hip read -- and
+// compile -- as if this file did not exist. The diagnostic builds are made by tools/diag/*.py into
+// /tmp and loaded through stepper.use_library(); they are never the in-tree libtb_stepper.so.
+//
+//   -DTB_DIAG_STAMPS         s_memtime stamps: cycles per substep segment and per kernel phase, summed per
+//                            wave into g_diag_cycles[16] (tools/diag/diag_stamps*.py, diag_ff_sort.py)
+//   -DTB_DIAG_LANES          lane census of the substep's wave votes into g_diag_lanes[16]
+//                            (tools/diag/diag_lanes.py)
+//   -DTB_DIAG_NO_ANGULAR / _NO_ORIENT / _NO_NARROW
+//                            timing-only ablations (tools/diag/diag_substep.py); RESULTS ARE WRONG
+//   -DTB_DIAG_SWEEP_HELPERS=k  helper lanes of the wave-cooperative outline sweep (default 8)
+//
+// Included twice by design: once near the top of tb_device.hpp (device side, inside namespace tb)
+// and once at the end of tb_stepper.hip with TB_DIAG_HOST_SECTION defined (the C entry points
+// that read the counters back).
+#ifndef TB_DIAG_HOST_SECTION
+#ifndef TB_DIAG_HPP_DEVICE
+#define TB_DIAG_HPP_DEVICE
+
+#ifndef TB_DIAG_SWEEP_HELPERS
+#define TB_DIAG_SWEEP_HELPERS 8
+#endif
+
+// ---- lane census ---------------------------------------------------------------------------
+#ifdef TB_DIAG_LANES
+__device__ unsigned long long g_diag_lanes[16];
+// [k] += lanes for which `pred` holds, [k + 1] += 1 if any does (per wave-substep)
+#define TB_LANES(k, pred) do { const unsigned long long m_ = __ballot(pred), a_ = __ballot(1); \
+  if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)a_) - 1u) { atomicAdd(&g_diag_lanes[k], (unsigned long long)__popcll(m_)); if (m_) atomicAdd(&g_diag_lanes[(k) + 1], 1ull); } } while (0)
+#define TB_LANES_ADD1(k) atomicAdd(&g_diag_lanes[k], 1ull)
+#else
+#define TB_LANES(k, pred)
+#define TB_LANES_ADD1(k)
+#endif
+
+// ---- cycle stamps --------------------------------------------------------------------------
+#ifdef TB_DIAG_STAMPS
+__device__ unsigned long long g_diag_cycles[16];
+struct Stamps { unsigned long long t; unsigned int acc[8]; };
+TB_DEV unsigned long long stamp_now() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+// a lane stops accumulating when its own env leaves the substep loop: the lane that stayed longest has
+// the wave's complete account (every stamp adds the same scalar delta to all lanes still in the loop)
+TB_DEV void diag_flush_stamps(const Stamps& st) {
+  unsigned int mine = 0u;
+  for (int k = 0; k < 6; ++k) mine += st.acc[k];
+  unsigned int best = mine;
+  for (int off = 32; off > 0; off >>= 1) { unsigned int o = __shfl_xor(best, off, 64); best = o > best ? o : best; }
+  const unsigned long long holders = __ballot(mine == best);
+  if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)holders) - 1u)
+    for (int k = 0; k < 6; ++k) atomicAdd(&g_diag_cycles[k], (unsigned long long)st.acc[k]);
+}
+#define TB_STAMP(st, k) do { unsigned long long _n = stamp_now(); (st).acc[k] += (unsigned int)(_n - (st).t); (st).t = _n; } while (0)
+#define TB_STAMP_ARG , Stamps& st
+#define TB_STAMP_PASS , st
+#define TB_DIAG_STAMPS_BEGIN(st) Stamps st; for (int k_ = 0; k_ < 8; ++k_) st.acc[k_] = 0u; st.t = stamp_now()
+#define TB_DIAG_STAMPS_END(st) diag_flush_stamps(st)
+#define TB_DIAG_NOW(var) const unsigned long long var = stamp_now()
+#define TB_DIAG_REALTIME(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()  /* 100 MHz ticks */
+#define TB_DIAG_WAIT_LOADS(live) do { if (live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+// g_diag_cycles[slot] += expr, once per wave (lane 0) / by the wave's first ACTIVE lane
+#define TB_DIAG_ADD_LANE0(slot, expr) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_diag_cycles[slot], (unsigned long long)(expr)); } while (0)
+#define TB_DIAG_ADD_LEADER(slot, expr) do { if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)__ballot(1)) - 1u) atomicAdd(&g_diag_cycles[slot], (unsigned long long)(expr)); } while (0)
+#define TB_DIAG_ADD_EACH(slot, expr) atomicAdd(&g_diag_cycles[slot], (unsigned long long)(expr))
+#else
+#define TB_STAMP(st, k) do { } while (0)
+#define TB_STAMP_ARG
+#define TB_STAMP_PASS
+#define TB_DIAG_STAMPS_BEGIN(st) do { } while (0)
+#define TB_DIAG_STAMPS_END(st) do { } while (0)
+#define TB_DIAG_NOW(var) do { } while (0)
+#define TB_DIAG_REALTIME(var) do { } while (0)
+#define TB_DIAG_WAIT_LOADS(live) do { } while (0)
+#define TB_DIAG_ADD_LANE0(slot, expr) do { } while (0)
+#define TB_DIAG_ADD_LEADER(slot, expr) do { } while (0)
+#define TB_DIAG_ADD_EACH(slot, expr) do { } while (0)
+#endif
+
+// ---- timing-only ablations (results are wrong) ---------------------------------------------
+#ifdef TB_DIAG_NO_ANGULAR
+#define TB_DIAG_ABLATE_ANGULAR(flag) flag = false
+#else
+#define TB_DIAG_ABLATE_ANGULAR(flag) do { } while (0)
+#endif
+#ifdef TB_DIAG_NO_ORIENT
+#define TB_DIAG_ABLATE_ORIENT(w2) w2 = 0.0f
+#else
+#define TB_DIAG_ABLATE_ORIENT(w2) do { } while (0)
+#endif
+#ifdef TB_DIAG_NO_NARROW
+#define TB_DIAG_ABLATE_NARROW(flag) flag = false
+#else
+#define TB_DIAG_ABLATE_NARROW(flag) do { } while (0)
+#endif
+
+#endif  // TB_DIAG_HPP_DEVICE
+#else   // TB_DIAG_HOST_SECTION: inside tb_stepper.hip's extern "C" block, after HIP_TRY / fail()
+
+#ifdef TB_DIAG_STAMPS
+int tb_diag_read_stamps(unsigned long long* out16, int reset) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_diag_cycles), sizeof(unsigned long long) * 16));
+  if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_diag_cycles), z, sizeof z)); }
+  return TB_OK;
+}
+#endif
+#ifdef TB_DIAG_LANES
+int tb_diag_read_lanes(unsigned long long* out16, int reset) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_diag_lanes), sizeof(unsigned long long) * 16));
+  if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_diag_lanes), z, sizeof z)); }
+  return TB_OK;
+}
+#endif
+
+#endif  // TB_DIAG_HOST_SECTION

@@ -1,7 +1,7 @@
 // tb_stepper.hip -- HIP kernels (gfx950 / MI355X) and the C ABI of include/tb_stepper.h.
 //
 // Data layout in HBM (DESIGN.md "Layout"): persistent state is structure-of-arrays along
-// the env index, 32-bit words [W][N] (W = 30 Swing / 27 Tennisbot) plus one done byte [N],
+// the env index, 32-bit words [W][N] (W = 30 Swing / 28 Tennisbot) plus one done byte [N],
 // so lane i of a wave reads word k at base + (k*N + i)*4: every row access is one fully
 // coalesced 256-B wave transaction. Per-call I/O keeps the caller's natural row-major
 // shapes (actions [N][A], obs [N][O]); a lane's 8/24/48-byte row is read/written with
@@ -49,7 +49,7 @@ struct KArgs {
   int n, T;
   // pipelined fast-forward (tb_set_pipeline): a step that starts a SwingRacket fast-forward parks
   // the env's pre-loop state in a slot and resets the env; tb_ff_kernel finishes it on a side stream
-  float4* ff_rec;         // [n][TB_FF_REC] slot: one record per env (park_env)
+  float4* ff_rec;         // [n][ff_rec<RG>()] slot: one record per env (park_env)
   uint8_t* ff_flag;       // [n] 1 = env i is parked in the slot (null for the compacted / sorted lists: their records' own tag says so)
   int ff_lanes;           // tb_ff_kernel: parked envs per wave (a few per wave at small batch sizes)
   float4* ff_next;        // tb_ff_kernel: where envs still running when their budget is spent are compacted to (null = last phase: no budget)
@@ -247,13 +247,17 @@ TB_DEV void reset_env(const KArgs& A, const float4* KP, int i, EnvRegs& e) {
   e.done = TB_DONE_NO;
 }
 
-// Parked SwingRacket envs travel as ONE 128-byte record each (array of structures, unlike the SoA state): the
-// fast-forward kernel hands records to lanes in another order than the env index (sorted by predicted flight
-// length, or a few per wave), and a lane that fetches a whole 128-byte line wastes nothing, where a gather from
-// the SoA rows would pull a 32-byte sector per word.
-#define TB_FF_REC 12  // float4 per record: state (8) + the racket<->court contact cache (4)
+// Parked SwingRacket envs travel as ONE record each (array of structures, unlike the SoA state): the fast-forward kernel
+// hands records to lanes in another order than the env index (compacted survivors, sorted by predicted flight length, or a
+// few per wave), and a lane that fetches whole 128-byte lines wastes nothing, where a gather from the SoA rows would pull a
+// 32-byte sector per word. The record is 8 float4 = 128 B = one line: the env's state. The RG instantiations (racket<->court
+// contact compiled in) append the contact cache: 12 float4 = 192 B. (Until round 3 every record was 192 B: a third of the
+// fast-forward's record traffic was a cache that the default kernels never look at.)
+#define TB_FF_REC_MAX 12  // what the handle allocates per env and slot (the parameter block may switch the extended contacts on later)
+template <bool RG> constexpr int ff_rec() { return RG ? TB_FF_REC_MAX : 8; }
+template <bool RG>
 TB_DEV void park_env(float4* rec, int i, const EnvRegs& e, const Manifold& M) {
-  float4* r = rec + (size_t)i * TB_FF_REC;
+  float4* r = rec + (size_t)i * ff_rec<RG>();
   r[0] = make_float4(e.r.p.x, e.r.p.y, e.r.p.z, e.r.q.x);
   r[1] = make_float4(e.r.q.y, e.r.q.z, e.r.q.w, e.r.v.x);
   r[2] = make_float4(e.r.v.y, e.r.v.z, e.r.w.x, e.r.w.y);
@@ -262,6 +266,7 @@ TB_DEV void park_env(float4* rec, int i, const EnvRegs& e, const Manifold& M) {
   r[5] = make_float4(e.b.w.y, e.b.w.z, e.aux[0], e.aux[1]);
   r[6] = make_float4(e.aux[2], e.aux[3], e.aux[4], e.aux[5]);
   r[7] = make_float4(__int_as_float(e.step_count), __uint_as_float(e.episode), __uint_as_float(1u), __int_as_float(i));
+  if constexpr (!RG) return;
   // (statically indexed: registers; lanes without cached points -- nearly all -- skip the LDS reads)
   uint32_t ids = 0u;
   float imp[3 * TB_MAX_RG];
@@ -280,8 +285,9 @@ TB_DEV void park_env(float4* rec, int i, const EnvRegs& e, const Manifold& M) {
   r[10] = make_float4(imp[6], imp[7], imp[8], imp[9]);
   r[11] = make_float4(imp[10], imp[11], 0.0f, 0.0f);
 }
+template <bool RG>
 TB_DEV void unpark_env(const float4* r, EnvRegs& e, Manifold& M, int& env_index) {
-  {
+  if constexpr (RG) {
     const uint32_t w0 = __float_as_uint(r[8].x), ids = __float_as_uint(r[8].y);
     const float imp[3 * TB_MAX_RG] = {r[8].z, r[8].w, r[9].x, r[9].y, r[9].z, r[9].w, r[10].x, r[10].y, r[10].z, r[10].w, r[11].x, r[11].y};
     M.n = (int)(w0 & 255u); M.deep = (int)(w0 >> 8);
@@ -489,9 +495,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
   const int w_n = SEP ? k_n : A.n, w_nhull = SEP ? k_nhull : A.P.n_hull;
   const bool live = i < w_n;
   EnvRegs e;
-#ifdef TB_DIAG_STAMPS
-  const unsigned long long t_entry = stamp_now();
-#endif
+  TB_DIAG_NOW(t_entry);
   // issue every load this launch depends on back to back -- state rows, the first step's actions,
   // the outline table -- so that their latencies overlap instead of queueing behind the barrier
   float a[NA];
@@ -522,22 +526,16 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
     for (int k = TB_HULL_PLANES + threadIdx.x; k < TB_HULL_LDS; k += blockDim.x) s_hull[k] = w_hull[k];
     __syncthreads();
   }
-#ifdef TB_DIAG_STAMPS
-  if (live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  const unsigned long long t_loaded = stamp_now();
-#endif
+  TB_DIAG_WAIT_LOADS(live);
+  TB_DIAG_NOW(t_loaded);
 
   uint32_t cnt[TB_N_COUNTERS];
 #pragma unroll
   for (int k = 0; k < TB_N_COUNTERS; ++k) cnt[k] = 0u;
 
-#ifdef TB_DIAG_STAMPS
-  Stamps st;
-  for (int k = 0; k < 8; ++k) st.acc[k] = 0u;
-  st.t = stamp_now();
-  const unsigned long long t_kernel0 = st.t;
-  const unsigned long long rt_kernel0 = __builtin_amdgcn_s_memrealtime();
-#endif
+  TB_DIAG_STAMPS_BEGIN(st);
+  TB_DIAG_NOW(t_kernel0);
+  TB_DIAG_REALTIME(rt_kernel0);
   if (live) {
     bool any_reset = false;
     int ns_total = 0;
@@ -558,7 +556,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
           // done = 1 is known now; reward, terminal obs and substep count of this step are written
           // later by tb_ff_kernel from the parked state. The env itself restarts immediately.
           if (A.ff_rec) {
-            park_env(A.ff_rec, i, e, M);
+            park_env<RG>(A.ff_rec, i, e, M);
             A.ff_flag[i] = 1;  // (a byte array of its own: cleared by the fast-forward with one coalesced store per wave, where a 4-byte
                                //  store into each 192-byte record cost a 64-byte memory write per env)
           } else {
@@ -587,35 +585,19 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
       A.reward[row] = rew;
       A.done_out[row] = d ? 1 : 0;
     }
-#ifdef TB_DIAG_STAMPS
-    if ((threadIdx.x & 63) == 0) atomicAdd(&g_diag_cycles[15], stamp_now() - t_loaded);  // compute + output stores issued
-#endif
+    TB_DIAG_ADD_LANE0(15, stamp_now() - t_loaded);  // compute + output stores issued
     if (A.substeps) A.substeps[i] = ns_total;
     store_env<KIND>(A.words, A.done_state, A.n, i, e, any_reset);
     if constexpr (RG) { if (M.n > 0 || had_contacts) store_manifold(A, i, M, had_contacts); }
   }
-#ifdef TB_DIAG_STAMPS
-  if ((threadIdx.x & 63) == 0) atomicAdd(&g_diag_cycles[7], t_loaded - t_entry);  // state + outline loads landed
-#endif
+  TB_DIAG_ADD_LANE0(7, t_loaded - t_entry);  // state + outline loads landed
   flush_counters(A.counters, cnt);
   if (blockIdx.x == 0 && threadIdx.x == 0)  // the first substep of every env in every agent step of this launch
     atomicAdd(&A.counters[6], (unsigned long long)A.n * (unsigned long long)(MULTI ? A.T : 1));
-#ifdef TB_DIAG_STAMPS
-  // a lane stops accumulating when its own env leaves the substep loop: the lane that stayed longest has
-  // the wave's complete account (every stamp adds the same scalar delta to all lanes still in the loop)
-  unsigned int mine = 0u;
-  for (int k = 0; k < 6; ++k) mine += st.acc[k];
-  unsigned int best = mine;
-  for (int off = 32; off > 0; off >>= 1) { unsigned int o = __shfl_xor(best, off, 64); best = o > best ? o : best; }
-  const unsigned long long holders = __ballot(mine == best);
-  if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)holders) - 1u)
-    for (int k = 0; k < 6; ++k) atomicAdd(&g_diag_cycles[k], (unsigned long long)st.acc[k]);
-  if ((threadIdx.x & 63) == 0) {  // per-wave scalars
-    atomicAdd(&g_diag_cycles[8], stamp_now() - t_kernel0);
-    atomicAdd(&g_diag_cycles[9], 1ull);
-    atomicAdd(&g_diag_cycles[14], __builtin_amdgcn_s_memrealtime() - rt_kernel0);  // 100 MHz ticks
-  }
-#endif
+  TB_DIAG_STAMPS_END(st);
+  TB_DIAG_ADD_LANE0(8, stamp_now() - t_kernel0);  // per-wave scalars: cycles in the kernel, waves, 100 MHz ticks
+  TB_DIAG_ADD_LANE0(9, 1);
+  TB_DIAG_ADD_LANE0(14, __builtin_amdgcn_s_memrealtime() - rt_kernel0);
 }
 
 // T agent steps with the policy inside, ONE launch: no launch boundary, no state round trip between the
@@ -670,11 +652,7 @@ __global__ void __launch_bounds__(320) tb_policy_rollout_kernel(KArgs A) {
 #pragma unroll
   for (int k = 0; k < TB_N_COUNTERS; ++k) cnt[k] = 0u;
   bool any_reset = false;
-#ifdef TB_DIAG_STAMPS
-  Stamps st;
-  for (int k = 0; k < 8; ++k) st.acc[k] = 0u;
-  st.t = stamp_now();
-#endif
+  TB_DIAG_STAMPS_BEGIN(st);
   __syncthreads();
   float stdv[NA];
 #pragma unroll
@@ -695,7 +673,7 @@ __global__ void __launch_bounds__(320) tb_policy_rollout_kernel(KArgs A) {
         d = e.done != TB_DONE_NO;
         if (parked) {
           if (A.ff_rec) {
-            park_env(A.ff_rec, i, e, M);
+            park_env<false>(A.ff_rec, i, e, M);
             A.ff_flag[i] = 1;
           } else {
             cnt[8]++;  // lockstep invariant broken (see launch_policy_rollout): reported, never silent
@@ -750,7 +728,9 @@ __global__ void tb_poke_kernel(float* dst, float v) { *dst = v; }
 // sorted workgroups would hold their short-flight waves' slots idle until their longest flight has landed (measured:
 // -20 % at 1 M envs). The source record's parked flag is cleared here; results never depend on which lane runs which env.
 #define TB_FF_SORT_BLOCK 1024
+template <bool RG>
 __global__ void __launch_bounds__(TB_FF_SORT_BLOCK) tb_ff_sort_kernel(KArgs A, float4* sorted) {
+  constexpr int TB_FF_REC = ff_rec<RG>();
   __shared__ int s_hist[256];
   const int lane = threadIdx.x & 63;
   const int src = blockIdx.x * TB_FF_SORT_BLOCK + threadIdx.x;
@@ -810,17 +790,14 @@ __global__ void __launch_bounds__(TB_FF_SORT_BLOCK) tb_ff_sort_kernel(KArgs A, f
 //  10.0 G env steps/s)
 template <bool RG, bool BIG, bool ESC = false>
 __global__ void __launch_bounds__(64, (ESC && !RG) ? 4 : 1) tb_ff_kernel(KArgs A) {
+  constexpr int TB_FF_REC = ff_rec<RG>();
   __shared__ float4 s_hull[TB_HULL_LDS];
   const int lane = threadIdx.x & 63;
   stage_hull(s_hull, A);
   uint32_t cnt[TB_N_COUNTERS];
 #pragma unroll
   for (int k = 0; k < TB_N_COUNTERS; ++k) cnt[k] = 0u;
-#ifdef TB_DIAG_STAMPS
-  Stamps st;
-  for (int k = 0; k < 8; ++k) st.acc[k] = 0u;
-  st.t = stamp_now();
-#endif
+  TB_DIAG_STAMPS_BEGIN(st);
   const int n_src = A.ff_src_count ? *A.ff_src_count : A.n;
   for (int base = blockIdx.x * A.ff_lanes; base < n_src; base += gridDim.x * A.ff_lanes) {
     float4 r[TB_FF_REC];
@@ -838,7 +815,7 @@ __global__ void __launch_bounds__(64, (ESC && !RG) ? 4 : 1) tb_ff_kernel(KArgs A
     init_manifold(M, lane, 64, true);
     int i = 0, ns = 1;  // fresh from the step kernel: it ran the first substep of this agent step
     if (live) {
-      unpark_env(r, e, M, i);
+      unpark_env<RG>(r, e, M, i);
       const uint32_t tag = __float_as_uint(r[7].z);
       if ((tag & 255u) == 2u) ns = (int)(tag >> 8);  // a survivor of an earlier phase: substeps so far
       const vec3 zero = mk(0.0f, 0.0f, 0.0f);
@@ -868,7 +845,7 @@ __global__ void __launch_bounds__(64, (ESC && !RG) ? 4 : 1) tb_ff_kernel(KArgs A
         if (lane == 0) first = atomicAdd(A.ff_next_count, __popcll(m));
         first = __shfl(first, 0, 64);
         if (unfinished) {
-          park_env(A.ff_next, first + __popcll(m & ((1ull << lane) - 1ull)), e, M);
+          park_env<RG>(A.ff_next, first + __popcll(m & ((1ull << lane) - 1ull)), e, M);
           uint32_t* w = reinterpret_cast<uint32_t*>(A.ff_next + (size_t)(first + __popcll(m & ((1ull << lane) - 1ull))) * TB_FF_REC + 7);
           w[2] = 2u | ((uint32_t)ns << 8);
           w[3] = (uint32_t)i;
@@ -877,18 +854,8 @@ __global__ void __launch_bounds__(64, (ESC && !RG) ? 4 : 1) tb_ff_kernel(KArgs A
     }
   }
   flush_counters(A.counters, cnt);
-#ifdef TB_DIAG_STAMPS
-  {  // the lane that stayed in the loop longest has the wave's complete account (see tb_step_kernel)
-    unsigned int mine = 0u;
-    for (int k = 0; k < 6; ++k) mine += st.acc[k];
-    unsigned int best = mine;
-    for (int off = 32; off > 0; off >>= 1) { unsigned int o = __shfl_xor(best, off, 64); best = o > best ? o : best; }
-    const unsigned long long holders = __ballot(mine == best);
-    if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)holders) - 1u)
-      for (int k = 0; k < 6; ++k) atomicAdd(&g_diag_cycles[k], (unsigned long long)st.acc[k]);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&g_diag_cycles[9], 1ull);
-  }
-#endif
+  TB_DIAG_STAMPS_END(st);
+  TB_DIAG_ADD_LANE0(9, 1);
 }
 
 // reset kernel (masked)
@@ -1017,6 +984,7 @@ void to_kparams(const TbParams* p, KParams* k, float* planes) {
 }  // namespace
 
 #define TB_FF_SLOTS 8  // parked-state buffers + side streams: ~2.5 fast-forwards are in flight in steady state
+#define TB_PIPELINE_MAX_ENVS (1 << 24)
 
 struct TbHandle {
   int device, kind, n, block;
@@ -1042,7 +1010,7 @@ struct TbHandle {
   hipStream_t side[TB_FF_SLOTS];  // one stream per slot: consecutive fast-forwards overlap each other too
   const void *last_term, *last_sub;  // shared late-written buffers force ordering between fast-forwards
   int last_slot;
-  float4* d_ff_rec[TB_FF_SLOTS];  // [n][TB_FF_REC] parked records (park_env)
+  float4* d_ff_rec[TB_FF_SLOTS];  // [n][ff_rec<RG>()] parked records (park_env), allocated for TB_FF_REC_MAX
   uint8_t* d_ff_flag[TB_FF_SLOTS];  // [n] parked flags
   float4* d_ff_sorted[TB_FF_SLOTS];  // ff_sort: the slot's records in the order tb_ff_sort_kernel gives them, padded to whole sort groups
   float4* d_ff_list[TB_FF_SLOTS][2];  // survivors of fast-forward phases 1 and 2 (worst case: every env), compacted
@@ -1062,7 +1030,7 @@ struct TbHandle {
   // finished" -- fast-forwards of different episodes overtake each other, one with a ball at rest on a grounded racket
   // runs five times as long as the next): inside the current / latest capture; eagerly since tb_mark_begin
   long long ff_cap[TB_FF_SLOTS], ff_eager[TB_FF_SLOTS];
-  long long mark_ff_before[TB_MAX_MARKS][TB_FF_SLOTS];  // recorded inside a capture: ff_cap at that point; eagerly: -1 - ff_eager
+  long long mark_ff_before[TB_MAX_MARKS][TB_FF_SLOTS];  // fast-forwards enqueued per slot before the mark: inside a capture ff_cap at that point, eagerly ff_eager (mark_in_capture says which)
   int mark_in_capture[TB_MAX_MARKS];
 };
 
@@ -1080,7 +1048,7 @@ int ensure_marks(TbHandle* h) {
   return TB_OK;
 }
 
-// 128-thread workgroups, measured with 64 / 128 / 256 alternated in one process (tools/diag_blocks2.py; M env steps/s):
+// 128-thread workgroups, measured with 64 / 128 / 256 alternated in one process (tools/diag/diag_blocks2.py; M env steps/s):
 //   SwingRacket  4096: 662-679 / 673-684 / 657-682    32768: 4570 / 4760 / 3600    65536: 4900 / 4600 / 4250    131072: 5900 / 5760 / 5450
 //                262144: 7630 / 7630 / 7390            1 M: 8980 / 9000 / 8830
 //   Tennisbot    4096: 667 / 666 / 669    32768: 3736 / 3825 / 3800    65536: 6300 / 6350 / 6430    262144: 13250 / 13450 / 13390    1 M: 18400 / 18900 / 18300
@@ -1135,7 +1103,8 @@ int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const 
   if (h->last_slot >= 0 && h->last_slot != slot && ((term && term == h->last_term) || (substeps && substeps == h->last_sub)))
     HIP_TRY(hipStreamWaitEvent(side, h->ev_ff[h->last_slot], 0));
   if (sort) {
-    hipLaunchKernelGGL(tb_ff_sort_kernel, dim3((unsigned)groups), dim3(TB_FF_SORT_BLOCK), 0, side, a, h->d_ff_sorted[slot]);
+    if (extended_contacts(h->kp)) hipLaunchKernelGGL(tb_ff_sort_kernel<true>, dim3((unsigned)groups), dim3(TB_FF_SORT_BLOCK), 0, side, a, h->d_ff_sorted[slot]);
+    else hipLaunchKernelGGL(tb_ff_sort_kernel<false>, dim3((unsigned)groups), dim3(TB_FF_SORT_BLOCK), 0, side, a, h->d_ff_sorted[slot]);
     HIP_TRY(hipGetLastError());
     a.ff_rec = h->d_ff_sorted[slot]; a.ff_flag = nullptr; a.n = groups * TB_FF_SORT_BLOCK;  // (outputs are addressed by the env index each record carries)
   }
@@ -1239,7 +1208,7 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
     // phase known and not the 26th step: every env has step_count = phase < 25 (all were reset
     // together and every library call that could break lockstep clears phase_valid), so no lane
     // can start a fast-forward in this launch and the lean kernel needs no slot. Should the
-    // invariant ever be broken, the lane is counted in counters[7] instead of being dropped silently.
+    // invariant ever be broken, the lane is counted in counters[8] (lockstep violations) instead of being dropped silently.
     a.ff_rec = nullptr;
     TB_LAUNCH_STEP(TB_ENV_SWING, true, false);
   } else TB_LAUNCH_STEP(TB_ENV_SWING, false, false);
@@ -1352,6 +1321,8 @@ int tb_create(const TbParams* params, const TbOptions* options, int env_kind, in
   return TB_OK;
 }
 
+static void release_pipeline(TbHandle* h);
+
 int tb_destroy(TbHandle* h) {
   if (!h) return TB_OK;
   DeviceGuard g(h->device);
@@ -1363,6 +1334,15 @@ int tb_destroy(TbHandle* h) {
   if (h->d_counters) (void)hipFree(h->d_counters);
   if (h->d_mani) (void)hipFree(h->d_mani);
   if (h->d_mflag) (void)hipFree(h->d_mflag);
+  release_pipeline(h);
+  if (h->h_marks) (void)hipHostFree(h->h_marks);
+  free(h);
+  return TB_OK;
+}
+
+// the pipeline's streams, events and buffers: all of them, or none (what release_pipeline leaves behind is the state of a
+// handle whose pipeline was never enabled)
+static void release_pipeline(TbHandle* h) {
   for (int k = 0; k < TB_FF_SLOTS; ++k) {
     if (h->d_ff_rec[k]) (void)hipFree(h->d_ff_rec[k]);
     if (h->d_ff_flag[k]) (void)hipFree(h->d_ff_flag[k]);
@@ -1372,11 +1352,40 @@ int tb_destroy(TbHandle* h) {
     if (h->d_ff_count[k]) (void)hipFree(h->d_ff_count[k]);
     if (h->ev_step[k]) (void)hipEventDestroy(h->ev_step[k]);
     if (h->ev_ff[k]) (void)hipEventDestroy(h->ev_ff[k]);
-  }
-  for (int k = 0; k < TB_FF_SLOTS; ++k)
     if (h->side[k]) (void)hipStreamDestroy(h->side[k]);
-  if (h->h_marks) (void)hipHostFree(h->h_marks);
-  free(h);
+    h->d_ff_rec[k] = nullptr; h->d_ff_flag[k] = nullptr; h->d_ff_sorted[k] = nullptr; h->d_ff_list[k][0] = nullptr; h->d_ff_list[k][1] = nullptr;
+    h->d_ff_count[k] = nullptr; h->ev_step[k] = nullptr; h->ev_ff[k] = nullptr; h->side[k] = nullptr; h->ff_busy[k] = 0;
+  }
+  h->pipeline = 0;
+}
+
+// test hook (tb_diag_fail_alloc): the n-th device allocation of the next tb_set_pipeline fails with hipErrorOutOfMemory
+static int g_fail_alloc_countdown = 0;
+static hipError_t pipeline_malloc(void** p, size_t bytes) {
+  if (g_fail_alloc_countdown > 0 && --g_fail_alloc_countdown == 0) { *p = nullptr; return hipErrorOutOfMemory; }
+  return hipMalloc(p, bytes);
+}
+
+static int alloc_pipeline(TbHandle* h) {
+  const size_t wb = sizeof(float4) * (size_t)TB_FF_REC_MAX * h->n;
+  for (int k = 0; k < TB_FF_SLOTS; ++k) {
+    HIP_TRY(hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
+    HIP_TRY(pipeline_malloc((void**)&h->d_ff_rec[k], wb));
+    HIP_TRY(hipMemset(h->d_ff_rec[k], 0, wb));
+    HIP_TRY(pipeline_malloc((void**)&h->d_ff_flag[k], (size_t)h->n));
+    HIP_TRY(hipMemset(h->d_ff_flag[k], 0, (size_t)h->n));
+    for (int ph = 0; ph + 1 < h->ff_phases; ++ph) HIP_TRY(pipeline_malloc((void**)&h->d_ff_list[k][ph], wb));
+    HIP_TRY(pipeline_malloc((void**)&h->d_ff_count[k], 2 * sizeof(int)));
+    HIP_TRY(hipMemset(h->d_ff_count[k], 0, 2 * sizeof(int)));
+    if (h->ff_sort) {
+      const size_t sb = sizeof(float4) * (size_t)TB_FF_REC_MAX * TB_FF_SORT_BLOCK * ((h->n + TB_FF_SORT_BLOCK - 1) / TB_FF_SORT_BLOCK);
+      HIP_TRY(pipeline_malloc((void**)&h->d_ff_sorted[k], sb));
+      HIP_TRY(hipMemset(h->d_ff_sorted[k], 0, sb));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_step[k], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_ff[k], hipEventDisableTiming));
+  }
+  HIP_TRY(hipDeviceSynchronize());
   return TB_OK;
 }
 
@@ -1385,28 +1394,23 @@ int tb_set_pipeline(TbHandle* h, int enable) {
   DeviceGuard g(h->device);
   if (enable && !h->side[0]) {
     if (h->kind != TB_ENV_SWING) return fail(TB_E_UNSUPPORTED, "tb_set_pipeline: only SwingRacket-v0 has a fast-forward to overlap");
-    const size_t wb = sizeof(float4) * (size_t)TB_FF_REC * h->n;
+    // 8 slots x (records + up to two survivor lists) x 192 B per env: 4.6 KB per env, 77 GB at the cap (of 288)
+    if (h->n > TB_PIPELINE_MAX_ENVS) return fail(TB_E_INVAL, "tb_set_pipeline: more than 2^24 envs (the parked-record slots would not fit next to the state)");
     h->last_slot = -1;
-    for (int k = 0; k < TB_FF_SLOTS; ++k) {
-      HIP_TRY(hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
-      HIP_TRY(hipMalloc((void**)&h->d_ff_rec[k], wb));
-      HIP_TRY(hipMemset(h->d_ff_rec[k], 0, wb));
-      HIP_TRY(hipMalloc((void**)&h->d_ff_flag[k], (size_t)h->n));
-      HIP_TRY(hipMemset(h->d_ff_flag[k], 0, (size_t)h->n));
-      for (int ph = 0; ph + 1 < h->ff_phases; ++ph) HIP_TRY(hipMalloc((void**)&h->d_ff_list[k][ph], wb));
-      HIP_TRY(hipMalloc((void**)&h->d_ff_count[k], 2 * sizeof(int)));
-      HIP_TRY(hipMemset(h->d_ff_count[k], 0, 2 * sizeof(int)));
-      if (h->ff_sort) {
-        const size_t sb = sizeof(float4) * (size_t)TB_FF_REC * TB_FF_SORT_BLOCK * ((h->n + TB_FF_SORT_BLOCK - 1) / TB_FF_SORT_BLOCK);
-        HIP_TRY(hipMalloc((void**)&h->d_ff_sorted[k], sb));
-        HIP_TRY(hipMemset(h->d_ff_sorted[k], 0, sb));
-      }
-      HIP_TRY(hipEventCreateWithFlags(&h->ev_step[k], hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&h->ev_ff[k], hipEventDisableTiming));
+    if (int rc = alloc_pipeline(h)) {
+      // all or nothing: a half-built pipeline would pass the `side[0]` test above on the next call and the step kernel would
+      // then park into a null slot. fail() has already recorded what went wrong.
+      release_pipeline(h);
+      (void)hipGetLastError();
+      return rc;
     }
-    HIP_TRY(hipDeviceSynchronize());
   }
   h->pipeline = enable ? 1 : 0;
+  return TB_OK;
+}
+
+int tb_diag_fail_alloc(int nth) {
+  g_fail_alloc_countdown = nth > 0 ? nth : 0;
   return TB_OK;
 }
 
@@ -1692,10 +1696,12 @@ int tb_set_state(TbHandle* h, const uint32_t* words, const uint8_t* done, int on
   if (done) HIP_TRY(hipMemcpyAsync(h->d_done, done, (size_t)h->n, k, s));
   else HIP_TRY(hipMemsetAsync(h->d_done, 0, (size_t)h->n, s));
   HIP_TRY(hipMemsetAsync(h->d_mflag, 0, (size_t)h->n, s));  // the racket<->court contact caches are not part of the state words
-  if (h->kind == TB_ENV_SWING) {
+  if (h->kind == TB_ENV_SWING && h->pipeline) {
     // the pipelined kernels need to know which launch ends the episodes: the injected envs are in lockstep again
     // when every one is running (done = 0) at the same step count s < 26 -- then the phase is s (e.g. a checkpoint
-    // of a training run restored into a fresh handle). Costs one small device-to-host copy; this call is rare.
+    // of a training run restored into a fresh handle). Costs one small device-to-host copy and a stream
+    // synchronisation (so: not capturable, and not asynchronous even with on_device); only paid with the pipeline on,
+    // the one mode that uses the phase -- without it the call stays fully asynchronous for on_device buffers.
     const size_t n = (size_t)h->n;
     uint32_t* steps = (uint32_t*)malloc(n * sizeof(uint32_t));
     uint8_t* dn = (uint8_t*)malloc(n);
@@ -1739,23 +1745,10 @@ int tb_diag_stream_copy(const uint32_t* src_dev, uint32_t* dst_dev, int n, int r
   return TB_OK;
 }
 
-#ifdef TB_DIAG_STAMPS
-int tb_diag_read_stamps(unsigned long long* out16, int reset) {
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_diag_cycles), sizeof(unsigned long long) * 16));
-  if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_diag_cycles), z, sizeof z)); }
-  return TB_OK;
-}
-#endif
-
-#ifdef TB_DIAG_LANES
-int tb_diag_read_lanes(unsigned long long* out16, int reset) {
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_diag_lanes), sizeof(unsigned long long) * 16));
-  if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_diag_lanes), z, sizeof z)); }
-  return TB_OK;
-}
-#endif
+// (diagnostic builds only: tb_diag_read_stamps / tb_diag_read_lanes)
+#define TB_DIAG_HOST_SECTION
+#include "tb_diag.hpp"
+#undef TB_DIAG_HOST_SECTION
 
 int tb_counters_reset(TbHandle* h, void* stream) {
   if (!h) return fail(TB_E_INVAL, "tb_counters_reset: null handle");

@@ -104,6 +104,8 @@ def load_library():
     L.tb_mark_enable.restype = i32
     L.tb_diag_stream_copy.argtypes = [vp, vp, i32, i32, i32, vp]
     L.tb_diag_stream_copy.restype = i32
+    L.tb_diag_fail_alloc.argtypes = [i32]
+    L.tb_diag_fail_alloc.restype = i32
     for f in ("tb_create", "tb_destroy", "tb_set_params", "tb_reset", "tb_step", "tb_rollout", "tb_get_state",
               "tb_set_state", "tb_counters", "tb_counters_reset", "tb_obs_dim", "tb_act_dim", "tb_state_words"):
         getattr(L, f).restype = i32
@@ -153,6 +155,11 @@ class StepGraph:
             if now != self.phase:
                 raise StepperError("this graph was captured at episode phase %d and can only be replayed from there; the envs are at phase %d "
                                    "(captured steps %% 26 = %d; or steps were taken outside the graph)" % (self.phase, now, self.n_steps % 26))
+        if env.pipeline:
+            # eager pipelined steps may still have fast-forwards running on the handle's side streams; the captured launches bake
+            # in slot indices and hold no wait on them (the capture began with every slot idle). Up to 8 hipStreamWaitEvent
+            # calls, nothing when no slot is busy.
+            env.flush()
         self.graph.replay()
         _check(env.L, env.L.tb_phase_advance(env._h, self.n_steps), "tb_phase_advance")
 

@@ -1043,3 +1043,74 @@ def test_abandoned_capture_leaves_the_env_usable(torch):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _ABANDONED_CAPTURE_CASE], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "survived" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_replay_orders_itself_behind_unflushed_eager_fast_forwards(torch):
+    """StepGraph.replay() after eager pipelined steps that were NOT flushed: the captured launches bake in slot indices and carry
+    no wait on the handle's side streams, so replay() itself must join the eager fast-forwards still reading those slots. Racket<->court
+    contact on: its fast-forwards run for milliseconds, eight episodes leave all eight slots busy when the replay starts."""
+    from tennisbot_rl_amd.rollout import RolloutBuffer
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    n, T, E = 2048, 52, 8 * 26
+    p = default_params(flags=F_DEFAULT | F_RACKET_GROUND)
+    rng = np.random.default_rng(77)
+    acts = torch.from_numpy(rng.uniform(-1, 1, (T, n, 6)).astype(np.float32)).cuda()
+    eager = torch.from_numpy(rng.uniform(-1, 1, (E, n, 6)).astype(np.float32)).cuda()
+    a = BatchedEnv(ENV_SWING, n, seed=3, params=p, pipeline=True, track_terminal_obs=False)
+    b = BatchedEnv(ENV_SWING, n, seed=3, params=p)
+    ba, bb = RolloutBuffer(ENV_SWING, T, n, "cuda:0").bind(a), RolloutBuffer(ENV_SWING, T, n, "cuda:0")
+    ea = RolloutBuffer(ENV_SWING, E, n, "cuda:0").bind(a)
+    ba.actions.copy_(acts); bb.actions.copy_(acts); ea.actions.copy_(eager)
+    a.reset(); b.reset()
+    g = a.capture(lambda: ba.step_range(a, 0, T))
+    ea.step_range(a, 0, E)  # eight episodes, eight fast-forwards in flight, no flush
+    g.replay()
+    eb_rew = []
+    for t in range(E):
+        eb_rew.append(b.step(eager[t])[1])
+    for t in range(T):
+        bb.step_into(b, t)
+    a.flush()
+    torch.cuda.synchronize()
+    assert torch.equal(ea.rewards, torch.stack(eb_rew)), "terminal rewards of the eager episodes were lost or garbled"
+    assert torch.equal(ba.obs, bb.obs) and torch.equal(ba.rewards, bb.rewards) and torch.equal(ba.dones, bb.dones)
+    ca, cb = a.counters(), b.counters()
+    assert ca == cb and ca["lockstep_violations"] == 0
+    a.close(); b.close()
+
+
+def test_set_pipeline_failure_is_all_or_nothing(torch):
+    """a device allocation that fails in the middle of tb_set_pipeline leaves NOTHING behind: the handle steps on unpipelined
+    (no kernel parks into a half-built slot), and a second tb_set_pipeline builds the pipeline from scratch -- both in lockstep
+    with the oracle"""
+    env, ref = make_pair(torch, ENV_SWING, 1000, seed=21)
+    rng = np.random.default_rng(5)
+    same(env.reset().cpu().numpy(), ref.reset(), "reset obs")
+    L, h = env.L, env._h
+    for nth in (1, 2, 5, 17):  # first slot's records, its flags, second slot's records, somewhere in the fourth slot
+        assert L.tb_diag_fail_alloc(nth) == 0
+        rc = L.tb_set_pipeline(h, 1)
+        assert rc == 2, rc  # hipErrorOutOfMemory, passed through
+        assert b"pipeline_malloc" in L.tb_last_error() or b"hipErrorOutOfMemory" in L.tb_last_error() or b"out of memory" in L.tb_last_error().lower()
+        for t in range(27):  # through an episode end: the fast-forward runs inside the step kernel, as without a pipeline
+            a = rng.uniform(-1, 1, (1000, 6)).astype(np.float32)
+            obs, rew, done = env.step(torch.from_numpy(a).cuda())
+            o2, r2, d2, s2 = ref.step(a)
+            same(done.cpu().numpy(), d2, "done"); same(rew.cpu().numpy(), r2, "reward"); same(obs.cpu().numpy(), o2, "obs")
+            same(env.last_substeps().cpu().numpy(), s2, "substeps")
+    L.tb_diag_fail_alloc(0)
+    same(env.reset().cpu().numpy(), ref.reset(), "reset obs")  # lockstep again: the pipelined kernels know the phase
+    assert L.tb_set_pipeline(h, 1) == 0
+    env.pipeline, env._term = True, None
+    rews, want = [], []
+    for t in range(54):
+        a = rng.uniform(-1, 1, (1000, 6)).astype(np.float32)
+        obs, rew, done = env.step(torch.from_numpy(a).cuda())
+        o2, r2, d2, s2 = ref.step(a)
+        same(done.cpu().numpy(), d2, "piped done"); same(obs.cpu().numpy(), o2, "piped obs")
+        rews.append(rew); want.append(r2)
+    env.flush()
+    same(torch.stack(rews).cpu().numpy(), np.stack(want), "piped rewards")
+    c = env.counters()
+    assert c["lockstep_violations"] == 0 and list(c.values()) == [int(x) for x in ref.counters()]
+    env.close()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Workgroup size of the step kernels, 64 vs 128 vs 256 threads, alternated in one process: both envs, 4096 / 32768 / 131072 envs."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tennisbot_rl_amd.params import ENV_SWING, ENV_TENNIS
 from tennisbot_rl_amd.rollout import RolloutBuffer

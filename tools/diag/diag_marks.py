@@ -3,7 +3,7 @@
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tennisbot_rl_amd.params import ENV_SWING, ENV_TENNIS
 from tennisbot_rl_amd.rollout import RolloutBuffer

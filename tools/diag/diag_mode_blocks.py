@@ -2,7 +2,7 @@
 """Per-process rate mode vs workgroup shape: in ONE process (one mode) the SwingRacket graph at 4096 envs with the step kernel
 as 64 one-wave workgroups (default), 32 of two waves, 16 of four; and the non-pipelined kernel (fast-forward inside the step)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tennisbot_rl_amd.params import ENV_SWING
 from tennisbot_rl_amd.rollout import RolloutBuffer

@@ -2,7 +2,7 @@
 """Is the SwingRacket graph's rate mode a property of the graph INSTANCE? One env, the same 1040-step rollout captured eight
 times; median rate of 12 replays of each instance, twice round."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tennisbot_rl_amd.params import ENV_SWING
 from tennisbot_rl_amd.rollout import RolloutBuffer

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-process rate mode vs the stream the graph is captured and launched on: argv[1] = 'null' (torch's default stream) or 'own'."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tennisbot_rl_amd.params import ENV_SWING
 from tennisbot_rl_amd.rollout import RolloutBuffer

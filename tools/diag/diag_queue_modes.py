@@ -3,7 +3,7 @@
 one after the other with 0..k dummy streams created in between (HIP maps streams onto its hardware queues round-robin); per env
 the median rate of 20 replays of the 1040-step rollout graph at 4096 envs (GPU box)."""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tennisbot_rl_amd.params import ENV_SWING
 from tennisbot_rl_amd.rollout import RolloutBuffer

@@ -4,12 +4,12 @@
 Builds variants of libtb_stepper.so with TB_DIAG_* macros into /tmp, puts every env in a
 state that runs the full 776-substep fast-forward without contacts (ball far off the court)
 and reports microseconds per substep of a full wave. Variant results are WRONG by
-construction; only the times matter. Usage: python tools/diag_substep.py [n_envs]"""
+construction; only the times matter. Usage: python tools/diag/diag_substep.py [n_envs]"""
 import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402

@@ -7,7 +7,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 
@@ -46,19 +46,17 @@ def measure(n, T, opts, reps=5, flags=None, kind=None):
 
 
 def main():
-    """usage: r02_ff_ab.py <small|large|all> [old] [norg]   old = build tools/diag/old_csrc (the library before racket<->court
-    contact became default) into /tmp and measure that; norg = clear TB_F_RACKET_GROUND"""
+    """usage: r02_ff_ab.py <small|large|all|lanes|tennis1m|opts1m|n=<envs>[:<steps>]> [lib=<path to another build of libtb_stepper.so>] [rg] [-D...]
+    lib= measures that build instead of the in-tree one (e.g. an earlier commit's, built into /tmp: the same-box A/B); rg sets
+    TB_F_RACKET_GROUND; -D... builds that variant of the present sources into /tmp and measures it"""
     from tennisbot_rl_amd.params import F_NET, F_RACKET_BALL, F_DEFAULT
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     from tennisbot_rl_amd.params import F_RACKET_GROUND
     flags = F_DEFAULT | (F_RACKET_GROUND if "rg" in sys.argv else 0)
-    if "old" in sys.argv:
-        import subprocess
+    other = [x[4:] for x in sys.argv[2:] if x.startswith("lib=")]
+    if other:
         from tennisbot_rl_amd import stepper
-        from tennisbot_rl_amd.build import HIPCC_FLAGS, hipcc
-        lib = "/tmp/libtb_old.so"
-        subprocess.check_call([hipcc()] + HIPCC_FLAGS + ["-o", lib, os.path.join(ROOT, "tools", "diag", "old_csrc", "tennisbot_rl_amd", "csrc", "tb_stepper.hip")])
-        stepper.use_library(lib)
+        stepper.use_library(other[0])
     extra = [x for x in sys.argv[2:] if x.startswith("-D")]
     if extra:  # extra hipcc flags: build that variant of the library into /tmp and measure it instead (same-box A/B)
         import subprocess

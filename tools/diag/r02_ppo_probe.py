@@ -2,7 +2,7 @@
 """PPO on the batched SwingRacket envs: collection rate at the trainer's default rollout (104 steps = 4 episodes) and at the
 reference's n_steps = 1100 (train_swing.py:49-50), update time, and a short learning curve."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from tennisbot_rl_amd.ppo import PPOTrainer

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """kernel-trace helper: one SwingRacket env batch, a few eager episodes with a given TbOptions set (run under rocprofv3)"""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from tennisbot_rl_amd.params import ENV_SWING, F_DEFAULT, F_RACKET_GROUND, default_params
