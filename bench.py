@@ -343,6 +343,22 @@ def open_loop_rate(kind, N, flags, pipeline, dev, seed, torch):
             "note": "tb_rollout: up to 26 agent steps per launch, actions known up front (not an RL loop; shows the cost of the per-step launch boundary)"}
 
 
+def parity_text():
+    """what the line may claim about parity, and -- from the committed sensitivity table (tools/pin_sensitivity.py ->
+    profiles/r03_pin_sensitivity.json) -- which recalled engine constants the reference's one PyBullet record constrains at all"""
+    txt = ("bit-exact vs the CPU restatement; PyBullet parity UNPINNED at trajectory level (the reference ships no tests or golden vectors, PyBullet is "
+           "not available offline); pinned statistically by what the reference's ppo_swing.zip holds: the returns of its last 100 PyBullet episodes "
+           "(two-sample KS + double-bonus count, with a leave-half-out selection test) and its critic's predictions (state-conditional calibration on 16 384 episodes)")
+    try:
+        st = json.load(open(os.path.join(ROOT, "profiles", "r03_pin_sensitivity.json")))["status"]
+        con = sorted(k for k, v in st.items() if v != "free")
+        free = sorted(k for k, v in st.items() if v == "free")
+        txt += "; constants that record CONSTRAINS: " + ", ".join(con) + "; constants it leaves FREE (recalled from Bullet, not checkable here): " + ", ".join(free)
+    except Exception:
+        txt += "; (sensitivity table profiles/r03_pin_sensitivity.json not found)"
+    return txt + " (DESIGN.md section 2)"
+
+
 def reference_record():
     """what the reference itself recorded: wall-clock of the last 100 PyBullet training episodes inside its shipped
     ppo_swing.zip (exported as data by tools/export_reference_episode_stats.py). Not this host, not this workload shape
@@ -652,7 +668,7 @@ def main():
                          "read_only": {"achieved": ab["read"] * N / launch_s / 1e9, "frac": ab["read"] * N / launch_s / 1e9 / HBM_PEAK_GBS,
                                        "algorithmic_bytes_per_env_step": ab["read"], "note": "the HBM-READ roofline north_star words its 40 % target on"},
                          "note": "latency-bound at this batch size, not bandwidth-bound (see sweep / DESIGN.md)"},
-            "parity": "bit-exact vs the CPU restatement; PyBullet parity unpinned at trajectory level (the reference ships no tests or golden vectors, PyBullet is not available offline), pinned statistically by the 100 PyBullet episodes recorded in the reference's ppo_swing.zip (DESIGN.md section 2)",
+            "parity": parity_text(),
         }
         if exch is not None:
             result["exchange"] = exch

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TB_ABI_VERSION 3
+#define TB_ABI_VERSION 4
 
 /* library error codes (negative); positive return values are hipError_t */
 #define TB_OK 0
@@ -109,8 +109,11 @@ typedef struct TbParams {
   float dt;                 /* 1/240, racket.py:24 */
   float inv_dt;             /* 240 */
   float gravity;            /* 9.81, swingracket_env.py:154 setGravity(0,0,-9.81) */
-  float lin_damp;           /* k1 = k2 = 0.04, force -m v (k1 + k2 |v|) */
-  float ang_damp;           /* 0.04 */
+  float lin_damp;           /* k1 = 0.04 of the damping force -m v (k1 + k2 |v|) */
+  float ang_damp;           /* 0.04, the same form on the angular momentum */
+  float lin_damp_quad;      /* k2 (ABI v4). Bullet's multibody path uses ONE damping value for both terms (k1 = k2 = 0.04): a field of its
+                             * own so that the speed-proportional term can be switched off on its own (profiles/r03_pin_sensitivity.md) */
+  float ang_damp_quad;
   float max_ang_step;       /* pi/4 per substep rotation clamp */
   float rest_vel_threshold; /* 0.2 m/s: below it restitution is 0 */
   float erp;                /* contact ERP (Baumgarte): 0.08 = PyBullet's world default (Bullet's library default is 0.2) */
@@ -159,8 +162,8 @@ typedef struct TbParams {
 typedef struct TbHandle TbHandle;
 
 /*
- * Kernel-selection options (ABI v3; they replace the TB_BLOCK / TB_TENNIS_REG_ROWS / TB_SWING_REG_ROWS
- * environment variables of v2). Every field: 0 = let the library choose from the batch size. None of
+ * Kernel-selection options (since ABI v3; they replace the TB_BLOCK / TB_TENNIS_REG_ROWS / TB_SWING_REG_ROWS
+ * environment variables of v2; v4 names the former `reserved` field and changes the policy blob's fragment order). Every field: 0 = let the library choose from the batch size. None of
  * them changes any result -- the variants are bit-identical (tests/test_gpu_parity.py runs them all) --
  * only which instantiation of the same arithmetic is launched.
  */
@@ -173,7 +176,7 @@ typedef struct TbOptions {
   int32_t ff_sort;          /* order parked envs by their ball's ballistic flight estimate before the fast-forward: 1 on (auto: off --
                              * with random actions the flight lengths are decided by events inside the loop, not by the parked state) */
   int32_t ff_phases;        /* the fast-forward as 1, 2 or 3 kernels: budgeted loop, then its compacted survivors (auto: 3 from 262144 envs on, else 1; from 131072 envs on the first of several also hands over every env whose ball reaches the racket) */
-  int32_t reserved;
+  int32_t policy_slices;    /* tb_policy_rollout: 16-env slices per workgroup, 1 (three waves per 16 envs) or 3 (seven waves per 48 envs) (auto: 1 up to 4096 envs) */
 } TbOptions;
 
 /* library identity / shape queries (host only, no device touched) */
@@ -266,15 +269,15 @@ int tb_step_sequence(TbHandle *h, int n_steps, const float *actions_dev, float *
  * * eps, clipped to the action space before the env sees it, as SB3 does. Per env i:
  *   obs_in_dev [N][O] the observation acted on  ->  actions_dev [N][A] (clipped), raw_actions_dev [N][A],
  *   logp_dev [N] (log-probability of the raw sample), value_dev [N]; then exactly tb_step on those actions.
- * The towers run on the matrix cores in exact fp32 (v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain),
+ * The towers run on the matrix cores in fp32 (v_mfma_f32_16x16x4_f32, 16 envs per wave),
  * one layer's accumulator tile feeding the next layer's operand registers directly; tanh is evaluated
  * as 1 - 2/(exp(2x)+1) on the hardware exp2/rcp units (absolute error < 3e-7).
  * weights_dev: tb_policy_floats(kind) floats, 16-byte aligned, in the fragment order the kernel loads:
- * per tower (pi, then vf) its hidden layers and its head (padded to 32 outputs), each layer as
- *   bias tiles     [ceil(out/32)][2][16]: value (t, h, r) = bias[32t + (r&3) + 8(r>>2) + 4h]
- *   weight frags   [ceil(out/32)][pairs][2][32]: value (t, p, h, j) = W[out 32t + j][in k(p, h)]
- * with k(p, h) = 2p + h for the first layer and k(16u + r, h) = 32u + (r&3) + 8(r>>2) + 4h after it
- * (W = torch's nn.Linear.weight, zero beyond `out`); then log_std[A] padded to a multiple of 4.
+ * per tower (pi, then vf) its hidden layers and its head (padded to 16 outputs), each layer as
+ *   bias tiles     [ceil(out/16)][4][4]: value (t, g, r) = bias[16t + 4g + r]
+ *   weight frags   [ceil(out/16)][chunks][4][16]: value (t, c, g, j) = W[out 16t + j][in k(c, g)]
+ * with k(c, g) = 4c + g for the first layer (zero beyond the observation) and k(4u + r, g) = 16u + 4g + r
+ * after it (W = torch's nn.Linear.weight, zero beyond `out`); then log_std[A] padded to a multiple of 4.
  * tennisbot_rl_amd/ppo.py pack_policy() is the reference packer. eps is drawn in-kernel from Philox
  * keyed by (noise_seed, global env id, episode, step), so
  * a captured graph draws fresh noise on every replay; deterministic != 0 uses the mean.
@@ -394,6 +397,10 @@ int tb_counters_reset(TbHandle *h, void *stream);
  * accesses. A known byte count in the kernel's own access pattern, used to calibrate the
  * rocprofv3 FETCH_SIZE / WRITE_SIZE counters (MI355X_MICROARCH.md, HBM section). */
 int tb_diag_stream_copy(const uint32_t *src_dev, uint32_t *dst_dev, int n, int rows, int device, void *stream);
+/* Diagnostics: `waves` one-wave workgroups that only stay resident (s_sleep) for `microseconds` on `stream`: the footprint of
+ * the fast-forward waves without their arithmetic (tools/diag/r03_idle_probe.py: do resident waves shorten the dispatch gap between
+ * the dependent launches of a graph?). */
+int tb_diag_idle(int waves, int microseconds, int device, void *stream);
 /* Test hook: the nth device allocation inside the NEXT tb_set_pipeline(h, 1) fails with hipErrorOutOfMemory
  * (0 = off). tb_set_pipeline is all-or-nothing: after a failure the handle is as if the pipeline had never
  * been enabled (nothing half-allocated for a later step to park into), and a second call starts over. */

@@ -141,7 +141,7 @@ static inline real uniform(real lo, real span, uint32_t u) { return lo + span * 
  * such as 4*9.81 - m g = 0 (swingracket_env.py:77) hold exactly, as they do in the
  * reference's float64 PyBullet build. */
 typedef struct {
-  real dt, inv_dt, gravity, lin_damp, ang_damp, max_ang_step, rest_vel_threshold, erp, contact_threshold;
+  real dt, inv_dt, gravity, lin_damp, ang_damp, lin_damp_quad, ang_damp_quad, max_ang_step, rest_vel_threshold, erp, contact_threshold;
   int solver_iters; uint32_t flags; real solver_tol;
   real racket_inv_mass, racket_inertia[3], racket_inv_inertia[3], racket_com[3], racket_half_thick, hull_margin, hull_bound_radius;
   real ball_inv_mass, ball_inv_inertia, ball_radius, magnus_k, ball_spin_max;
@@ -173,7 +173,7 @@ static void prm_from(Prm *Q, const TbParams *P) {
   memset(Q, 0, sizeof *Q);
   Q->inv_dt = W(P->inv_dt);
   Q->dt = W(P->dt);
-  Q->gravity = W(P->gravity); Q->lin_damp = W(P->lin_damp); Q->ang_damp = W(P->ang_damp);
+  Q->gravity = W(P->gravity); Q->lin_damp = W(P->lin_damp); Q->ang_damp = W(P->ang_damp); Q->lin_damp_quad = W(P->lin_damp_quad); Q->ang_damp_quad = W(P->ang_damp_quad);
   Q->max_ang_step = W(P->max_ang_step); Q->rest_vel_threshold = W(P->rest_vel_threshold); Q->erp = W(P->erp);
   Q->contact_threshold = W(P->contact_threshold); Q->solver_iters = P->solver_iters; Q->flags = P->flags; Q->solver_tol = W(P->solver_tol);
   Q->racket_inv_mass = W(P->racket_inv_mass);
@@ -746,7 +746,7 @@ static void solve_contacts(const Prm *P, Row *rows, int nrows, RowG *rg, int nrg
 static void integrate_velocities(const Prm *P, Racket *rk, Ball *b, v3 Fr, v3 Tr, v3 Fb) {
   const real dt = P->dt, g = P->gravity;
   { /* racket, linear: v += dt (F/m + g - v (k1 + k2 |v|)) */
-    real kd = FMA(P->lin_damp, SQRT(dot3(rk->v, rk->v)), P->lin_damp);
+    real kd = FMA(P->lin_damp_quad, SQRT(dot3(rk->v, rk->v)), P->lin_damp);
     v3 a = V3(FMA(Fr.x, P->racket_inv_mass, -(rk->v.x * kd)), FMA(Fr.y, P->racket_inv_mass, -(rk->v.y * kd)),
               FMA(Fr.z, P->racket_inv_mass, -(rk->v.z * kd)) - g);
     rk->v = axpy3(dt, a, rk->v);
@@ -758,7 +758,7 @@ static void integrate_velocities(const Prm *P, Racket *rk, Ball *b, v3 Fr, v3 Tr
       v3 wb = qrot_inv(rk->q, rk->w), Tb = torqued ? qrot_inv(rk->q, Tr) : V3(R(0), R(0), R(0));
       v3 L = V3(P->racket_inertia[0] * wb.x, P->racket_inertia[1] * wb.y, P->racket_inertia[2] * wb.z);
       v3 gy = cross3(wb, L);
-      real ka = FMA(P->ang_damp, SQRT(dot3(wb, wb)), P->ang_damp);
+      real ka = FMA(P->ang_damp_quad, SQRT(dot3(wb, wb)), P->ang_damp);
       v3 ab = V3(P->racket_inv_inertia[0] * ((Tb.x - gy.x) - L.x * ka), P->racket_inv_inertia[1] * ((Tb.y - gy.y) - L.y * ka),
                  P->racket_inv_inertia[2] * ((Tb.z - gy.z) - L.z * ka));
       rk->w = axpy3(dt, qrot(rk->q, ab), rk->w);
@@ -766,12 +766,12 @@ static void integrate_velocities(const Prm *P, Racket *rk, Ball *b, v3 Fr, v3 Tr
   }
   { /* ball: isotropic inertia => no gyroscopic term */
     if (P->magnus_k != R(0)) Fb = axpy3(P->magnus_k, cross3(b->w, b->v), Fb);
-    real kd = FMA(P->lin_damp, SQRT(dot3(b->v, b->v)), P->lin_damp);
+    real kd = FMA(P->lin_damp_quad, SQRT(dot3(b->v, b->v)), P->lin_damp);
     v3 a = V3(FMA(Fb.x, P->ball_inv_mass, -(b->v.x * kd)), FMA(Fb.y, P->ball_inv_mass, -(b->v.y * kd)),
               FMA(Fb.z, P->ball_inv_mass, -(b->v.z * kd)) - g);
     b->v = axpy3(dt, a, b->v);
     if ((b->w.x != R(0)) | (b->w.y != R(0)) | (b->w.z != R(0))) {
-      real ka = FMA(P->ang_damp, SQRT(dot3(b->w, b->w)), P->ang_damp);
+      real ka = FMA(P->ang_damp_quad, SQRT(dot3(b->w, b->w)), P->ang_damp);
       v3 aw = V3(-(b->w.x * ka), -(b->w.y * ka), -(b->w.z * ka));
       b->w = axpy3(dt, aw, b->w);
     }

@@ -120,7 +120,7 @@ TB_DEV float uniform(float lo, float span, uint32_t u) { return lo + span * ((fl
 // the scalar part of TbParams travels in the kernarg segment (SGPRs, wave-uniform);
 // the outline table goes through LDS
 struct KParams {
-  float dt, inv_dt, gravity, lin_damp, ang_damp, max_ang_step, rest_vel_threshold, erp, contact_threshold;
+  float dt, inv_dt, gravity, lin_damp, ang_damp, lin_damp_quad, ang_damp_quad, max_ang_step, rest_vel_threshold, erp, contact_threshold;
   int solver_iters; uint32_t flags; float solver_tol;
   float racket_inv_mass, racket_inertia[3], racket_inv_inertia[3], racket_com[3], racket_half_thick, hull_margin, hull_bound_radius, racket_scale;
   float ball_inv_mass, ball_inv_inertia, ball_radius, magnus_k, ball_spin_max;
@@ -876,14 +876,19 @@ TB_DEV void solve_contacts(const KParams& P, Rows<RG>& R, const Manifold& M, int
 
 // ---------------------------------------------------------------- one 1/240 s substep
 // wb_pre = rotate_inv(rk.q, rk.w), computed by the caller (rotate_inv2)
+// LAZY (the large-batch fast-forward instantiations, where VALU issue slots count and not latency): the ball's spin rate is
+// only taken where a ball spins -- after a contact, i.e. for a few lanes -- instead of next to the two speeds
+template <bool LAZY = false>
 TB_DEV void integrate_velocities(const KParams& P, Racket& rk, Ball& b, vec3 Fr, vec3 Tr, vec3 Fb, vec3 wb_pre) {
   const float dt = P.dt, g = P.gravity;
   // the three speeds that do not wait for anything are taken first, side by side: a correctly rounded sqrtf is a
   // ~16-instruction dependent chain, and three independent chains in one block interleave where three chains behind
   // three branches queue (the values and every operation on them are the same as before: bit-identical)
-  const float speed_r = sqrtf(dot(rk.v, rk.v)), speed_b = sqrtf(dot(b.v, b.v)), spin_b = sqrtf(dot(b.w, b.w));
+  const float speed_r = sqrtf(dot(rk.v, rk.v)), speed_b = sqrtf(dot(b.v, b.v));
+  float spin_b = 0.0f;
+  if constexpr (!LAZY) spin_b = sqrtf(dot(b.w, b.w));
   {
-    float kd = FMA(P.lin_damp, speed_r, P.lin_damp);
+    float kd = FMA(P.lin_damp_quad, speed_r, P.lin_damp);
     vec3 a = mk(FMA(Fr.x, P.racket_inv_mass, -(rk.v.x * kd)), FMA(Fr.y, P.racket_inv_mass, -(rk.v.y * kd)),
                 FMA(Fr.z, P.racket_inv_mass, -(rk.v.z * kd)) - g);
     rk.v = fma3(dt, a, rk.v);
@@ -898,7 +903,7 @@ TB_DEV void integrate_velocities(const KParams& P, Racket& rk, Ball& b, vec3 Fr,
       if (torqued) Tb = rotate_inv(rk.q, Tr);
       vec3 L = mk(P.racket_inertia[0] * wb.x, P.racket_inertia[1] * wb.y, P.racket_inertia[2] * wb.z);
       vec3 gy = cross(wb, L);
-      float ka = FMA(P.ang_damp, sqrtf(dot(wb, wb)), P.ang_damp);
+      float ka = FMA(P.ang_damp_quad, sqrtf(dot(wb, wb)), P.ang_damp);
       vec3 ab = mk(P.racket_inv_inertia[0] * ((Tb.x - gy.x) - L.x * ka), P.racket_inv_inertia[1] * ((Tb.y - gy.y) - L.y * ka),
                    P.racket_inv_inertia[2] * ((Tb.z - gy.z) - L.z * ka));
       rk.w = fma3(dt, rotate(rk.q, ab), rk.w);
@@ -906,13 +911,14 @@ TB_DEV void integrate_velocities(const KParams& P, Racket& rk, Ball& b, vec3 Fr,
   }
   {
     if (P.magnus_k != 0.0f) Fb = fma3(P.magnus_k, cross(b.w, b.v), Fb);
-    float kd = FMA(P.lin_damp, speed_b, P.lin_damp);
+    float kd = FMA(P.lin_damp_quad, speed_b, P.lin_damp);
     vec3 a = mk(FMA(Fb.x, P.ball_inv_mass, -(b.v.x * kd)), FMA(Fb.y, P.ball_inv_mass, -(b.v.y * kd)),
                 FMA(Fb.z, P.ball_inv_mass, -(b.v.z * kd)) - g);
     b.v = fma3(dt, a, b.v);
     bool spinning = (b.w.x != 0.0f) | (b.w.y != 0.0f) | (b.w.z != 0.0f);
     if (spinning) {
-      float ka = FMA(P.ang_damp, spin_b, P.ang_damp);
+      if constexpr (LAZY) spin_b = sqrtf(dot(b.w, b.w));
+      float ka = FMA(P.ang_damp_quad, spin_b, P.ang_damp);
       vec3 aw = mk(-(b.w.x * ka), -(b.w.y * ka), -(b.w.z * ka));
       b.w = fma3(dt, aw, b.w);
     }
@@ -1006,7 +1012,7 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
   }
   vec3 lp = mk(0.0f, 0.0f, 0.0f);
   if constexpr (!ESC) rotate_inv2(rk.q, b.p - rk.p, rk.w, lp, wb0);  // (as above; 4096 envs, same box: 612-619 -> 660-694 M env steps/s)
-  integrate_velocities(P, rk, b, Fr, Tr, Fb, wb0);
+  integrate_velocities<RELOAD>(P, rk, b, Fr, Tr, Fb, wb0);
   TB_STAMP(st, 3);  // velocity update
   Hit hr, hg, hn, hc;
   hr.hit = false; hg.hit = false; hn.hit = false; hc.hit = false;
@@ -1037,7 +1043,12 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
   TB_DIAG_ADD_LEADER(13, 1);  // wave-substeps
   TB_STAMP(st, 1);  // racket narrowphase
   const float zlow = ball_low_point(P, b);
-  bool near_g = near_ground(P, zlow), near_n = near_net(P, b, zlow), near_c = near_goal<KIND>(P, zlow);
+  bool near_g = false, near_n = false, near_c = false;
+  // every per-shape cull below needs the ball's low point under that shape's top: one wave vote against the highest of them
+  // (host-derived static_top) skips the three tests for waves whose balls are all still up in the air
+  if (__any(!(zlow >= P.static_top + 1.0e-3f))) {
+    near_g = near_ground(P, zlow); near_n = near_net(P, b, zlow); near_c = near_goal<KIND>(P, zlow);
+  }
   TB_DIAG_ABLATE_NARROW(near_g); TB_DIAG_ABLATE_NARROW(near_n); TB_DIAG_ABLATE_NARROW(near_c);
   TB_LANES(6, near_g | near_n | near_c);  // [6] lanes near a static shape, [7] wave-substeps with one
   if (__any(near_g | near_n | near_c)) {

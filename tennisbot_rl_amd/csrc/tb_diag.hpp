@@ -7,6 +7,7 @@
 //
 //   -DTB_DIAG_STAMPS         s_memtime stamps: cycles per substep segment and per kernel phase, summed per
 //                            wave into g_diag_cycles[16] (tools/diag/diag_stamps*.py, diag_ff_sort.py)
+//   -DTB_DIAG_TRACE          entry / exit real-time of every step-kernel launch into g_diag_trace (tools/diag/r03_cadence_probe.py)
 //   -DTB_DIAG_LANES          lane census of the substep's wave votes into g_diag_lanes[16]
 //                            (tools/diag/diag_lanes.py)
 //   -DTB_DIAG_NO_ANGULAR / _NO_ORIENT / _NO_NARROW
@@ -84,6 +85,21 @@ TB_DEV void diag_flush_stamps(const Stamps& st) {
 #define TB_DIAG_ADD_EACH(slot, expr) do { } while (0)
 #endif
 
+// ---- launch trace (-DTB_DIAG_TRACE, also part of -DTB_DIAG_STAMPS) ---------------------------
+// the first thread of a step-kernel launch logs the 100 MHz real-time counter at entry and exit: the cadence of the launches
+// inside a graph replay WITHOUT a profiler serialising them, at two scalar instructions and one atomic per launch
+// (tools/diag/r03_cadence_probe.py)
+#if defined(TB_DIAG_TRACE) || defined(TB_DIAG_STAMPS)
+__device__ unsigned long long g_diag_trace[2 * 8192];
+__device__ unsigned int g_diag_trace_n;
+#define TB_DIAG_TRACE_ENTRY(tr) unsigned int tr = 0xffffffffu; do { if (blockIdx.x == 0 && threadIdx.x == 0) { \
+  tr = atomicAdd(&g_diag_trace_n, 1u) & 8191u; g_diag_trace[2 * tr] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define TB_DIAG_TRACE_EXIT(tr) do { if (tr != 0xffffffffu) g_diag_trace[2 * tr + 1] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TB_DIAG_TRACE_ENTRY(tr) do { } while (0)
+#define TB_DIAG_TRACE_EXIT(tr) do { } while (0)
+#endif
+
 // ---- timing-only ablations (results are wrong) ---------------------------------------------
 #ifdef TB_DIAG_NO_ANGULAR
 #define TB_DIAG_ABLATE_ANGULAR(flag) flag = false
@@ -110,6 +126,18 @@ int tb_diag_read_stamps(unsigned long long* out16, int reset) {
   HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_diag_cycles), sizeof(unsigned long long) * 16));
   if (reset) { unsigned long long z[16] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_diag_cycles), z, sizeof z)); }
   return TB_OK;
+}
+#endif
+#if defined(TB_DIAG_TRACE) || defined(TB_DIAG_STAMPS)
+int tb_diag_read_trace(unsigned long long* out_pairs, int max_pairs, int reset) {
+  HIP_TRY(hipDeviceSynchronize());
+  unsigned int n = 0;
+  HIP_TRY(hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_diag_trace_n), sizeof n));
+  int k = (int)(n < 8192u ? n : 8192u);
+  if (k > max_pairs) k = max_pairs;
+  if (k > 0) HIP_TRY(hipMemcpyFromSymbol(out_pairs, HIP_SYMBOL(g_diag_trace), sizeof(unsigned long long) * 2 * (size_t)k));
+  if (reset) { unsigned int z = 0; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_diag_trace_n), &z, sizeof z)); }
+  return k;
 }
 #endif
 #ifdef TB_DIAG_LANES

@@ -1,4 +1,4 @@
-// Policy inference for the fused policy + step kernel (tb_policy_step). Device code only; included by
+// Policy inference for the fused policy + step kernels (tb_policy_step, tb_policy_rollout). Device code only; included by
 // tb_stepper.hip after KArgs / EnvRegs / Dims / philox4x32 are defined. This file is part of the HIP
 // library's single translation unit (everything lives in one anonymous namespace there).
 #pragma once
@@ -10,31 +10,36 @@ namespace {
 // Tennisbot 12 -> 64 -> 64 (SB3 default, train.py:104-110) -- tanh hidden layers, linear action mean,
 // state-independent log_std, a = mean + std * eps.
 //
-// The towers run on the matrix cores in exact fp32 (v_mfma_f32_32x32x2_f32: bitwise a k-ordered fmaf
-// chain, same peak as packed VALU FMA, but ONE VGPR per operand fragment instead of a broadcast weight
-// per FMA -- a first VALU version spent its time re-reading weights out of LDS). Each layer is computed
-// TRANSPOSED, H^T[out][env] = W^T[out][k] * X^T[k][env], 32 envs per wave: the weight fragment is the A
-// operand, the activations the B operand, and -- the point of the transposition -- the C/D layout of one
-// layer's output (lane = env, 16 registers = rows (r&3) + 8(r>>2) + 4(lane>>5)) IS the B layout of the
-// next layer's input if the k-pairs are taken in that row order: register r of the output tile feeds
-// "pair r" (k = row(r) on lanes 0-31, row(r)+4 on lanes 32-63). pack_policy() permutes the weights to
-// match, so activations never leave the registers: no LDS, no shuffles, no barrier between layers. The
-// k-sum order is that permutation (a fixed order; vs. torch within 1e-6).
-// Four waves per 64 envs: {pi, vf} x {envs 0-31, 32-63}, independent until the pi waves hand the action
-// means to wave 0 through LDS; wave 0 then samples and steps all 64 envs, the others retire.
-// Blob, per tower and layer: bias tiles [out/32][2 halves][16 regs], then weight fragments
-// [out/32][pairs][2][32] -- i.e. exactly what lane l loads at index l; heads padded to 32 outputs.
+// The towers run on the matrix cores in fp32 (v_mfma_f32_16x16x4_f32: ONE VGPR per operand fragment instead of a
+// broadcast weight per FMA -- a first VALU version spent its time re-reading weights out of LDS). Each layer is computed
+// TRANSPOSED, H^T[out][env] = W^T[out][k] * X^T[k][env], 16 envs per wave: the weight fragment is the A operand
+// (lane l: out l % 16, k-slot l / 16), the activations the B operand (lane l: k-slot l / 16, env l % 16), and -- the point of
+// the transposition -- the C/D layout of one layer's output (lane l, register r: row 4 (l / 16) + r of the 16-row tile,
+// env l % 16) IS the B layout of the next layer's input if the k-chunks are taken in that order: register r of output tile
+// t feeds "chunk (t, r)" = k in {16 t + 4 g + r : g = 0..3}, lane group g holding its own k. pack_policy() permutes the
+// weights to match, so activations never leave the registers: no LDS, no shuffles, no barrier between layers. The k-sum
+// order is that permutation (a fixed order; vs. torch within 2e-5, tests/test_gpu_policy.py).
+//
+// Round 3: 16-env slices with the 16x16x4 shape replace 32-env halves with 32x32x2. The matrix pipe of a SIMD issues one
+// MFMA at a time -- a tower for 32 envs was 83 x 64 = 5312 pipe cycles per step whatever the schedule, 67 of the 83 on
+// one dependent chain -- and at 4096 envs only 64 of the 256 CUs had a workgroup at all. A 16-env slice is 76 x 32 = 2432
+// pipe cycles in chains of at most 16 with 2-4 independent tiles side by side, half the tanh evaluations per lane, and a
+// workgroup per 16 envs puts a tower on every CU (tb_policy_rollout_kernel<KIND, 1>).
+// Blob, per tower and layer: bias tiles [ceil(out/16)][4 lane groups][4 regs], then weight fragments
+// [ceil(out/16)][chunks][64 lanes] -- i.e. exactly what lane l loads at index l; heads padded to 16 outputs,
+// the first layer's k padded to a multiple of 4 with zeros.
 template <int KIND> struct PolicyNet;
 template <> struct PolicyNet<TB_ENV_SWING> { static constexpr int NH = 3, H0 = 32, H1 = 64, H2 = 32, LAST = 32; };
 template <> struct PolicyNet<TB_ENV_TENNIS> { static constexpr int NH = 2, H0 = 64, H1 = 64, H2 = 64, LAST = 64; };
-constexpr int layer_floats(int in, int out) { return ((out + 31) / 32) * (32 + (in / 2) * 64); }
+constexpr int layer_floats(int in, int out) { return ((out + 15) / 16) * (16 + ((in + 3) / 4) * 64); }
 template <int KIND> constexpr int tower_floats() {  // hidden layers + the (padded) head
   using N = PolicyNet<KIND>;
-  return layer_floats(Dims<KIND>::O, N::H0) + layer_floats(N::H0, N::H1) + (N::NH == 3 ? layer_floats(N::H1, N::H2) : 0) + layer_floats(N::LAST, 32);
+  return layer_floats(Dims<KIND>::O, N::H0) + layer_floats(N::H0, N::H1) + (N::NH == 3 ? layer_floats(N::H1, N::H2) : 0) + layer_floats(N::LAST, 16);
 }
 template <int KIND> constexpr int policy_floats() { return 2 * tower_floats<KIND>() + (Dims<KIND>::A + 3) / 4 * 4; }
+constexpr int TB_POLICY_SLICE = 16;  // envs per tower wave
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 // tanh(x) = 1 - 2 / (e^(2x) + 1) on the hardware exp2 / rcp units (1 ulp each): absolute error < 3e-7,
 // saturates correctly at +-inf; 5 instructions instead of libm's ~40
 TB_DEV float fast_tanh(float x) {
@@ -42,98 +47,96 @@ TB_DEV float fast_tanh(float x) {
   return FMA(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 
-// one layer's operands for this lane: NT bias tiles (16 floats each) and NT * NP weight fragments
-template <int NT, int NP>
+// one layer's operands for this lane: NT bias tiles (4 floats each) and NT * NC weight fragments
+template <int NT, int NC>
 struct LayerRegs {
-  f32x16 bias[NT];
-  float frag[NT * NP];
+  f32x4 bias[NT];
+  float frag[NT * NC];
   TB_DEV void load(const float* g, int lane) {
-    const int h = lane >> 5;
+    const int grp = lane >> 4;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const float4* p = reinterpret_cast<const float4*>(g + t * 32 + h * 16);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float4 v = p[q];
-        bias[t][4 * q] = v.x; bias[t][4 * q + 1] = v.y; bias[t][4 * q + 2] = v.z; bias[t][4 * q + 3] = v.w;
-      }
+      const float4 v = *reinterpret_cast<const float4*>(g + t * 16 + grp * 4);
+      bias[t][0] = v.x; bias[t][1] = v.y; bias[t][2] = v.z; bias[t][3] = v.w;
     }
-    g += NT * 32;
+    g += NT * 16;
 #pragma unroll
-    for (int f = 0; f < NT * NP; ++f) frag[f] = g[f * 64 + lane];
+    for (int f = 0; f < NT * NC; ++f) frag[f] = g[f * 64 + lane];
   }
-  // y[t * 16 + r] = act(bias + sum over pairs): the next layer's B operands, in place
+  // y[4 t + r] = act(bias + sum over chunks): the next layer's B operands, in place. Chunk-outer, tile-inner: the NT
+  // accumulator chains are independent and written side by side, so the matrix pipe always has a ready MFMA
   template <bool TANH>
-  TB_DEV void apply(const float (&x)[NP], float (&y)[NT * 16]) const {
+  TB_DEV void apply(const float (&x)[NC], float (&y)[NT * 4]) const {
+    f32x4 c[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) c[t] = bias[t];
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[t * NC + ch], x[ch], c[t], 0, 0, 0);
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      f32x16 c = bias[t];
 #pragma unroll
-      for (int pr = 0; pr < NP; ++pr) c = __builtin_amdgcn_mfma_f32_32x32x2f32(frag[t * NP + pr], x[pr], c, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) y[t * 16 + r] = TANH ? fast_tanh(c[r]) : c[r];
+      for (int r = 0; r < 4; ++r) y[t * 4 + r] = TANH ? fast_tanh(c[t][r]) : c[t][r];
     }
   }
 };
 
-// one tower for 32 envs: lane l works on env (l & 31); out[0..3] = head rows 0-3 (lanes 0-31) or 4-7
-// (lanes 32-63) of that env. Every operand of the tower is requested by load() up front (one VGPR per
-// fragment): the loads of the later layers land while the earlier ones compute (policy_tower), or stay
-// resident across the steps of a rollout launch (tb_policy_rollout_kernel).
+// one tower for 16 envs: lane l works on env (l & 15); out[0..3] = head rows 4 (l >> 4) + 0..3 of that env. Every operand
+// of the tower is requested by load() up front (one VGPR per fragment): the loads of the later layers land while the
+// earlier ones compute (policy_tower), or stay resident across the steps of a rollout launch (tb_policy_rollout_kernel).
 template <int KIND> struct TowerRegs;
 template <> struct TowerRegs<TB_ENV_SWING> {  // 6 -> 32 -> 64 -> 32 -> head
   using N = PolicyNet<TB_ENV_SWING>;
-  static constexpr int O = Dims<TB_ENV_SWING>::O, NP0 = O / 2;
-  LayerRegs<1, NP0> l0;
-  LayerRegs<2, 16> l1;
-  LayerRegs<1, 32> l2;
-  LayerRegs<1, 16> lh;
+  static constexpr int O = Dims<TB_ENV_SWING>::O, NC0 = (O + 3) / 4;
+  LayerRegs<2, NC0> l0;
+  LayerRegs<4, 8> l1;
+  LayerRegs<2, 16> l2;
+  LayerRegs<1, 8> lh;
   TB_DEV void load(const float* g, int lane) {
     l0.load(g, lane); g += layer_floats(O, N::H0);
     l1.load(g, lane); g += layer_floats(N::H0, N::H1);
     l2.load(g, lane); g += layer_floats(N::H1, N::H2);
     lh.load(g, lane);
   }
-  TB_DEV void apply(const float (&x0)[NP0], float (&out)[4]) const {
-    float h0[16], h1[32], h2[16], y[16];
+  TB_DEV void apply(const float (&x0)[NC0], float (&out)[4]) const {
+    float h0[8], h1[16], h2[8];
     l0.template apply<true>(x0, h0);
     l1.template apply<true>(h0, h1);
     l2.template apply<true>(h1, h2);
-    lh.template apply<false>(h2, y);
-    out[0] = y[0]; out[1] = y[1]; out[2] = y[2]; out[3] = y[3];
+    lh.template apply<false>(h2, out);
   }
 };
 template <> struct TowerRegs<TB_ENV_TENNIS> {  // 12 -> 64 -> 64 -> head
   using N = PolicyNet<TB_ENV_TENNIS>;
-  static constexpr int O = Dims<TB_ENV_TENNIS>::O, NP0 = O / 2;
-  LayerRegs<2, NP0> l0;
-  LayerRegs<2, 32> l1;
-  LayerRegs<1, 32> lh;
+  static constexpr int O = Dims<TB_ENV_TENNIS>::O, NC0 = (O + 3) / 4;
+  LayerRegs<4, NC0> l0;
+  LayerRegs<4, 16> l1;
+  LayerRegs<1, 16> lh;
   TB_DEV void load(const float* g, int lane) {
     l0.load(g, lane); g += layer_floats(O, N::H0);
     l1.load(g, lane); g += layer_floats(N::H0, N::H1);
     lh.load(g, lane);
   }
-  TB_DEV void apply(const float (&x0)[NP0], float (&out)[4]) const {
-    float h0[32], h1[32], y[16];
+  TB_DEV void apply(const float (&x0)[NC0], float (&out)[4]) const {
+    float h0[16], h1[16];
     l0.template apply<true>(x0, h0);
     l1.template apply<true>(h0, h1);
-    lh.template apply<false>(h1, y);
-    out[0] = y[0]; out[1] = y[1]; out[2] = y[2]; out[3] = y[3];
+    lh.template apply<false>(h1, out);
   }
 };
 
-// `obs_row`: this lane's env's observation (clamped to a valid env)
+// the first layer's B operand of this lane: obs[4 ch + (lane >> 4)] of its env, 0 beyond the observation
 template <int KIND>
-TB_DEV void policy_tower(const float* g, const float* obs_row, int lane, float (&out)[4]) {
-  constexpr int NP0 = TowerRegs<KIND>::NP0;
-  float x0[NP0];
+TB_DEV void policy_inputs(const float* obs_row, int lane, float (&x0)[TowerRegs<KIND>::NC0]) {
+  constexpr int NO = Dims<KIND>::O;
+  const int grp = lane >> 4;
 #pragma unroll
-  for (int pr = 0; pr < NP0; ++pr) x0[pr] = obs_row[2 * pr + (lane >> 5)];
-  TowerRegs<KIND> regs;
-  regs.load(g, lane);
-  __builtin_amdgcn_sched_barrier(0);  // keeps the scheduler from sinking each load down to its MFMA
-  regs.apply(x0, out);
+  for (int ch = 0; ch < TowerRegs<KIND>::NC0; ++ch) {
+    if ((NO & 3) == 0 || ch < NO / 4) x0[ch] = obs_row[4 * ch + grp];
+    else x0[ch] = 4 * ch + grp < NO ? obs_row[4 * ch + grp] : 0.0f;
+  }
 }
 
 // standard normals from Philox bits (Box-Muller); keyed by (seed, global env id, episode, step):
@@ -155,23 +158,27 @@ TB_DEV void policy_noise(unsigned long long seed, unsigned long long env_id, uin
     }
   }
 }
-// the tower part: wave w of the workgroup = (tower w >> 1, env half w & 1); the pi waves leave the
-// action means in s_mean[64][8], the vf waves write the values
+// the tower part of the one-step kernel (tb_policy_step: 256-thread workgroups, 64 envs): wave w runs BOTH towers of the
+// 16-env slice w -- two independent chains the scheduler interleaves -- leaves the action means in s_mean[64][8] and
+// writes the values
 template <int KIND>
 TB_DEV void policy_towers(const KArgs& A, float* s_mean) {
   constexpr int NO = Dims<KIND>::O;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tower = wave >> 1, half = wave & 1;
-  const int slot = half * 32 + (lane & 31), env = blockIdx.x * 64 + slot;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane >> 4;
+  const int slot = wave * TB_POLICY_SLICE + (lane & 15), env = blockIdx.x * 64 + slot;
   const int env_c = env < A.n ? env : A.n - 1;
-  float out[4];
-  policy_tower<KIND>(A.pol_weights + tower * tower_floats<KIND>(), A.pol_obs + (size_t)env_c * NO, lane, out);
-  if (tower == 0) {
-    *reinterpret_cast<float4*>(s_mean + slot * 8 + (lane >> 5) * 4) = make_float4(out[0], out[1], out[2], out[3]);
-  } else if (lane < 32 && env < A.n) {
-    A.pol_value[env] = out[0];
-  }
+  float x0[TowerRegs<KIND>::NC0], mean[4], val[4];
+  policy_inputs<KIND>(A.pol_obs + (size_t)env_c * NO, lane, x0);
+  TowerRegs<KIND> pi, vf;
+  pi.load(A.pol_weights, lane);
+  vf.load(A.pol_weights + tower_floats<KIND>(), lane);
+  __builtin_amdgcn_sched_barrier(0);  // keeps the scheduler from sinking each load down to its MFMA
+  pi.apply(x0, mean);
+  vf.apply(x0, val);
+  if (grp < 2) *reinterpret_cast<float4*>(s_mean + slot * 8 + grp * 4) = make_float4(mean[0], mean[1], mean[2], mean[3]);
+  if (lane < 16 && env < A.n) A.pol_value[env] = val[0];
 }
-// wave 0, after the workgroup barrier: sample, report, and hand the clipped actions to the env step
+// the env wave, after the workgroup barrier: sample, report, and hand the clipped actions to the env step
 // `t`: the step of a rollout launch (tb_policy_rollout_kernel) whose output rows are written; 0 otherwise
 // The noise of a step depends on the env's (episode, step) only, not on the policy's output: a caller
 // with idle time before the means arrive (the env wave of tb_policy_rollout_kernel, while the towers

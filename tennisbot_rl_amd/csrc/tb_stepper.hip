@@ -322,7 +322,7 @@ TB_DEV int predict_flight(const KParams& P, vec3 bp, vec3 bv) {
   float z = bp.z, vz = bv.z, vh = __builtin_amdgcn_sqrtf(FMA(bv.x, bv.x, bv.y * bv.y));
   int k = 0;
   while (k < 200 && z > z_land) {
-    float kd = FMA(P.lin_damp, __builtin_amdgcn_sqrtf(FMA(vh, vh, vz * vz)), P.lin_damp);
+    float kd = FMA(P.lin_damp_quad, __builtin_amdgcn_sqrtf(FMA(vh, vh, vz * vz)), P.lin_damp);
     vz = FMA(dt4, -P.gravity - vz * kd, vz);
     vh = FMA(dt4, -(vh * kd), vh);
     z = FMA(dt4, vz, z);
@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
   constexpr int NA = Dims<KIND>::A, NO = Dims<KIND>::O;
   __shared__ float4 s_hull[TB_HULL_LDS];
   __shared__ __attribute__((aligned(16))) float s_mean[POLICY ? 64 * 8 : 4];
-  // POLICY: 256-thread workgroups, four waves per 64 envs (see policy_towers); wave 0 steps the envs
+  // POLICY: 256-thread workgroups, four waves per 64 envs, each running both towers of a 16-env slice (see policy_towers); wave 0 steps the envs
   const int i = POLICY ? blockIdx.x * 64 + (threadIdx.x & 63) : blockIdx.x * blockDim.x + threadIdx.x;
   // measured at 4096 envs: Tennisbot +5.6 % (687 -> 726 M env steps/s); SwingRacket -6 % if it uses them too
   // (its kernels sit at the SGPR limit), so SwingRacket keeps reading the struct
@@ -496,6 +496,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
   const bool live = i < w_n;
   EnvRegs e;
   TB_DIAG_NOW(t_entry);
+  TB_DIAG_TRACE_ENTRY(trace_slot);
   // issue every load this launch depends on back to back -- state rows, the first step's actions,
   // the outline table -- so that their latencies overlap instead of queueing behind the barrier
   float a[NA];
@@ -598,56 +599,60 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
   TB_DIAG_ADD_LANE0(8, stamp_now() - t_kernel0);  // per-wave scalars: cycles in the kernel, waves, 100 MHz ticks
   TB_DIAG_ADD_LANE0(9, 1);
   TB_DIAG_ADD_LANE0(14, __builtin_amdgcn_s_memrealtime() - rt_kernel0);
+  TB_DIAG_TRACE_EXIT(trace_slot);
 }
 
 // T agent steps with the policy inside, ONE launch: no launch boundary, no state round trip between the
-// steps of an episode. Five waves per 64 envs: waves 0-3 are the towers of tb_policy.hpp, their weight
-// fragments loaded once and resident in registers for the whole launch; wave 4 holds the 64 envs' state
-// in registers and steps them. Per step: towers (obs from LDS) -> barrier -> wave 4 samples, steps,
-// writes the step's outputs and the new observations to LDS -> barrier. The two role branches execute
-// the same number of barriers. SwingRacket episodes end at most once per launch, at its last step (the
-// host cuts rollouts at episode ends): those lanes are parked for tb_ff_kernel exactly as in the
-// pipelined step kernel. Same arithmetic per env as tb_policy_step, step after step: identical results.
-template <int KIND>
-__global__ void __launch_bounds__(320) tb_policy_rollout_kernel(KArgs A) {
-  constexpr int NA = Dims<KIND>::A, NO = Dims<KIND>::O;
+// steps of an episode. A workgroup owns E = 16 S envs: waves 0 .. 2S-1 are the towers of tb_policy.hpp -- wave w is tower
+// w / S (pi, vf) of the 16-env slice w % S -- their weight fragments loaded once and resident in registers for the whole
+// launch; wave 2S holds the E envs' state in registers (lanes >= E idle) and steps them. Per step: towers (obs from LDS) ->
+// barrier -> the env wave samples, steps, writes the step's outputs and the new observations to LDS -> barrier. The two
+// role branches execute the same number of barriers. S = 1 (three waves per 16 envs) for batches that would otherwise
+// leave CUs without a workgroup -- 4096 envs: 256 workgroups, one per CU, every tower alone on its SIMD's matrix pipe;
+// S = 3 (seven waves per 48 envs) where the chip is full anyway and a 16-lane env wave would waste VALU issue slots
+// (S = 4, nine waves, would put three waves on one SIMD: 168 VGPRs each, and the env wave's ~200 spill).
+// SwingRacket episodes end at most once per launch, at its last step (the host cuts rollouts at episode ends): those
+// lanes are parked for tb_ff_kernel exactly as in the pipelined step kernel. Same arithmetic per env as tb_policy_step,
+// step after step: identical results.
+// RG: the extended contact set compiled in (racket<->court manifold cache in the env wave's LDS columns, rolling-friction rows).
+template <int KIND, int S, bool RG>
+__global__ void __launch_bounds__((2 * S + 1) * 64) tb_policy_rollout_kernel(KArgs A) {
+  constexpr int NA = Dims<KIND>::A, NO = Dims<KIND>::O, E = TB_POLICY_SLICE * S;
   __shared__ float4 s_hull[TB_HULL_LDS];
-  __shared__ __attribute__((aligned(16))) float s_mean[64 * 8];
-  __shared__ __attribute__((aligned(16))) float s_obs[64 * NO];
+  __shared__ __attribute__((aligned(16))) float s_mean[E * 8];
+  __shared__ __attribute__((aligned(16))) float s_obs[E * NO];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int k = threadIdx.x; k < 2 * A.P.n_hull; k += blockDim.x) s_hull[k] = A.hull[k];
   for (int k = TB_HULL_PLANES + threadIdx.x; k < TB_HULL_LDS; k += blockDim.x) s_hull[k] = A.hull[k];
-  if (wave < 4) {
-    constexpr int NP0 = TowerRegs<KIND>::NP0;
-    const int tower = wave >> 1, half = wave & 1, h = lane >> 5;
-    const int slot = half * 32 + (lane & 31), env = blockIdx.x * 64 + slot;
+  if (wave < 2 * S) {
+    const int tower = wave / S, slice = wave % S, grp = lane >> 4;
+    const int slot = slice * TB_POLICY_SLICE + (lane & 15), env = blockIdx.x * E + slot;
     const int env_c = env < A.n ? env : A.n - 1;
     TowerRegs<KIND> regs;
     regs.load(A.pol_weights + tower * tower_floats<KIND>(), lane);
     __syncthreads();
     for (int t = 0; t < A.T; ++t) {
-      float x0[NP0], out[4];
-      if (t == 0) {
-#pragma unroll
-        for (int pr = 0; pr < NP0; ++pr) x0[pr] = A.pol_obs[(size_t)env_c * NO + 2 * pr + h];
-      } else {
-#pragma unroll
-        for (int pr = 0; pr < NP0; ++pr) x0[pr] = s_obs[slot * NO + 2 * pr + h];
-      }
+      float x0[TowerRegs<KIND>::NC0], out[4];
+      if (t == 0) policy_inputs<KIND>(A.pol_obs + (size_t)env_c * NO, lane, x0);
+      else policy_inputs<KIND>(s_obs + slot * NO, lane, x0);
       regs.apply(x0, out);
-      if (tower == 0) *reinterpret_cast<float4*>(s_mean + slot * 8 + h * 4) = make_float4(out[0], out[1], out[2], out[3]);
-      else if (lane < 32 && env < A.n) A.pol_value[(size_t)t * A.st_val + env] = out[0];
+      if (tower == 0) { if (grp < 2) *reinterpret_cast<float4*>(s_mean + slot * 8 + grp * 4) = make_float4(out[0], out[1], out[2], out[3]); }
+      else if (lane < 16 && env < A.n) A.pol_value[(size_t)t * A.st_val + env] = out[0];
       __syncthreads();  // the action means of step t are in LDS
       __syncthreads();  // the observations after step t are in LDS
     }
     return;
   }
-  const int i = blockIdx.x * 64 + lane;
-  const bool live = i < A.n;
+  const int i = blockIdx.x * E + lane;
+  const bool live = lane < E && i < A.n;
   EnvRegs e;
   if (live) load_env<KIND>(A.words, A.done_state, A.n, i, e);
   Manifold M;
-  init_manifold(M, lane, 64, KIND == TB_ENV_SWING);  // (the cache part is never touched: no extended contact set in this kernel)
+  init_manifold(M, lane, 64, KIND == TB_ENV_SWING);  // SwingRacket: static rows in LDS; Tennisbot keeps them in registers (REGROWS below)
+  bool had_contacts = false;
+  if constexpr (RG) {
+    if (live) { had_contacts = A.mflag[i] != 0; if (had_contacts) load_manifold(A, i, M); }
+  }
   uint32_t cnt[TB_N_COUNTERS];
 #pragma unroll
   for (int k = 0; k < TB_N_COUNTERS; ++k) cnt[k] = 0u;
@@ -668,12 +673,12 @@ __global__ void __launch_bounds__(320) tb_policy_rollout_kernel(KArgs A) {
       bool d, parked = false;
       float rew;
       if (KIND == TB_ENV_SWING) {
-        rew = swing_step<false, false, true>(A.P, s_hull, e, M, a, ns, cnt, true, parked TB_STAMP_PASS);  // never loops in here: see tb_step_kernel<LEAN>; COLD
+        rew = swing_step<RG, false, true>(A.P, s_hull, e, M, a, ns, cnt, true, parked TB_STAMP_PASS);  // never loops in here: see tb_step_kernel<LEAN>; COLD
         make_obs<TB_ENV_SWING>(e, o);
         d = e.done != TB_DONE_NO;
         if (parked) {
           if (A.ff_rec) {
-            park_env<false>(A.ff_rec, i, e, M);
+            park_env<RG>(A.ff_rec, i, e, M);
             A.ff_flag[i] = 1;
           } else {
             cnt[8]++;  // lockstep invariant broken (see launch_policy_rollout): reported, never silent
@@ -681,7 +686,7 @@ __global__ void __launch_bounds__(320) tb_policy_rollout_kernel(KArgs A) {
           d = true;
         }
       } else {
-        rew = tennis_step<false, true, true>(A.P, s_hull, e, M, a, o, d, cnt TB_STAMP_PASS);
+        rew = tennis_step<RG, true, true>(A.P, s_hull, e, M, a, o, d, cnt TB_STAMP_PASS);
       }
       cnt[6] += (uint32_t)(ns - 1);
       if (!(finite3(e.r.p) && finite3(e.r.v) && finite3(e.r.w) && finite3(e.b.p) && finite3(e.b.v) && finite3(e.b.w) &&
@@ -695,15 +700,19 @@ __global__ void __launch_bounds__(320) tb_policy_rollout_kernel(KArgs A) {
         make_obs<KIND>(e, o);
         any_reset = true;
       }
+      // the towers wait for the observations only: they go to LDS before the step's outputs go to memory
+#pragma unroll
+      for (int k = 0; k < NO; ++k) s_obs[lane * NO + k] = o[k];
       write_obs<KIND>(A.obs + (size_t)t * A.st_obs, (size_t)i, o);
       A.reward[(size_t)t * A.st_rew + i] = rew;
       A.done_out[(size_t)t * A.st_done + i] = d ? 1 : 0;
-#pragma unroll
-      for (int k = 0; k < NO; ++k) s_obs[lane * NO + k] = o[k];
     }
     __syncthreads();  // the observations after step t are in LDS
   }
-  if (live) store_env<KIND>(A.words, A.done_state, A.n, i, e, any_reset);
+  if (live) {
+    store_env<KIND>(A.words, A.done_state, A.n, i, e, any_reset);
+    if constexpr (RG) { if (M.n > 0 || had_contacts) store_manifold(A, i, M, had_contacts); }
+  }
   flush_counters(A.counters, cnt);
   if (blockIdx.x == 0 && lane == 0) atomicAdd(&A.counters[6], (unsigned long long)A.n * (unsigned long long)A.T);
 }
@@ -894,6 +903,13 @@ __global__ void __launch_bounds__(256) tb_diag_copy_kernel(const uint32_t* src, 
   for (int r = 0; r < rows; ++r) dst[(size_t)r * n + i] = src[(size_t)r * n + i];
 }
 
+// diagnostics: `gridDim.x` one-wave workgroups that do nothing but stay resident (s_sleep) until the 100 MHz real-time counter has
+// advanced by `ticks` -- what the fast-forward waves look like to the dispatcher, without their arithmetic (tools/diag/r03_idle_probe.py)
+__global__ void __launch_bounds__(64) tb_diag_idle_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 thread_local char g_err[512] = "";
@@ -935,7 +951,7 @@ int validate_params(const TbParams* p) {
 }
 
 void to_kparams(const TbParams* p, KParams* k, float* planes) {
-  k->dt = p->dt; k->inv_dt = p->inv_dt; k->gravity = p->gravity; k->lin_damp = p->lin_damp; k->ang_damp = p->ang_damp;
+  k->dt = p->dt; k->inv_dt = p->inv_dt; k->gravity = p->gravity; k->lin_damp = p->lin_damp; k->ang_damp = p->ang_damp; k->lin_damp_quad = p->lin_damp_quad; k->ang_damp_quad = p->ang_damp_quad;
   k->max_ang_step = p->max_ang_step; k->rest_vel_threshold = p->rest_vel_threshold; k->erp = p->erp;
   k->contact_threshold = p->contact_threshold; k->solver_iters = p->solver_iters; k->flags = p->flags; k->solver_tol = p->solver_tol;
   k->racket_inv_mass = p->racket_inv_mass;
@@ -1180,11 +1196,12 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
   }
   const bool rg = extended_contacts(h->kp);  // selects the instantiation that contains the rolling-friction rows
   const unsigned lanes = pol ? 64u : block.x;
-  const size_t lds_rows = dyn_lds(false, rg && !pol, lanes), lds_regs = dyn_lds(true, false, lanes);  // instantiations with the static rows in LDS / in registers
+  const size_t lds_rows = dyn_lds(false, rg, lanes), lds_regs = dyn_lds(true, false, lanes);  // instantiations with the static rows in LDS / in registers
   (void)hipGetLastError();  // the check below is about THIS launch, not about whatever another library left behind
 #define TB_LAUNCH_STEP(KIND, LEAN, MULTI)                                                                      \
   do {                                                                                                         \
-    if (pol) hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, false, false, true>), grid, block, lds_rows, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);        \
+    if (pol && rg) hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, false, true, true>), grid, block, lds_rows, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);   \
+    else if (pol) hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, false, false, true>), grid, block, lds_rows, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);   \
     else if (rg) hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, MULTI, true>), grid, block, lds_rows, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);           \
     else hipLaunchKernelGGL((tb_step_kernel<KIND, LEAN, MULTI, false>), grid, block, lds_rows, s, a.words, a.done_state, a.actions, a.hull, a.n, a.P.n_hull, a);                  \
   } while (0)
@@ -1239,10 +1256,21 @@ int launch_policy_rollout(TbHandle* h, int T, const PolicyIO& pol, float* obs, f
     if (h->ff_busy[slot]) HIP_TRY(hipStreamWaitEvent(s, h->ev_ff[slot], 0));
     a.defer = 1; a.ff_rec = h->d_ff_rec[slot]; a.ff_flag = h->d_ff_flag[slot];
   }
-  dim3 grid((unsigned)((h->n + 63) / 64)), block(320);
+  // 16 envs per workgroup (3 waves) while every workgroup still gets a CU of its own, else 48 (7 waves): see the kernel
+  const bool narrow = h->opt.policy_slices ? h->opt.policy_slices == 1 : h->n <= 4096;
+  const int E = narrow ? TB_POLICY_SLICE : 3 * TB_POLICY_SLICE;
+  dim3 grid((unsigned)((h->n + E - 1) / E)), block(narrow ? 192 : 448);
   (void)hipGetLastError();
-  if (swing) hipLaunchKernelGGL(tb_policy_rollout_kernel<TB_ENV_SWING>, grid, block, dyn_lds(false, false, 64), s, a);
-  else hipLaunchKernelGGL(tb_policy_rollout_kernel<TB_ENV_TENNIS>, grid, block, 0, s, a);
+  const bool rg = extended_contacts(h->kp);
+  const size_t lds = dyn_lds(!swing, rg, 64);  // the env wave's columns: static rows (SwingRacket) + the racket<->court cache (RG)
+#define TB_LAUNCH_PR(KIND, SL)                                                                                 \
+  do {                                                                                                         \
+    if (rg) hipLaunchKernelGGL((tb_policy_rollout_kernel<KIND, SL, true>), grid, block, lds, s, a);            \
+    else hipLaunchKernelGGL((tb_policy_rollout_kernel<KIND, SL, false>), grid, block, lds, s, a);              \
+  } while (0)
+  if (swing) { if (narrow) TB_LAUNCH_PR(TB_ENV_SWING, 1); else TB_LAUNCH_PR(TB_ENV_SWING, 3); }
+  else { if (narrow) TB_LAUNCH_PR(TB_ENV_TENNIS, 1); else TB_LAUNCH_PR(TB_ENV_TENNIS, 3); }
+#undef TB_LAUNCH_PR
   HIP_TRY(hipGetLastError());
   if (may_park) {
     a.reward = reward + (size_t)(T - 1) * st[5];  // the fast-forward owes its reward to the step that parked: the last one
@@ -1276,6 +1304,7 @@ int tb_create(const TbParams* params, const TbOptions* options, int env_kind, in
     if (opt.block != 0 && opt.block != 64 && opt.block != 128 && opt.block != 256) return fail(TB_E_INVAL, "tb_create: TbOptions.block must be 0, 64, 128 or 256");
     if (opt.ff_lanes_per_wave < 0 || opt.ff_lanes_per_wave > 64) return fail(TB_E_INVAL, "tb_create: TbOptions.ff_lanes_per_wave must be in [0, 64]");
     if (opt.ff_phases < 0 || opt.ff_phases > 3) return fail(TB_E_INVAL, "tb_create: TbOptions.ff_phases must be in [0, 3]");
+    if (opt.policy_slices != 0 && opt.policy_slices != 1 && opt.policy_slices != 3) return fail(TB_E_INVAL, "tb_create: TbOptions.policy_slices must be 0, 1 or 3");
   }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -1606,7 +1635,6 @@ int tb_policy_step(TbHandle* h, const float* weights_dev, const float* obs_in_de
                    float* value_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, uint64_t noise_seed, int deterministic, void* stream) {
   if (!h || !weights_dev || !obs_in_dev || !actions_dev || !raw_actions_dev || !logp_dev || !value_dev || !obs_dev || !reward_dev || !done_dev)
     return fail(TB_E_INVAL, "tb_policy_step: null argument");
-  if (extended_contacts(h->kp)) return fail(TB_E_UNSUPPORTED, "tb_policy_step is not instantiated with TB_F_RACKET_GROUND / rolling friction");
   DeviceGuard g(h->device);
   PolicyIO pol = {weights_dev, obs_in_dev, actions_dev, raw_actions_dev, logp_dev, value_dev, noise_seed, deterministic};
   return launch_step(h, 1, nullptr, obs_dev, reward_dev, done_dev, nullptr, nullptr, (hipStream_t)stream, &pol);
@@ -1619,7 +1647,6 @@ int tb_policy_rollout(TbHandle* h, int n_steps, const float* weights_dev, const 
     return fail(TB_E_INVAL, "tb_policy_rollout: null argument");
   if (n_steps < 1) return fail(TB_E_INVAL, "tb_policy_rollout: n_steps must be >= 1");
   if (!(h->kp.flags & TB_F_AUTO_RESET)) return fail(TB_E_UNSUPPORTED, "tb_policy_rollout needs TB_F_AUTO_RESET (episodes must restart inside the launch)");
-  if (extended_contacts(h->kp)) return fail(TB_E_UNSUPPORTED, "tb_policy_rollout is not instantiated with TB_F_RACKET_GROUND / rolling friction");
   const bool swing = h->kind == TB_ENV_SWING;
   if (swing && !(h->pipeline && h->phase_valid))
     return fail(TB_E_UNSUPPORTED, "tb_policy_rollout on SwingRacket-v0 needs tb_set_pipeline(h, 1) and episodes in lockstep (every env reset together): "
@@ -1741,6 +1768,15 @@ int tb_diag_stream_copy(const uint32_t* src_dev, uint32_t* dst_dev, int n, int r
   DeviceGuard g(device);
   if (g.err != hipSuccess) return fail((int)g.err, "hipSetDevice");
   hipLaunchKernelGGL(tb_diag_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src_dev, dst_dev, n, rows);
+  HIP_TRY(hipGetLastError());
+  return TB_OK;
+}
+
+int tb_diag_idle(int waves, int microseconds, int device, void* stream) {
+  if (waves <= 0 || microseconds <= 0) return fail(TB_E_INVAL, "tb_diag_idle: bad argument");
+  DeviceGuard g(device);
+  if (g.err != hipSuccess) return fail((int)g.err, "hipSetDevice");
+  hipLaunchKernelGGL(tb_diag_idle_kernel, dim3((unsigned)waves), dim3(64), 0, (hipStream_t)stream, (unsigned long long)microseconds * 100ull);
   HIP_TRY(hipGetLastError());
   return TB_OK;
 }

@@ -48,7 +48,8 @@ _ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "sc
 class TbParams(ctypes.Structure):
     _fields_ = [
         ("dt", ctypes.c_float), ("inv_dt", ctypes.c_float), ("gravity", ctypes.c_float),
-        ("lin_damp", ctypes.c_float), ("ang_damp", ctypes.c_float), ("max_ang_step", ctypes.c_float),
+        ("lin_damp", ctypes.c_float), ("ang_damp", ctypes.c_float), ("lin_damp_quad", ctypes.c_float), ("ang_damp_quad", ctypes.c_float),
+        ("max_ang_step", ctypes.c_float),
         ("rest_vel_threshold", ctypes.c_float), ("erp", ctypes.c_float), ("contact_threshold", ctypes.c_float),
         ("solver_iters", ctypes.c_int32), ("solver_tol", ctypes.c_float), ("flags", ctypes.c_uint32),
         ("racket_mass", ctypes.c_float), ("racket_inv_mass", ctypes.c_float),
@@ -78,14 +79,14 @@ class TbParams(ctypes.Structure):
 
 
 class TbOptions(ctypes.Structure):
-    """kernel-selection options of tb_create (include/tb_stepper.h, ABI v3): 0 = the library chooses.
+    """kernel-selection options of tb_create (include/tb_stepper.h, ABI v4): 0 = the library chooses.
     They never change a result, only which bit-identical instantiation runs."""
     _fields_ = [("struct_size", ctypes.c_uint32), ("block", ctypes.c_int32), ("tennis_reg_rows", ctypes.c_int32),
                 ("swing_reg_rows", ctypes.c_int32), ("ff_lanes_per_wave", ctypes.c_int32), ("ff_sort", ctypes.c_int32),
-                ("ff_phases", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("ff_phases", ctypes.c_int32), ("policy_slices", ctypes.c_int32)]
 
 
-def make_options(block=0, tennis_reg_rows=None, swing_reg_rows=None, ff_lanes_per_wave=0, ff_sort=None, ff_phases=0):
+def make_options(block=0, tennis_reg_rows=None, swing_reg_rows=None, ff_lanes_per_wave=0, ff_sort=None, ff_phases=0, policy_slices=0):
     """None = auto; True / False force a variant on / off"""
     def tri(x):
         return 0 if x is None else (1 if x else -1)
@@ -93,6 +94,7 @@ def make_options(block=0, tennis_reg_rows=None, swing_reg_rows=None, ff_lanes_pe
     o.struct_size = ctypes.sizeof(TbOptions)
     o.block, o.tennis_reg_rows, o.swing_reg_rows = int(block), tri(tennis_reg_rows), tri(swing_reg_rows)
     o.ff_lanes_per_wave, o.ff_sort, o.ff_phases = int(ff_lanes_per_wave), tri(ff_sort), int(ff_phases)
+    o.policy_slices = int(policy_slices)
     return o
 
 
@@ -163,7 +165,8 @@ def default_params(racket_scale=1.0, flags=F_DEFAULT, scene=None, **overrides):
     prim = dict(
         dt=1.0 / 240.0,                 # racket.py:24; PyBullet default fixed time step
         gravity=9.81,                   # swingracket_env.py:154
-        lin_damp=0.04, ang_damp=0.04,   # [3P-recalled] PyBullet default damping
+        lin_damp=0.04, ang_damp=0.04,   # [3P-recalled] PyBullet default damping: force -m v (k1 + k2 |v|), k1 = k2 = this value
+        lin_damp_quad=None, ang_damp_quad=None,  # k2 on its own (None = the same as k1, as in Bullet)
         max_ang_step=0.25 * math.pi,
         rest_vel_threshold=0.2,
         # contact ERP: Bullet's library default is 0.2, but PyBullet's server creates its world with
@@ -193,9 +196,12 @@ def default_params(racket_scale=1.0, flags=F_DEFAULT, scene=None, **overrides):
     if unknown:
         raise TypeError("unknown parameter(s): %s" % sorted(unknown))
     prim.update(overrides)
+    for k in ("lin_damp", "ang_damp"):
+        if prim[k + "_quad"] is None:
+            prim[k + "_quad"] = prim[k]
 
     p = TbParams()
-    for k in ("dt", "gravity", "lin_damp", "ang_damp", "max_ang_step", "rest_vel_threshold", "erp",
+    for k in ("dt", "gravity", "lin_damp", "ang_damp", "lin_damp_quad", "ang_damp_quad", "max_ang_step", "rest_vel_threshold", "erp",
               "contact_threshold", "solver_tol", "racket_mass", "hull_margin", "ball_mass", "ball_radius", "magnus_k",
               "ball_spin_max", "rest_racket", "rest_court", "rest_goal", "fric_racket", "fric_court",
               "fric_goal", "roll_racket", "roll_court", "roll_goal", "rest_racket_court", "fric_racket_court", "goal_radius",

@@ -81,33 +81,32 @@ def build_actor_critic(obs_dim, act_dim, net_arch=(32, 64, 32)):
     return ActorCritic()
 
 
-def _row_of(r):
-    """row of a 32x32 MFMA accumulator tile held by register r on lanes 0-31 (lanes 32-63: +4)"""
-    return (r & 3) + 8 * (r >> 2)
-
-
 def _fragment_indices(n_in, n_out, first_layer):
     """Gather indices into [bias (n_out), W^T (n_in x n_out) row-major, one trailing 0.0] that produce
-    one layer of the blob `tb_policy_step` reads: bias tiles [out/32][2 halves][16 regs], then weight
-    fragments [out/32][pairs][2][32] (include/tb_stepper.h; csrc/tb_stepper.hip, LayerRegs)."""
+    one layer of the blob `tb_policy_step` reads (include/tb_stepper.h; csrc/tb_policy.hpp, LayerRegs): bias tiles
+    [out/16][4 lane groups][4 regs], then weight fragments [out/16][chunks][64 lanes] of v_mfma_f32_16x16x4_f32 -- lane l of
+    a fragment holds W[out 16 t + l % 16][k(chunk, l // 16)]. The first layer takes k in natural order, k = 4 c + g (zero
+    beyond the observation); every later layer takes it in the order the previous layer's accumulator registers hold it:
+    chunk 4 u + r = register r of output tile u, whose lane group g holds row 16 u + 4 g + r."""
     zero = n_out + n_in * n_out
     if first_layer:
-        pairs = [(2 * p, 2 * p + 1) for p in range(n_in // 2)]
-    else:  # the previous layer's accumulator registers ARE this layer's B operands, in register order
-        pairs = [(32 * t + _row_of(r), 32 * t + _row_of(r) + 4) for t in range(n_in // 32) for r in range(16)]
-    n_tiles = (n_out + 31) // 32
+        chunks = [[4 * c + g for g in range(4)] for c in range((n_in + 3) // 4)]
+    else:
+        assert n_in % 16 == 0
+        chunks = [[16 * u + 4 * g + r for g in range(4)] for u in range(n_in // 16) for r in range(4)]
+    n_tiles = (n_out + 15) // 16
     idx = []
     for t in range(n_tiles):
-        for h in range(2):
-            for r in range(16):
-                o = 32 * t + _row_of(r) + 4 * h
+        for g in range(4):
+            for r in range(4):
+                o = 16 * t + 4 * g + r
                 idx.append(o if o < n_out else zero)
     for t in range(n_tiles):
-        for pair in pairs:
-            for k in pair:
-                for j in range(32):
-                    o = 32 * t + j
-                    idx.append(n_out + k * n_out + o if o < n_out else zero)
+        for ks in chunks:
+            for g in range(4):
+                for j in range(16):
+                    o, k = 16 * t + j, ks[g]
+                    idx.append(n_out + k * n_out + o if (o < n_out and k < n_in) else zero)
     return idx
 
 
@@ -147,7 +146,7 @@ class PPOTrainer:
     """clipped-surrogate PPO over a BatchedEnv; one process per GPU when distributed"""
 
     def __init__(self, env_id="SwingRacket-v0", num_envs=4096, n_steps=104, device=None, seed=0, batch_size=None,
-                 pipeline=True, graph=True, fused=True, rollout_launch=True, **hp):
+                 pipeline=True, graph=True, fused=True, rollout_launch=True, params=None, **hp):
         import torch
         self.torch = torch
         kind = ENV_IDS[env_id]
@@ -158,7 +157,9 @@ class PPOTrainer:
         dist = torch.distributed
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
-        self.env = BatchedEnv(kind, num_envs, device=device, seed=seed, env_id_base=self.rank * num_envs,
+        # params: a TbParams (default_params(flags=..., **overrides)), e.g. the reference's full contact set
+        # (TB_F_RACKET_GROUND, rolling friction): the fused policy kernels are instantiated for it too
+        self.env = BatchedEnv(kind, num_envs, device=device, seed=seed, env_id_base=self.rank * num_envs, params=params,
                               track_terminal_obs=False, pipeline=pipeline and kind == ENV_SWING)
         self.device = self.env.device
         self.n_steps, self.num_envs = int(n_steps), int(num_envs)

@@ -19,7 +19,7 @@ from .params import (ACT_DIM, COUNTER_NAMES, ENV_SWING, ENV_TENNIS, F_AUTO_RESET
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtb_stepper.so")
 _LIB = None
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 ENV_IDS = {"SwingRacket-v0": ENV_SWING, "Tennisbot-v0": ENV_TENNIS}  # tennisbot/__init__.py:3-11
 
@@ -104,6 +104,8 @@ def load_library():
     L.tb_mark_enable.restype = i32
     L.tb_diag_stream_copy.argtypes = [vp, vp, i32, i32, i32, vp]
     L.tb_diag_stream_copy.restype = i32
+    L.tb_diag_idle.argtypes = [i32, i32, i32, vp]
+    L.tb_diag_idle.restype = i32
     L.tb_diag_fail_alloc.argtypes = [i32]
     L.tb_diag_fail_alloc.restype = i32
     for f in ("tb_create", "tb_destroy", "tb_set_params", "tb_reset", "tb_step", "tb_rollout", "tb_get_state",

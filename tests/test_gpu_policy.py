@@ -43,7 +43,13 @@ def numpy_policy(policy, obs):
     return mean, value[:, 0], sd["log_std"]
 
 
-def make(torch, kind, n, seed=5, scale=1.0):
+def extended_params():
+    """the reference's full contact set: racket<->court contact + the rolling-friction rows"""
+    from tennisbot_rl_amd.params import F_DEFAULT, F_RACKET_GROUND, default_params, reference_rolling_friction
+    return default_params(flags=F_DEFAULT | F_RACKET_GROUND, **reference_rolling_friction())
+
+
+def make(torch, kind, n, seed=5, scale=1.0, params=None):
     from tennisbot_rl_amd.ppo import SWING_DEFAULTS, TENNIS_DEFAULTS, build_actor_critic, pack_policy
     from tennisbot_rl_amd.stepper import BatchedEnv
     torch.manual_seed(seed)
@@ -52,14 +58,16 @@ def make(torch, kind, n, seed=5, scale=1.0):
     with torch.no_grad():  # SB3's init has a near-zero action head; make the test see real signal
         policy.action_net.weight.mul_(30.0 * scale)
         policy.log_std.copy_(torch.linspace(-1.0, 0.2, ACT_DIM[kind]))
-    env = BatchedEnv(kind, n, device="cuda:0", seed=seed)
-    twin = BatchedEnv(kind, n, device="cuda:0", seed=seed)
+    env = BatchedEnv(kind, n, device="cuda:0", seed=seed, params=params)
+    twin = BatchedEnv(kind, n, device="cuda:0", seed=seed, params=params)
     return policy, pack_policy(policy), env, twin
 
 
-@pytest.mark.parametrize("kind,n", [(ENV_SWING, 4096), (ENV_SWING, 257), (ENV_TENNIS, 4096), (ENV_TENNIS, 65)])
-def test_deterministic_policy_step_matches_module_and_plain_step(torch, kind, n):
-    policy, packed, env, twin = make(torch, kind, n)
+@pytest.mark.parametrize("kind,n,full", [(ENV_SWING, 4096, False), (ENV_SWING, 257, False), (ENV_TENNIS, 4096, False), (ENV_TENNIS, 65, False),
+                                         (ENV_SWING, 1000, True), (ENV_TENNIS, 1000, True)])
+def test_deterministic_policy_step_matches_module_and_plain_step(torch, kind, n, full):
+    # full: the reference's full contact set (racket<->court contact, rolling friction) -- f3 composes with f1
+    policy, packed, env, twin = make(torch, kind, n, params=extended_params() if full else None)
     assert packed.numel() == env.policy_floats()
     obs_a, obs_b = env.reset(), twin.reset()
     assert torch.equal(obs_a, obs_b)
@@ -154,8 +162,10 @@ def test_policy_step_rejects_bad_arguments(torch):
     with pytest.raises(ValueError):
         env.policy_step(packed, torch.zeros((64, 5), device="cuda:0"))
     rg = BatchedEnv(ENV_SWING, 64, device="cuda:0", params=default_params(flags=F_DEFAULT | F_RACKET_GROUND))
+    (o, r, d), _ = rg.policy_step(packed, rg.reset())  # (refused until round 3: the policy kernels now exist for the extended contact set)
+    assert o.shape == (64, 6) and bool(torch.isfinite(o).all())
     with pytest.raises(StepperError):
-        rg.policy_step(packed, rg.reset())
+        BatchedEnv(ENV_SWING, 64, device="cuda:0", options=dict(policy_slices=2))
 
 
 def test_reference_policy_reward_distribution_matches_the_pybullet_record(torch):
@@ -193,8 +203,73 @@ def test_reference_policy_reward_distribution_matches_the_pybullet_record(torch)
     assert 0.01 < s_got["two_bonus_good_shots"] < 0.10 and 0.03 < s_ref["two_bonus_good_shots"] < 0.07, (s_got, s_ref)
 
 
-@pytest.mark.parametrize("kind,n,T,lead", [(ENV_SWING, 1000, 70, 9), (ENV_SWING, 4096, 52, 0), (ENV_TENNIS, 777, 150, 3)])
-def test_policy_rollout_equals_repeated_policy_steps(torch, kind, n, T, lead):
+def test_leave_half_out_selection_of_the_two_constants_chosen_on_the_record(torch):
+    """HOLD-OUT for the two engine constants that were selected on the PyBullet record in round 1 (inertia source, contact ERP).
+    The rule is fixed here, before the second half of the record is looked at: of the four candidates {inertia from the collision
+    shapes, from the URDF files} x {ERP 0.08, 0.2}, drop those under which the FIRST half's count of double-bonus episodes (racket
+    contact reported on two consecutive agent steps of a good shot: 3 of 49) has binomial probability < 0.01, and of the rest take the
+    smallest two-sample KS D against the first half's returns (episodes 0-48). The winner is then TESTED on episodes 49-97 with
+    thresholds fixed here: D below the 1 % critical value 1.628 / sqrt(49) = 0.233, and the second half's double-bonus count (2 of
+    49) not improbable under it (p >= 0.01). Measured (profiles/r03_pin_sensitivity.md): shape/0.08 wins (ERP 0.2 never produces a
+    double bonus: p = 0; URDF inertia: D 0.196 vs 0.149) and passes with D = 0.144, p = 0.47; both URDF candidates fail the second half."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import compare_reference_policy as crp
+    from pin_sensitivity import binom_tail, two_bonus_count
+    from tennisbot_rl_amd.params import urdf_file_inertia
+    ref, _ = crp.reference_record()
+    first, second = ref[:49], ref[49:]
+    assert first.size == second.size == 49 and two_bonus_count(first) == 3 and two_bonus_count(second) == 2
+    cands = {}
+    for iname, iover in (("shape", {}), ("urdf", urdf_file_inertia())):
+        for erp in (0.08, 0.2):
+            r = crp.rollout_rewards(num_envs=4096, episodes=4, erp=erp, **iover)
+            rate = crp.summarize(r)["two_bonus_good_shots"]
+            cands[(iname, erp)] = dict(D1=crp.ks_two_sample(first, r)[0], D2=crp.ks_two_sample(second, r)[0],
+                                       p1=binom_tail(3, 49, rate), p2=binom_tail(2, 49, rate))
+    alive = [k for k, v in cands.items() if v["p1"] >= 0.01]
+    chosen = min(alive, key=lambda k: cands[k]["D1"])
+    assert chosen == ("shape", 0.08), (chosen, cands)          # what round 1 had selected on the whole record
+    crit = 1.628 / 49 ** 0.5
+    won = cands[chosen]
+    assert won["D2"] < crit and won["p2"] >= 0.01, won          # ... holds on the half it was not selected on
+    assert cands[("urdf", 0.08)]["D2"] > crit and cands[("urdf", 0.2)]["D2"] > crit, cands   # and the alternatives do not
+    assert cands[("shape", 0.2)]["p2"] < 0.01, cands
+
+
+def test_reference_critic_predicts_the_returns_realised_here(torch):
+    """A state-conditional check with thousands of samples instead of a 98-sample marginal: the reference's CRITIC (value head of
+    backup_models/ppo_swing.zip, weights in tests/golden/ppo_swing_policy.npz) was fitted under PyBullet to the discounted return
+    (gamma = 0.99) from the reset observation. 16 384 episodes of the shipped stochastic policy on the HIP envs, binned into 10
+    quantile bins of V(s0): the realised mean return per bin against the predicted one. Bounds fixed here (measured: slope 0.987,
+    intercept -1.20, correlation 0.53, means 24.9 predicted / 23.3 realised, largest bin gap 3.6; profiles/r03_pin_sensitivity.md):
+    0.85 <= slope <= 1.15, |intercept| <= 3, per-episode correlation >= 0.45, means within 12 %, no bin off by more than 5.5.
+    It discriminates: with the URDF files' inertia or half / double the damping the slope is below 0.2 (measured -0.03, 0.14, -0.61)
+    -- those engines send the balls somewhere else than PyBullet did, in a way that depends on the start state. Not a trajectory pin:
+    the parity text stays "unpinned"."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import compare_reference_policy as crp
+    from tennisbot_rl_amd.params import urdf_file_inertia
+    _, disc, v0 = crp.rollout_rewards(num_envs=4096, episodes=4, gamma=0.99)
+    c = crp.critic_calibration(v0, disc)
+    assert disc.size == 16384 and len(c["bins"]) == 10
+    assert 0.85 <= c["slope"] <= 1.15 and abs(c["intercept"]) <= 3.0 and c["corr"] >= 0.45, c
+    assert abs(c["mean_realised"] / c["mean_predicted"] - 1.0) <= 0.12 and c["max_bin_gap"] <= 5.5, c
+    for over in (urdf_file_inertia(), dict(lin_damp=0.02, ang_damp=0.02), dict(lin_damp=0.08, ang_damp=0.08)):
+        _, d2, v2 = crp.rollout_rewards(num_envs=4096, episodes=4, gamma=0.99, **over)
+        c2 = crp.critic_calibration(v2, d2)
+        assert c2["slope"] < 0.5 and c2["max_bin_gap"] > 15.0, (over, c2)
+
+
+@pytest.mark.parametrize("kind,n,T,lead,full,slices", [(ENV_SWING, 1000, 70, 9, False, 0), (ENV_SWING, 4096, 52, 0, False, 0), (ENV_TENNIS, 777, 150, 3, False, 0),
+                                                       (ENV_SWING, 1000, 70, 9, False, 3), (ENV_TENNIS, 5000, 40, 3, False, 0),
+                                                       (ENV_SWING, 1000, 104, 5, True, 0), (ENV_SWING, 1000, 52, 0, True, 3), (ENV_TENNIS, 777, 150, 3, True, 1)])
+def test_policy_rollout_equals_repeated_policy_steps(torch, kind, n, T, lead, full, slices):
     """tb_policy_rollout (whole episodes per launch, weights and env state resident in registers)
     against tb_policy_step called T times: every output of every step bit-identical, from a start in
     the middle of an episode, with the SwingRacket fast-forwards on the side streams"""
@@ -208,8 +283,10 @@ def test_policy_rollout_equals_repeated_policy_steps(torch, kind, n, T, lead):
         policy.log_std.fill_(-0.5)
     blob = pack_policy(policy)
     pipe = kind == ENV_SWING
-    a = BatchedEnv(kind, n, device="cuda:0", seed=8, pipeline=pipe, track_terminal_obs=False)
-    b = BatchedEnv(kind, n, device="cuda:0", seed=8, pipeline=pipe, track_terminal_obs=False)
+    # slices: TbOptions.policy_slices (0 = auto: one 16-env slice per workgroup up to 4096 envs, three above); full: the extended contact set
+    prm = extended_params() if full else None
+    a = BatchedEnv(kind, n, device="cuda:0", seed=8, pipeline=pipe, track_terminal_obs=False, params=prm, options=dict(policy_slices=slices))
+    b = BatchedEnv(kind, n, device="cuda:0", seed=8, pipeline=pipe, track_terminal_obs=False, params=prm)
     oa, ob = a.reset(), b.reset()
     for t in range(lead):
         (oa, _, _), _ = a.policy_step(blob, oa, seed=5)

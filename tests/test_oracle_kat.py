@@ -275,6 +275,24 @@ def test_damping_one_step():
     assert (v0[0] - b.get_state()["ball_vel"][0, 0]) / DT == pytest.approx(0.04 * (1 + np.linalg.norm(v0)) * 15, rel=1e-6)
 
 
+def test_damping_terms_are_separate_parameters():
+    """k1 and k2 of -m v (k1 + k2 |v|) are one value in Bullet (0.04) and two TbParams fields here: k2 = 0 leaves pure linear
+    drag -- v_k = v0 (1 - k1 dt)^k without gravity, a closed form -- and k1 = 0 the speed-proportional term alone"""
+    v0 = np.float32((15.0, -2.0, 3.0)).astype(np.float64)
+    w, d = make_words(ENV_TENNIS, 1, racket_pos=(10, 0, 0.7), ball_pos=FAR, ball_vel=v0, step_count=10)
+    b = batch(ENV_TENNIS, gravity=0.0, lin_damp_quad=0.0, ang_damp_quad=0.0)
+    b.set_state_words(w, d)
+    for _ in range(10):
+        b.step(np.zeros((1, 2), np.float32))
+    assert np.allclose(b.get_state()["ball_vel"][0], v0 * (1.0 - 0.04 * DT) ** 10, rtol=1e-12)
+    b = batch(ENV_TENNIS, gravity=0.0, lin_damp=0.0, lin_damp_quad=0.04)
+    b.set_state_words(w, d)
+    b.step(np.zeros((1, 2), np.float32))
+    assert np.allclose(b.get_state()["ball_vel"][0], v0 * (1.0 - DT * 0.04 * np.linalg.norm(v0)), rtol=1e-12)
+    p = default_params(lin_damp=0.07)
+    assert p.lin_damp_quad == p.lin_damp == np.float32(0.07) and p.ang_damp_quad == p.ang_damp  # unset: k2 follows k1, as in Bullet
+
+
 def test_tennis_shoot_pulse():
     """5 substeps of F=(30,0,20) on 0.05 kg (tennisbot_env.py:118-119): v = (12.5, 0, 8.1290)"""
     b = batch(ENV_TENNIS, lin_damp=0.0, ang_damp=0.0)

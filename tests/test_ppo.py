@@ -122,33 +122,34 @@ def test_resumed_checkpoint_collects_and_learns_like_an_unpipelined_trainer(tmp_
 
 def _emulate_blob(blob, obs, kind):
     """What the fused kernel computes from the packed blob, restated with numpy from the MFMA
-    semantics alone (v_mfma_f32_32x32x2_f32: D[i][j] += sum_kk A[i][kk] * B[kk][j]; operand lane
-    l = 32 * kk + index; accumulator register r on lane half h holds row (r&3) + 8(r>>2) + 4h):
+    semantics alone (v_mfma_f32_16x16x4_f32: D[i][j] += sum_g A[i][g] * B[g][j]; operand lane
+    l = 16 * g + index; accumulator register r on lane group g holds row 4 g + r; a wave works on 16 envs):
     returns (mean [n, A], value [n], log_std [A]). Independent of the packer's index tables."""
     from tennisbot_rl_amd.params import ACT_DIM, ENV_SWING, OBS_DIM
     hidden = (32, 64, 32) if kind == ENV_SWING else (64, 64)
     n_obs, n_act = OBS_DIM[kind], ACT_DIM[kind]
     blob = np.asarray(blob, dtype=np.float64)
-    row = lambda r: (r & 3) + 8 * (r >> 2)
+    n_env = obs.shape[0]
     pos, heads = 0, []
     for tower in range(2):
-        # B operands of the first layer: pair p, lane half h -> obs[2p + h]
-        x = np.stack([np.stack([obs[:, 2 * p + h] for h in range(2)], 0) for p in range(n_obs // 2)], 0)  # [pairs][h][env]
-        widths = list(hidden) + [32]
+        # B operands of the first layer: chunk c, lane group g -> obs[4c + g] (0 beyond the observation)
+        padded = np.concatenate([obs, np.zeros((n_env, -n_obs % 4))], 1)
+        x = np.stack([np.stack([padded[:, 4 * c + g] for g in range(4)], 0) for c in range(padded.shape[1] // 4)], 0)  # [chunks][g][env]
+        widths = list(hidden) + [16]
         for li, n_out in enumerate(widths):
-            n_tiles, n_pairs = n_out // 32, x.shape[0]
-            bias = blob[pos:pos + n_tiles * 32].reshape(n_tiles, 2, 16); pos += n_tiles * 32
-            frag = blob[pos:pos + n_tiles * n_pairs * 64].reshape(n_tiles, n_pairs, 2, 32); pos += n_tiles * n_pairs * 64
+            n_tiles, n_chunks = n_out // 16, x.shape[0]
+            bias = blob[pos:pos + n_tiles * 16].reshape(n_tiles, 4, 4); pos += n_tiles * 16
+            frag = blob[pos:pos + n_tiles * n_chunks * 64].reshape(n_tiles, n_chunks, 4, 16); pos += n_tiles * n_chunks * 64
             y = []
             for t in range(n_tiles):
-                d = np.einsum("pki,pke->ie", frag[t], x)  # D[i][env]
-                for r in range(16):
-                    y.append(np.stack([d[row(r) + 4 * h] + bias[t, h, r] for h in range(2)], 0))  # register r: [h][env]
+                d = np.einsum("cgi,cge->ie", frag[t], x)  # D[i][env]
+                for r in range(4):
+                    y.append(np.stack([d[4 * g + r] + bias[t, g, r] for g in range(4)], 0))  # register r: [g][env]
             x = np.stack(y, 0)
             if li < len(hidden):
                 x = np.tanh(x)
-        heads.append(x)  # [16 regs][h][env] of the head tile
-    out = lambda head, i: head[i & 3, i >> 2]  # head row i < 8: register i & 3 of lane half i >> 2
+        heads.append(x)  # [4 regs][g][env] of the head tile
+    out = lambda head, i: head[i & 3, i >> 2]  # head row i: register i & 3 of lane group i >> 2
     mean = np.stack([out(heads[0], i) for i in range(n_act)], -1)
     value = out(heads[1], 0)
     log_std = blob[pos:pos + n_act]

@@ -20,7 +20,10 @@ def bullet_recomputed_inertia():
     return bullet_shape_inertia()
 
 
-def rollout_rewards(num_envs=4096, episodes=4, seed=0, racket_ground=False, **overrides):
+def rollout_rewards(num_envs=4096, episodes=4, seed=0, racket_ground=False, gamma=None, net=True, **overrides):
+    """episode returns of the reference's shipped policy (stochastic, its own log_std) on the HIP envs. gamma: also return, per
+    episode, the DISCOUNTED return sum_t gamma^t r_t and the reference critic's V(s0) (its value head, evaluated by the same fused
+    kernel on the episode's reset observation): (returns, discounted, v0)."""
     import torch
     from tennisbot_rl_amd.params import ENV_SWING, F_DEFAULT, F_RACKET_GROUND, default_params
     from tennisbot_rl_amd.ppo import build_actor_critic, pack_policy
@@ -29,27 +32,56 @@ def rollout_rewards(num_envs=4096, episodes=4, seed=0, racket_ground=False, **ov
     policy.load_sb3_arrays(dict(np.load(os.path.join(ROOT, "tests", "golden", "ppo_swing_policy.npz"))))
     blob = pack_policy(policy)
     flags = F_DEFAULT | (F_RACKET_GROUND if racket_ground else 0)
+    if not net:
+        from tennisbot_rl_amd.params import F_NET
+        flags &= ~F_NET
     env = BatchedEnv(ENV_SWING, num_envs, device="cuda:0", seed=seed, pipeline=True, track_terminal_obs=False, params=default_params(flags=flags, **overrides))
     obs = env.reset()
-    # the fused policy kernels are built without the extended contact set: roll the torch module out instead
-    fused = not racket_ground and not any(k.startswith("roll_") and v > 0 for k, v in overrides.items())
+    fused = True  # (since round 3 the fused policy kernels are instantiated with the extended contact set too)
     torch.manual_seed(seed + 17)
-    out = []
+    out, disc, v0s = [], [], []
     for ep in range(episodes):
-        steps = []
+        steps, v0 = [], None
         for t in range(26):
             if fused:
-                (obs, rew, done), _ = env.policy_step(blob, obs, seed=seed + 17)
+                (obs, rew, done), (_, _, _, value) = env.policy_step(blob, obs, seed=seed + 17)
             else:
                 with torch.no_grad():
-                    act, _, _ = policy.act(obs)
+                    act, value, _ = policy.act(obs)
                 obs, rew, done = env.step(act.clamp(-1.0, 1.0))
+            if t == 0:
+                v0 = value.clone()
             steps.append((rew, done))
         env.flush()  # terminal rewards arrive from the side streams
-        ret = torch.stack([r for r, _ in steps]).sum(0)
+        r = torch.stack([r for r, _ in steps])
         assert bool(steps[-1][1].all()) and not bool(torch.stack([d for _, d in steps[:-1]]).any())
-        out.append(ret.cpu().numpy())
+        out.append(r.sum(0).cpu().numpy())
+        if gamma is not None:
+            w = torch.tensor([gamma ** t for t in range(26)], device=r.device, dtype=torch.float64)
+            disc.append((r.double() * w[:, None]).sum(0).cpu().numpy())
+            v0s.append(v0.double().cpu().numpy())
+    env.close()
+    if gamma is not None:
+        return np.concatenate(out), np.concatenate(disc), np.concatenate(v0s)
     return np.concatenate(out)
+
+
+def critic_calibration(v0, disc, bins=10):
+    """The reference's critic (value_net of backup_models/ppo_swing.zip, trained under PyBullet on discounted returns, gamma = 0.99)
+    against the returns realised HERE: episodes binned into `bins` quantile bins of V(s0); per bin the mean prediction and the mean
+    realised discounted return; least-squares line realised = slope * predicted + intercept through the bin means, and the
+    correlation of the per-episode values. A state-conditional check with thousands of samples: an engine that treats some
+    region of start states differently from PyBullet bends the line there."""
+    v0, disc = np.asarray(v0, np.float64), np.asarray(disc, np.float64)
+    order = np.argsort(v0)
+    chunks = np.array_split(order, bins)
+    pred = np.array([v0[c].mean() for c in chunks])
+    real = np.array([disc[c].mean() for c in chunks])
+    sem = np.array([disc[c].std(ddof=1) / np.sqrt(c.size) for c in chunks])
+    slope, intercept = np.polyfit(pred, real, 1)
+    return {"bins": [{"n": int(c.size), "predicted": float(p), "realised": float(r), "sem": float(e)} for c, p, r, e in zip(chunks, pred, real, sem)],
+            "slope": float(slope), "intercept": float(intercept), "corr": float(np.corrcoef(v0, disc)[0, 1]),
+            "mean_predicted": float(v0.mean()), "mean_realised": float(disc.mean()), "max_bin_gap": float(np.abs(pred - real).max())}
 
 
 def reference_record(exclude_interrupted=True):

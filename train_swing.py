@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--gui", action="store_true", help="accepted for CLI compatibility; there is no GUI")
     ap.add_argument("-s", "--select", default="ppo", help="only ppo is provided (sac / tqc / trpo are third-party learners)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--racket-ground", action="store_true", help="also simulate racket<->court contact (court.urdf:19-24; TB_F_RACKET_GROUND, opt-in: DESIGN.md section 3)")
+    ap.add_argument("--rolling-friction", action="store_true", help="also solve the rolling-friction rows of every ball contact (rollingFriction=.001 in racket.py:43-45, objects.py:29-31,48-50)")
     ap.add_argument("--no-fused", action="store_true", help="run the policy as torch modules between env steps instead of inside the step kernel")
     ap.add_argument("--log-json", type=str, default=None)
     args = ap.parse_args()
@@ -59,8 +61,12 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.distributed.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     total = args.total_timesteps or (2e6 if args.env == "SwingRacket-v0" else 1e6)
+    params = None
+    if args.racket_ground or args.rolling_friction:
+        from tennisbot_rl_amd.params import F_DEFAULT, F_RACKET_GROUND, default_params, reference_rolling_friction
+        params = default_params(flags=F_DEFAULT | (F_RACKET_GROUND if args.racket_ground else 0), **(reference_rolling_friction() if args.rolling_friction else {}))
     tr = PPOTrainer(args.env, num_envs=args.num_envs, n_steps=args.n_steps, device=torch.device("cuda", local_rank), seed=args.seed,
-                    fused=not args.no_fused)
+                    fused=not args.no_fused, params=params)
     if args.load_reference:
         import numpy as np
         tr.policy.load_sb3_arrays(dict(np.load(os.path.join(ROOT, "tests", "golden", "ppo_swing_policy.npz"))))
