@@ -176,6 +176,19 @@ typedef struct TbOptions {
   int32_t ff_sort;          /* order parked envs by their ball's ballistic flight estimate before the fast-forward: 1 on (auto: off --
                              * with random actions the flight lengths are decided by events inside the loop, not by the parked state) */
   int32_t ff_phases;        /* the fast-forward as 1, 2 or 3 kernels: budgeted loop, then its compacted survivors (auto: 3 from 262144 envs on, else 1; from 131072 envs on the first of several also hands over every env whose ball reaches the racket) */
+  int32_t ff_defer;         /* deferred stragglers (SwingRacket-v0 pipeline, up to 131072 envs): a parked env still running after its ballistic
+                             * flight estimate + ff_defer_margin substeps moves on to a pool shared by all episodes, which ONE kernel launch runs
+                             * to its end when the caller joins (tb_flush and every call that flushes) -- hundreds of stragglers side by side
+                             * instead of one or two holding up each episode's fast-forward kernel. 1 on, -1 off, 2 = EVERY parked env goes
+                             * straight to the pool (no fast-forward kernel per episode at all: up to 64 episodes per join; what a PPO
+                             * collect wants, whose rollout kernels then run undisturbed and whose flights are long) (auto: 1 with
+                             * TB_F_RACKET_GROUND, whose resting stacks run to the 800-substep limit; off otherwise -- with random actions the
+                             * plain kernels are faster; tennisbot_rl_amd.ppo turns it on: struck balls fly long). Results do not change. Not
+                             * used while progress marks are enabled or terminal-observation / substep outputs are asked for. */
+  int32_t ff_defer_margin;  /* substeps beyond the estimate before an env is deferred (auto: 16) */
+  int32_t ff_eager_launch;  /* 1: enqueue an episode end's fast-forward right behind the parking launch, as rounds 1-2 did (auto: one launch
+                             * later, so that in a captured graph the NEXT STEP is the parking node's first successor and the chain of steps
+                             * stays on one hardware queue: csrc/tb_stepper.hip launch_ff) */
   int32_t policy_slices;    /* tb_policy_rollout: 16-env slices per workgroup, 1 (three waves per 16 envs) or 3 (seven waves per 48 envs) (auto: 1 up to 4096 envs) */
 } TbOptions;
 

@@ -773,40 +773,88 @@ TB_DEV void setup_ground_row(const KParams& P, const Manifold& M, int j, const S
   float pos = dist > 0.0f ? -(dist * P.inv_dt) : -(dist * P.erp) * P.inv_dt;
   mw(M, j, MW_TGT) = rest + pos;
 }
-TB_DEV void warm_start_ground(const KParams& P, const Manifold& M, int j, const Sym3& W, Racket& rk, float& jref) {
-  const vec3 rr = mani_arm(M, j);
-  const float jn = mw(M, j, MW_JN), jt1 = mw(M, j, MW_JT1), jt2 = mw(M, j, MW_JT2);
+// The racket<->court rows of ONE solve, seen through an accessor: LdsGround reads and writes the lane's LDS column at every
+// use (what every kernel did until round 3: no registers held for a path few lanes take); RegGround is a register copy made
+// once per solve (GroundRegs, statically indexed from unrolled loops) and written back at its end. Same arithmetic, same
+// order: bit-identical. Why both: a row update through LDS is ~12 DEPENDENT LDS round trips (~100 cycles each); a lane with a
+// racket at rest on the court and the ball on top of it -- 9 of 4096 random-action envs run like that to the 800-substep
+// limit, 3-5 sweeps x 5 rows x 3 directions per substep -- spent 22-60 us per substep on them, alone in its wave: fast-forward
+// kernels of 17-47 ms at 4096 envs (profiles/r03_racket_ground.md). Where one wave per SIMD is all there is anyway (small
+// batches) the registers cost nothing; the large-batch instantiations (BIG) keep the LDS form for occupancy.
+struct GroundRegs { float rx[TB_MAX_RG], ry[TB_MAX_RG], rz[TB_MAX_RG], kn[TB_MAX_RG], kt1[TB_MAX_RG], kt2[TB_MAX_RG], tgt[TB_MAX_RG], jn[TB_MAX_RG], jt1[TB_MAX_RG], jt2[TB_MAX_RG]; };
+struct LdsGround {
+  const Manifold& M; int j;
+  TB_DEV vec3 arm() const { return mani_arm(M, j); }
+  TB_DEV float kn() const { return mw(M, j, MW_KN); }
+  TB_DEV float kt1() const { return mw(M, j, MW_KT1); }
+  TB_DEV float kt2() const { return mw(M, j, MW_KT2); }
+  TB_DEV float tgt() const { return mw(M, j, MW_TGT); }
+  TB_DEV float jn() const { return mw(M, j, MW_JN); }
+  TB_DEV float jt1() const { return mw(M, j, MW_JT1); }
+  TB_DEV float jt2() const { return mw(M, j, MW_JT2); }
+  TB_DEV void set_jn(float v) const { mw(M, j, MW_JN) = v; }
+  TB_DEV void set_jt1(float v) const { mw(M, j, MW_JT1) = v; }
+  TB_DEV void set_jt2(float v) const { mw(M, j, MW_JT2) = v; }
+};
+template <int J> struct RegGround {
+  GroundRegs& G;
+  TB_DEV vec3 arm() const { return mk(G.rx[J], G.ry[J], G.rz[J]); }
+  TB_DEV float kn() const { return G.kn[J]; }
+  TB_DEV float kt1() const { return G.kt1[J]; }
+  TB_DEV float kt2() const { return G.kt2[J]; }
+  TB_DEV float tgt() const { return G.tgt[J]; }
+  TB_DEV float jn() const { return G.jn[J]; }
+  TB_DEV float jt1() const { return G.jt1[J]; }
+  TB_DEV float jt2() const { return G.jt2[J]; }
+  TB_DEV void set_jn(float v) const { G.jn[J] = v; }
+  TB_DEV void set_jt1(float v) const { G.jt1[J] = v; }
+  TB_DEV void set_jt2(float v) const { G.jt2[J] = v; }
+};
+template <int J> TB_DEV void load_ground_row(const Manifold& M, GroundRegs& G) {
+  G.rx[J] = mw(M, J, MW_RX); G.ry[J] = mw(M, J, MW_RY); G.rz[J] = mw(M, J, MW_RZ);
+  G.kn[J] = mw(M, J, MW_KN); G.kt1[J] = mw(M, J, MW_KT1); G.kt2[J] = mw(M, J, MW_KT2); G.tgt[J] = mw(M, J, MW_TGT);
+  G.jn[J] = mw(M, J, MW_JN); G.jt1[J] = mw(M, J, MW_JT1); G.jt2[J] = mw(M, J, MW_JT2);
+}
+template <int J> TB_DEV void store_ground_row(const Manifold& M, const GroundRegs& G) {
+  mw(M, J, MW_JN) = G.jn[J]; mw(M, J, MW_JT1) = G.jt1[J]; mw(M, J, MW_JT2) = G.jt2[J];
+}
+template <class Row>
+TB_DEV void warm_start_ground(const KParams& P, const Row& c, const Sym3& W, Racket& rk, float& jref) {
+  const vec3 rr = c.arm();
+  const float jn = c.jn(), jt1 = c.jt1(), jt2 = c.jt2();
   if (jn > jref) jref = jn;
   rk.v.z = FMA(jn, P.racket_inv_mass, rk.v.z);   rk.w = fma3(jn, sym3_mul(W, mk(rr.y, -rr.x, 0.0f)), rk.w);
   rk.v.y = FMA(-jt1, P.racket_inv_mass, rk.v.y); rk.w = fma3(jt1, sym3_mul(W, mk(rr.z, 0.0f, -rr.x)), rk.w);
   rk.v.x = FMA(jt2, P.racket_inv_mass, rk.v.x);  rk.w = fma3(jt2, sym3_mul(W, mk(0.0f, rr.z, -rr.y)), rk.w);
 }
-TB_DEV bool normal_ground(const KParams& P, const Manifold& M, int j, const Sym3& W, Racket& rk, float& jref) {
-  const vec3 rr = mani_arm(M, j);
-  const float old = mw(M, j, MW_JN);
+template <class Row>
+TB_DEV bool normal_ground(const KParams& P, const Row& c, const Sym3& W, Racket& rk, float& jref) {
+  const vec3 rr = c.arm();
+  const float old = c.jn();
   float vn = (rk.v + cross(rk.w, rr)).z;
-  float jn = FMA(mw(M, j, MW_TGT) - vn, mw(M, j, MW_KN), old);
+  float jn = FMA(c.tgt() - vn, c.kn(), old);
   if (jn < 0.0f) jn = 0.0f;
   float d = jn - old;
-  mw(M, j, MW_JN) = jn;
+  c.set_jn(jn);
   if (jn > jref) jref = jn;
   if (d == 0.0f) return false;
   rk.v.z = FMA(d, P.racket_inv_mass, rk.v.z);
   rk.w = fma3(d, sym3_mul(W, mk(rr.y, -rr.x, 0.0f)), rk.w);
   return fabsf(d) > P.solver_tol * jref;
 }
-TB_DEV bool friction_ground(const KParams& P, const Manifold& M, int j, const Sym3& W, Racket& rk, float jref) {
-  float lim = P.fric_racket_court * mw(M, j, MW_JN);
+template <class Row>
+TB_DEV bool friction_ground(const KParams& P, const Row& c, const Sym3& W, Racket& rk, float jref) {
+  float lim = P.fric_racket_court * c.jn();
   if (!(lim > 0.0f)) return false;
-  const vec3 rr = mani_arm(M, j);
+  const vec3 rr = c.arm();
   bool moved = false;
-  float d, acc = mw(M, j, MW_JT1);
-  bool m = clamp_friction(-((rk.v + cross(rk.w, rr)).y), mw(M, j, MW_KT1), lim, P.solver_tol, jref, acc, d);
-  mw(M, j, MW_JT1) = acc;
+  float d, acc = c.jt1();
+  bool m = clamp_friction(-((rk.v + cross(rk.w, rr)).y), c.kt1(), lim, P.solver_tol, jref, acc, d);
+  c.set_jt1(acc);
   if (d != 0.0f) { moved |= m; rk.v.y = FMA(-d, P.racket_inv_mass, rk.v.y); rk.w = fma3(d, sym3_mul(W, mk(rr.z, 0.0f, -rr.x)), rk.w); }
-  acc = mw(M, j, MW_JT2);
-  m = clamp_friction((rk.v + cross(rk.w, rr)).x, mw(M, j, MW_KT2), lim, P.solver_tol, jref, acc, d);
-  mw(M, j, MW_JT2) = acc;
+  acc = c.jt2();
+  m = clamp_friction((rk.v + cross(rk.w, rr)).x, c.kt2(), lim, P.solver_tol, jref, acc, d);
+  c.set_jt2(acc);
   if (d != 0.0f) { moved |= m; rk.v.x = FMA(d, P.racket_inv_mass, rk.v.x); rk.w = fma3(d, sym3_mul(W, mk(0.0f, rr.z, -rr.y)), rk.w); }
   return moved;
 }
@@ -824,12 +872,31 @@ template <> struct Rows<true> { RowR rk; RowS st[3]; int on; RollR qrk; RollS qs
 // the steady state; tb_create decides) and SwingRacket's loop-free pipelined step kernel up to 131072
 // envs (+2.7 % at 4096); in SwingRacket's fast-forward loop the registers cost more than they give
 // (-6 % at 4096 envs, -17 % at 1 M). Same arithmetic either way.
-template <bool RG, bool REGROWS, bool TWO = false>
+// REGGROUND: the racket<->court rows of this solve in registers (RegGround) instead of the lane's LDS column (LdsGround)
+#define TB_EACH_GROUND_ROW(CALL_REG, CALL_LDS)                                         \
+  do {                                                                                  \
+    if constexpr (REGGROUND) {                                                          \
+      if (0 < nrg) { const RegGround<0> c{G}; CALL_REG; }                               \
+      if (1 < nrg) { const RegGround<1> c{G}; CALL_REG; }                               \
+      if (2 < nrg) { const RegGround<2> c{G}; CALL_REG; }                               \
+      if (3 < nrg) { const RegGround<3> c{G}; CALL_REG; }                               \
+    } else {                                                                            \
+      _Pragma("unroll 1") for (int j = 0; j < nrg; ++j) { const LdsGround c{M, j}; CALL_LDS; } \
+    }                                                                                   \
+  } while (0)
+template <bool RG, bool REGROWS, bool TWO = false, bool REGGROUND = false>
 TB_DEV void solve_contacts(const KParams& P, Rows<RG>& R, const Manifold& M, int nrg, const Sym3& W, Racket& rk, Ball& b) {
+  static_assert(TB_MAX_RG == 4, "TB_EACH_GROUND_ROW unrolls four rows");
   float jref = 0.0f;
+  GroundRegs G;
+  if constexpr (RG && REGGROUND) {
+    if (0 < nrg) load_ground_row<0>(M, G);
+    if (1 < nrg) load_ground_row<1>(M, G);
+    if (2 < nrg) load_ground_row<2>(M, G);
+    if (3 < nrg) load_ground_row<3>(M, G);
+  }
   if constexpr (RG) {
-#pragma unroll 1
-    for (int j = 0; j < nrg; ++j) warm_start_ground(P, M, j, W, rk, jref);  // the cached impulses of the last solve
+    TB_EACH_GROUND_ROW(warm_start_ground(P, c, W, rk, jref), warm_start_ground(P, c, W, rk, jref));  // the cached impulses of the last solve
   }
   for (int it = 0; it < P.solver_iters; ++it) {
     bool moved = false;
@@ -844,8 +911,7 @@ TB_DEV void solve_contacts(const KParams& P, Rows<RG>& R, const Manifold& M, int
         if (((R.on >> (i + 1)) & 1)) { RowS c = load_row<TWO>(M, i); moved |= normal_static(P, c, b, jref); store_row_impulses<TWO>(M, i, c); }
     }
     if constexpr (RG) {
-#pragma unroll 1
-      for (int j = 0; j < nrg; ++j) moved |= normal_ground(P, M, j, W, rk, jref);
+      TB_EACH_GROUND_ROW(moved |= normal_ground(P, c, W, rk, jref), moved |= normal_ground(P, c, W, rk, jref));
     }
     if constexpr (RG) {  // rolling rows: after the normals, before sliding friction
       if ((R.on & 1)) moved |= rolling_racket(P, R.rk, R.qrk, rk, b, jref);
@@ -867,12 +933,18 @@ TB_DEV void solve_contacts(const KParams& P, Rows<RG>& R, const Manifold& M, int
         if (((R.on >> (i + 1)) & 1)) { RowS c = load_row<TWO>(M, i); moved |= friction_static(P, c, b, jref); store_row_impulses<TWO>(M, i, c); }
     }
     if constexpr (RG) {
-#pragma unroll 1
-      for (int j = 0; j < nrg; ++j) moved |= friction_ground(P, M, j, W, rk, jref);
+      TB_EACH_GROUND_ROW(moved |= friction_ground(P, c, W, rk, jref), moved |= friction_ground(P, c, W, rk, jref));
     }
     if (!moved) break;
   }
+  if constexpr (RG && REGGROUND) {
+    if (0 < nrg) store_ground_row<0>(M, G);
+    if (1 < nrg) store_ground_row<1>(M, G);
+    if (2 < nrg) store_ground_row<2>(M, G);
+    if (3 < nrg) store_ground_row<3>(M, G);
+  }
 }
+#undef TB_EACH_GROUND_ROW
 
 // ---------------------------------------------------------------- one 1/240 s substep
 // wb_pre = rotate_inv(rk.q, rk.w), computed by the caller (rotate_inv2)
@@ -975,7 +1047,8 @@ template <int KIND> TB_DEV bool near_goal(const KParams& P, float zlow) { return
 // It returns CT_ESCAPE with the env UNTOUCHED (the culls read poses only and come first), the caller hands the env to the next
 // phase kernel as a survivor, and that kernel repeats this substep with everything compiled in -- among lanes that mostly want
 // the same. Same arithmetic, same order per env: bit-identical.
-template <int KIND, bool RG, bool REGROWS = false, bool COLD = false, bool RELOAD = false, bool ESC = false>
+// REGGROUND: see solve_contacts (the looping small-batch kernels ask for it)
+template <int KIND, bool RG, bool REGROWS = false, bool COLD = false, bool RELOAD = false, bool ESC = false, bool REGGROUND = false>
 TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Manifold& M, vec3 Fr, vec3 Tr, vec3 Fb, float goal_x, float goal_y, float scale TB_STAMP_ARG) {
   int bits = 0;
   TB_STAMP(st, 0);  // everything between two substeps (loop control, env logic)
@@ -1096,7 +1169,7 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
         if ((R.on & 4)) setup_roll_static(PC, R.qst[1], PC.roll_court);
         if ((R.on & 8)) setup_roll_static(PC, R.qst[2], PC.roll_goal);
       }
-      solve_contacts<RG, REGROWS, TWO>(PC, R, M, nrg, W, rk, b);
+      solve_contacts<RG, REGROWS, TWO, RG && REGGROUND>(PC, R, M, nrg, W, rk, b);
     }
   }
   TB_STAMP(st, 4);  // contact solve

@@ -55,6 +55,11 @@ struct KArgs {
   float4* ff_next;        // tb_ff_kernel: where envs still running when their budget is spent are compacted to (null = last phase: no budget)
   int* ff_next_count;     // ... and how many there are so far
   const int* ff_src_count;  // tb_ff_kernel, phases 2+: how many records ff_rec holds (null = A.n slots, parked or not)
+  // deferred stragglers (tb_ff_kernel<.., POOL>): ff_next is then the handle's POOL, shared by every episode until the next flush
+  int ff_cap;             // its capacity in records (a lane whose place does not fit finishes its loop in this launch)
+  int ff_extra;           // substeps granted beyond the ballistic estimate before an env is deferred
+  float** pool_dst_out;   // [ff_cap] where the deferred env's terminal reward goes: written next to its record
+  float* const* pool_dst_in;  // the pool kernel reads it back (null: A.reward + env index)
   int defer;
   // fused policy inference (tb_policy_step): actions are computed in-kernel from pol_obs
   const float* pol_weights;  // packed SB3 MlpPolicy towers, see PolicyNet
@@ -354,13 +359,13 @@ TB_DEV vec3 restoring_force(const EnvRegs& e) {  // swingracket_env.py:135-141
 //           next phase kernel resumes it from the saved state, with the restoring force recomputed from that state.
 // ESC     = first phase of the large-batch tb_ff_kernel: a lane that needs the racket's exact narrowphase leaves the loop BEFORE
 //           that substep (`parked` again, nothing of the substep applied); see substep<ESC>.
-template <bool RG, bool REGROWS = false, bool COLD = false, bool BUDGET = false, bool RELOAD = false, bool ESC = false>
+template <bool RG, bool REGROWS = false, bool COLD = false, bool BUDGET = false, bool RELOAD = false, bool ESC = false, bool REGGROUND = false>
 TB_DEV float swing_loop(const KParams& P, const float4* hull, EnvRegs& e, Manifold& M, vec3 F, vec3 T, bool in_ff, bool defer, bool& parked,
                         int& ns, uint32_t* cnt TB_STAMP_ARG, int budget = 0) {
   const vec3 zero = mk(0.0f, 0.0f, 0.0f);
   float reward = 0.0f;
   for (;;) {
-    int bits = substep<TB_ENV_SWING, RG, REGROWS, COLD, RELOAD, ESC>(P, hull, e.r, e.b, M, F, T, zero, e.aux[0], e.aux[1], 1.0f TB_STAMP_PASS);  // :82 / :107
+    int bits = substep<TB_ENV_SWING, RG, REGROWS, COLD, RELOAD, ESC, REGGROUND>(P, hull, e.r, e.b, M, F, T, zero, e.aux[0], e.aux[1], 1.0f TB_STAMP_PASS);  // :82 / :107
     if (ESC && (bits & CT_ESCAPE)) { parked = true; break; }
     e.step_count += 1; ns++;                                                                                   // :83 / :108
     if (bits & CT_RACKET) cnt[0]++;
@@ -558,8 +563,9 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
           // later by tb_ff_kernel from the parked state. The env itself restarts immediately.
           if (A.ff_rec) {
             park_env<RG>(A.ff_rec, i, e, M);
-            A.ff_flag[i] = 1;  // (a byte array of its own: cleared by the fast-forward with one coalesced store per wave, where a 4-byte
-                               //  store into each 192-byte record cost a 64-byte memory write per env)
+            if (A.ff_flag) A.ff_flag[i] = 1;  // (a byte array of its own: cleared by the fast-forward with one coalesced store per wave, where a 4-byte
+                                              //  store into each record cost a 64-byte memory write per env; the record's own tag says "parked" too)
+            if (A.pool_dst_out) A.pool_dst_out[i] = A.reward + row;  // parked straight into the pool (TbOptions.ff_defer = 2): where its reward will go
           } else {
             cnt[8]++;  // lockstep invariant broken (see launch_step): reported, never silent
           }
@@ -679,7 +685,8 @@ __global__ void __launch_bounds__((2 * S + 1) * 64) tb_policy_rollout_kernel(KAr
         if (parked) {
           if (A.ff_rec) {
             park_env<RG>(A.ff_rec, i, e, M);
-            A.ff_flag[i] = 1;
+            if (A.ff_flag) A.ff_flag[i] = 1;
+            if (A.pool_dst_out) A.pool_dst_out[i] = A.reward + (size_t)t * A.st_rew + i;
           } else {
             cnt[8]++;  // lockstep invariant broken (see launch_policy_rollout): reported, never silent
           }
@@ -797,8 +804,19 @@ __global__ void __launch_bounds__(TB_FF_SORT_BLOCK) tb_ff_sort_kernel(KArgs A, f
 // (ESC without the extended contact set is also built for four waves per SIMD: 125 VGPRs -- no spills -- and, with the
 //  two-slot static rows of substep<ESC>, 9.5 KB of LDS per wave: 16 waves per CU instead of 12; 1 M envs, same box: 9.3-9.4 ->
 //  10.0 G env steps/s)
-template <bool RG, bool BIG, bool ESC = false>
+// POOL (small batches, opt-in: TbOptions.ff_defer): DEFERRED STRAGGLERS. A fast-forward kernel lasts as long as its slowest env, and
+// at most four of them run at once (one per hardware queue). With random actions that is 370 us for a mean flight of 108 substeps;
+// under a trained policy struck balls fly 300-775 substeps (0.9-2.5 ms per kernel: the PPO collect was bound by it, 229 M env
+// steps/s), and with racket<->court contact a ball at rest on a grounded racket runs to the 800-substep limit at 12-20 us per
+// substep (15 ms per kernel: 21 M). So every env gets its ballistic estimate (at most an un-struck ball's) + ff_extra substeps, and one that is still running
+// then is parked once more -- into a pool that all episodes share. The pool is run to its end by ONE launch of this kernel when the
+// caller joins (tb_flush and everything that flushes): its hundreds of stragglers advance side by side, 64 to a wave, instead of
+// one or two per kernel. Same arithmetic per env, same results, complete after the flush as before. A lane that finds the pool
+// full (ff_cap records) finishes its loop here instead; lanes that pass that check together may overshoot the capacity by what
+// all resident waves can hold, and the pool is allocated with that much slack.
+template <bool RG, bool BIG, bool ESC = false, bool POOL = false>
 __global__ void __launch_bounds__(64, (ESC && !RG) ? 4 : 1) tb_ff_kernel(KArgs A) {
+  static_assert(!POOL || (!BIG && !ESC), "deferred stragglers are a small-batch scheme");
   constexpr int TB_FF_REC = ff_rec<RG>();
   __shared__ float4 s_hull[TB_HULL_LDS];
   const int lane = threadIdx.x & 63;
@@ -807,12 +825,21 @@ __global__ void __launch_bounds__(64, (ESC && !RG) ? 4 : 1) tb_ff_kernel(KArgs A
 #pragma unroll
   for (int k = 0; k < TB_N_COUNTERS; ++k) cnt[k] = 0u;
   TB_DIAG_STAMPS_BEGIN(st);
-  const int n_src = A.ff_src_count ? *A.ff_src_count : A.n;
-  for (int base = blockIdx.x * A.ff_lanes; base < n_src; base += gridDim.x * A.ff_lanes) {
+  int n_src = A.ff_src_count ? *A.ff_src_count : A.n;
+  if (A.pool_dst_in && n_src > A.ff_cap) n_src = A.ff_cap;  // (the pool's counter runs on past its capacity; what did not fit was finished in place)
+  int wave_lanes = A.ff_lanes;
+  if (POOL && A.pool_dst_in) {
+    // the pool run: one wave per SIMD before any wave gets a second record -- its lanes are the long, contact-heavy flights, every
+    // one on a path of its own, and a wave pays for the sum of its lanes' paths
+    const int want = (n_src + 1023) / 1024;
+    wave_lanes = 4;
+    while (wave_lanes < want && wave_lanes < 64) wave_lanes <<= 1;
+  }
+  for (int base = blockIdx.x * wave_lanes; base < n_src; base += gridDim.x * wave_lanes) {
     float4 r[TB_FF_REC];
     bool live = false;
     const int src = base + lane;
-    if (lane < A.ff_lanes && src < n_src) {
+    if (lane < wave_lanes && src < n_src) {
       const float4* g = A.ff_rec + (size_t)src * TB_FF_REC;
 #pragma unroll
       for (int k = 0; k < TB_FF_REC; ++k) r[k] = g[k];
@@ -831,9 +858,23 @@ __global__ void __launch_bounds__(64, (ESC && !RG) ? 4 : 1) tb_ff_kernel(KArgs A
       // the first loop substep runs without any force (the accumulators were cleared by the agent's substep), every later
       // one with the restoring force of the state before it (swingracket_env.py:135-141): what a resumed env recomputes
       const vec3 F0 = e.step_count > 26 ? restoring_force(e) : zero;
-      const int budget = A.ff_next ? 4 * predict_flight(A.P, e.b.p, e.b.v) + 8 : 0x7fffffff;
+      // POOL: the estimate is capped at an un-struck ball's flight (104 + 8 substeps): what flies longer -- under a trained policy
+      // most balls -- is finished with everybody else's long flights at the join, not four kernels at a time
+      int budget = 0x7fffffff;
+      if (A.ff_next) {
+        budget = 4 * predict_flight(A.P, e.b.p, e.b.v) + 8;
+        if (POOL) budget = (budget < 112 ? budget : 112) + A.ff_extra;
+      }
       const int ns0 = ns;
-      float rew = swing_loop<RG, false, false, true, BIG, ESC>(A.P, s_hull, e, M, F0, zero, true, false, unfinished, ns, cnt TB_STAMP_PASS, budget);
+      // (small batches: the racket<->court rows of a solve in registers -- one wave per SIMD anyway, and a grounded racket's lane is alone in its wave)
+      float rew = swing_loop<RG, false, false, true, BIG, ESC, RG && !BIG>(A.P, s_hull, e, M, F0, zero, true, false, unfinished, ns, cnt TB_STAMP_PASS, budget);
+      if constexpr (POOL) {
+        // a full pool: finish here after all (the counter is read, not reserved: see the slack above)
+        if (unfinished && A.ff_next && *reinterpret_cast<volatile int*>(A.ff_next_count) >= A.ff_cap) {
+          unfinished = false;
+          rew = swing_loop<RG, false, false, true, BIG, ESC, RG && !BIG>(A.P, s_hull, e, M, restoring_force(e), zero, true, false, unfinished, ns, cnt TB_STAMP_PASS, 0x7fffffff);
+        }
+      }
       cnt[6] += (uint32_t)(ns - ns0);
       if (!unfinished) {
         if (!(finite3(e.r.p) && finite3(e.r.v) && finite3(e.r.w) && finite3(e.b.p) && finite3(e.b.v) && finite3(e.b.w) &&
@@ -842,7 +883,9 @@ __global__ void __launch_bounds__(64, (ESC && !RG) ? 4 : 1) tb_ff_kernel(KArgs A
         float o[TB_SWING_OBS_DIM];
         make_obs<TB_ENV_SWING>(e, o);
         if (A.term_obs) write_obs<TB_ENV_SWING>(A.term_obs, (size_t)i, o);
-        A.reward[i] = rew;  // (a survivor has earned nothing yet: every reward of the loop is paid in its last substep)
+        // (a survivor has earned nothing yet: every reward of the loop is paid in its last substep)
+        if (POOL && A.pool_dst_in) *A.pool_dst_in[src] = rew;  // the pool kernel: each record brought its own destination
+        else A.reward[i] = rew;
         if (A.substeps) A.substeps[i] = ns;
       }
       if (A.ff_flag) A.ff_flag[src] = 0;  // the record is free again (lists and sorted copies are rewritten whole before their next use)
@@ -858,6 +901,7 @@ __global__ void __launch_bounds__(64, (ESC && !RG) ? 4 : 1) tb_ff_kernel(KArgs A
           uint32_t* w = reinterpret_cast<uint32_t*>(A.ff_next + (size_t)(first + __popcll(m & ((1ull << lane) - 1ull))) * TB_FF_REC + 7);
           w[2] = 2u | ((uint32_t)ns << 8);
           w[3] = (uint32_t)i;
+          if (POOL && A.pool_dst_out) A.pool_dst_out[first + __popcll(m & ((1ull << lane) - 1ull))] = A.reward + i;
         }
       }
     }
@@ -1001,6 +1045,7 @@ void to_kparams(const TbParams* p, KParams* k, float* planes) {
 
 #define TB_FF_SLOTS 8  // parked-state buffers + side streams: ~2.5 fast-forwards are in flight in steady state
 #define TB_PIPELINE_MAX_ENVS (1 << 24)
+#define TB_DEFER_MAX_ENVS 131072  // deferred stragglers: a small-batch scheme (large batches run the fast-forward in phases)
 
 struct TbHandle {
   int device, kind, n, block;
@@ -1033,8 +1078,22 @@ struct TbHandle {
   int* d_ff_count[TB_FF_SLOTS];       // [2] their numbers
   int ff_phases;                      // 1 = one kernel runs every loop to its end; 2, 3 = budgeted phases + survivor kernels
   int ff_lanes, ff_sort;          // how tb_ff_kernel hands records to lanes (TbOptions.ff_lanes_per_wave / ff_sort, or chosen from n)
+  // deferred stragglers (tb_ff_kernel<.., POOL>; TbOptions.ff_defer): one pool for all episodes between two flushes
+  float4* d_pool;                 // [pool_cap + pool_slack][TB_FF_REC_MAX]
+  float** d_pool_dst;             // [pool_cap + pool_slack] where each deferred env's terminal reward goes
+  int* d_pool_count;
+  int pool_cap, pool_slack, pool_pending;  // pending: records may be waiting (the next flush runs the pool kernel)
+  int pool_episodes;              // ff_defer = 2: episodes parked straight into the pool since the last flush (records [k n, (k + 1) n) each)
+  hipEvent_t ev_direct;           // ... and the latest launch that did so (a flush on another stream waits for it)
+  hipEvent_t ev_pool;             // the last pool run (+ the reset of its counter): later fast-forwards append behind it, whatever stream flushed
+  int pool_ev_valid, direct_ev_valid;
   hipEvent_t ev_step[TB_FF_SLOTS], ev_ff[TB_FF_SLOTS];
   int ff_busy[TB_FF_SLOTS], next_slot;
+  // the fast-forward whose enqueue waits for the next step launch (launch_ff)
+  int pend_valid, pend_slot;
+  KArgs pend_args;
+  const void *pend_term, *pend_sub;
+  hipStream_t pend_stream;
   // progress marks (tb_mark_record). h_marks: pinned host counters written by tb_mark_kernel -- [k] firings of mark k
   // (a kernel on the caller's own stream), [TB_MAX_MARKS] fast-forwards finished (a kernel behind every tb_ff_kernel on
   // its side stream). No extra streams, no extra graph edges: a mark never makes anything wait. What a mark still has
@@ -1093,7 +1152,9 @@ int upload_hull(TbHandle* h, hipStream_t s) {
 }
 
 // make `s` wait for every fast-forward still running on the side stream
+int launch_pending_ff(TbHandle* h);
 int wait_side(TbHandle* h, hipStream_t s) {
+  if (int rc = launch_pending_ff(h)) return rc;
   for (int k = 0; k < TB_FF_SLOTS; ++k)
     if (h->ff_busy[k]) HIP_TRY(hipStreamWaitEvent(s, h->ev_ff[k], 0));
   return TB_OK;
@@ -1105,7 +1166,30 @@ bool extended_contacts(const KParams& kp) {
 }
 
 // finish the lanes parked in `slot` on that slot's side stream, ordered after everything issued to `s` so far
-int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const void* substeps, hipStream_t s) {
+int launch_ff_now(TbHandle* h, int slot, const KArgs& a_in, const void* term, const void* substeps, hipStream_t s);
+
+// The fast-forward of an episode end is ENQUEUED one launch late: its dependency is fixed now (the event behind the parking
+// launch), but its kernel goes to the side stream only after the NEXT step kernel has been issued (launch_pending_ff; or at a
+// flush / mark, whichever comes first). Eagerly that costs it ~5 us. Under stream capture it decides the ORDER IN WHICH THE
+// PARKING NODE GETS ITS TWO SUCCESSORS: the next step first, the fast-forward second -- a replayed graph keeps a node's first
+// successor on its own internal stream and moves the second to another one, and with the fast-forward captured first it was
+// the CHAIN OF STEPS that changed hardware queues at every episode end (step kernels spread 572 / 520 / 520 / 520 over the four
+// queues, ~10 us from the parking kernel to the next step against ~2.5 us between other steps: profiles/r03_contact_off_inversion.md).
+int launch_ff(TbHandle* h, int slot, const KArgs& a, const void* term, const void* substeps, hipStream_t s) {
+  HIP_TRY(hipEventRecord(h->ev_step[slot], s));
+  if (!h->phase_valid || h->opt.ff_eager_launch > 0) return launch_ff_now(h, slot, a, term, substeps, s);
+  if (h->pend_valid) { if (int rc = launch_ff_now(h, h->pend_slot, h->pend_args, h->pend_term, h->pend_sub, h->pend_stream)) return rc; }
+  h->pend_valid = 1; h->pend_slot = slot; h->pend_args = a; h->pend_term = term; h->pend_sub = substeps; h->pend_stream = s;
+  h->ff_busy[slot] = 1;  // (taken from now on; its completion event is recorded when the kernel is enqueued, before anybody can wait for it)
+  return TB_OK;
+}
+int launch_pending_ff(TbHandle* h) {
+  if (!h->pend_valid) return TB_OK;
+  h->pend_valid = 0;
+  return launch_ff_now(h, h->pend_slot, h->pend_args, h->pend_term, h->pend_sub, h->pend_stream);
+}
+
+int launch_ff_now(TbHandle* h, int slot, const KArgs& a_in, const void* term, const void* substeps, hipStream_t s) {
   KArgs a = a_in;
   hipStream_t side = h->side[slot];
   // lockstep episodes (every env parks in the same launch): sorted, or a few envs per wave; without the host knowing the
@@ -1113,8 +1197,7 @@ int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const 
   const bool sort = h->ff_sort && h->phase_valid;
   a.ff_lanes = sort || !h->phase_valid ? 64 : h->ff_lanes;
   const int groups = (h->n + TB_FF_SORT_BLOCK - 1) / TB_FF_SORT_BLOCK;
-  HIP_TRY(hipEventRecord(h->ev_step[slot], s));
-  HIP_TRY(hipStreamWaitEvent(side, h->ev_step[slot], 0));
+  HIP_TRY(hipStreamWaitEvent(side, h->ev_step[slot], 0));  // (recorded behind the parking launch by launch_ff)
   // two fast-forwards that write the same terminal-obs / substeps buffer must finish in order
   if (h->last_slot >= 0 && h->last_slot != slot && ((term && term == h->last_term) || (substeps && substeps == h->last_sub)))
     HIP_TRY(hipStreamWaitEvent(side, h->ev_ff[h->last_slot], 0));
@@ -1128,6 +1211,11 @@ int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const 
   // record is idle: one plain kernel.
   const int phases = h->phase_valid ? h->ff_phases : 1;
   const bool rg = extended_contacts(h->kp);
+  // deferred stragglers: on request (TbOptions.ff_defer > 0), or by default with racket<->court contact, whose resting stacks run
+  // to the 800-substep limit. Not with progress marks (a mark promises that the steps before it are FINAL), not with late-written
+  // terminal observations / substep counts (the pool keeps one destination per record: the reward's)
+  const bool defer = h->d_pool && phases == 1 && h->phase_valid && !sort && !h->marks_on && !term && !substeps &&
+                     (h->opt.ff_defer == 1 || (h->opt.ff_defer == 0 && (h->kp.flags & TB_F_RACKET_GROUND)));
   if (phases > 1) HIP_TRY(hipMemsetAsync(h->d_ff_count[slot], 0, 2 * sizeof(int), side));
   for (int ph = 0; ph < phases; ++ph) {
     KArgs k = a;
@@ -1138,6 +1226,16 @@ int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const 
       grid = dim3((unsigned)g);
     }
     if (ph + 1 < phases) { k.ff_next = h->d_ff_list[slot][ph]; k.ff_next_count = h->d_ff_count[slot] + ph; }
+    if (defer) {
+      k.ff_next = h->d_pool; k.ff_next_count = h->d_pool_count; k.ff_cap = h->pool_cap; k.pool_dst_out = h->d_pool_dst;
+      k.ff_extra = h->opt.ff_defer_margin ? h->opt.ff_defer_margin : 16;
+      h->pool_pending = 1;
+      if (h->pool_ev_valid) HIP_TRY(hipStreamWaitEvent(side, h->ev_pool, 0));  // append behind the last pool run and its counter reset
+      if (rg) hipLaunchKernelGGL((tb_ff_kernel<true, false, false, true>), grid, block, dyn_lds(false, true, 64), side, k);
+      else hipLaunchKernelGGL((tb_ff_kernel<false, false, false, true>), grid, block, dyn_lds(false, false, 64), side, k);
+      HIP_TRY(hipGetLastError());
+      continue;
+    }
     const bool big = h->n >= 131072;
     const bool esc = big && ph == 0 && phases > 1;
     const size_t lds = esc && !rg ? sizeof(float) * 64 * TB_ROWS_LDS_TWO : dyn_lds(false, rg, 64);
@@ -1160,7 +1258,51 @@ int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const 
 }
 
 // every result of every fast-forward is in place once `s` gets past this point
-int flush_all(TbHandle* h, hipStream_t s) { return wait_side(h, s); }
+int flush_all(TbHandle* h, hipStream_t s) {
+  if (int rc = wait_side(h, s)) return rc;
+  if (h->pool_pending) {  // the deferred stragglers of every episode since the last flush, side by side in one launch
+    KArgs k = base_args(h);
+    k.ff_rec = h->d_pool; k.ff_flag = nullptr; k.ff_src_count = h->d_pool_count; k.ff_lanes = 64;
+    k.ff_cap = h->pool_cap + h->pool_slack; k.pool_dst_in = h->d_pool_dst;
+    if (h->pool_episodes > 0) {  // whole episodes parked straight into the pool: the host knows how many records there are
+      k.ff_src_count = nullptr; k.n = h->pool_episodes * h->n;
+      if (h->direct_ev_valid) HIP_TRY(hipStreamWaitEvent(s, h->ev_direct, 0));  // (a flush on another stream than the steps')
+    }
+    const bool rg = extended_contacts(h->kp);
+    int g = (h->pool_cap + h->pool_slack + 63) / 64;
+    g = g < 1024 ? 1024 : g > 16384 ? 16384 : g;  // (workgroups beyond the pool's fill exit at once; grid-stride beyond 1 M records)
+    (void)hipGetLastError();
+    if (rg) hipLaunchKernelGGL((tb_ff_kernel<true, false, false, true>), dim3((unsigned)g), dim3(64), dyn_lds(false, true, 64), s, k);
+    else hipLaunchKernelGGL((tb_ff_kernel<false, false, false, true>), dim3((unsigned)g), dim3(64), dyn_lds(false, false, 64), s, k);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(h->d_pool_count, 0, sizeof(int), s));
+    HIP_TRY(hipEventRecord(h->ev_pool, s));
+    h->pool_pending = 0; h->pool_ev_valid = 1; h->pool_episodes = 0;
+  }
+  return TB_OK;
+}
+
+// TbOptions.ff_defer = 2: the launch that ends the episodes parks them STRAIGHT into the pool -- region [k n, (k + 1) n) for the
+// k-th such launch since the last flush -- and no fast-forward kernel of its own follows: the pool run at the join does all of
+// them at once. Returns whether `a` was set up that way (not with progress marks / late-written outputs / a full pool: then the
+// ordinary slot + tb_ff_kernel path serves the launch).
+bool park_direct(TbHandle* h, KArgs& a, const void* term, const void* substeps, hipStream_t s, int* rc) {
+  *rc = TB_OK;
+  if (!(h->d_pool && h->opt.ff_defer == 2 && h->phase_valid && !h->marks_on && !term && !substeps && h->pool_episodes < h->pool_cap / h->n)) return false;
+  if (h->pool_ev_valid) {  // behind the last pool run (which may have been enqueued on another stream)
+    hipError_t e = hipStreamWaitEvent(s, h->ev_pool, 0);
+    if (e != hipSuccess) { *rc = fail((int)e, "hipStreamWaitEvent(s, h->ev_pool, 0)"); return false; }
+  }
+  const size_t rec = extended_contacts(h->kp) ? TB_FF_REC_MAX : 8;
+  a.defer = 1; a.ff_rec = h->d_pool + (size_t)h->pool_episodes * h->n * rec; a.ff_flag = nullptr;
+  a.pool_dst_out = h->d_pool_dst + (size_t)h->pool_episodes * h->n;
+  return true;
+}
+int parked_direct(TbHandle* h, hipStream_t s) {
+  HIP_TRY(hipEventRecord(h->ev_direct, s));
+  h->direct_ev_valid = 1; h->pool_episodes++; h->pool_pending = 1;
+  return TB_OK;
+}
 
 struct PolicyIO {  // non-null weights = fused policy step
   const float* weights; const float* obs_in; float* actions; float* raw; float* logp; float* value;
@@ -1187,10 +1329,13 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
   // call gets a slot and a (then mostly idle) tb_ff_kernel.
   const bool piped = (T == 1 || lean_multi) && h->pipeline && h->kind == TB_ENV_SWING && (h->kp.flags & TB_F_AUTO_RESET);
   const bool may_park = piped && (T == 1 ? (!h->phase_valid || h->phase == 25) : h->phase + T - 1 == 25);
-  int slot = -1;
-  if (may_park) {
+  int slot = -1, rc_direct = TB_OK;
+  const bool direct = may_park && park_direct(h, a, term, substeps, s, &rc_direct);
+  if (rc_direct) return rc_direct;
+  if (may_park && !direct) {
     slot = h->next_slot;
     h->next_slot = (slot + 1) % TB_FF_SLOTS;
+    if (h->pend_valid && h->pend_slot == slot) { if (int rc = launch_pending_ff(h)) return rc; }
     if (h->ff_busy[slot]) HIP_TRY(hipStreamWaitEvent(s, h->ev_ff[slot], 0));  // slot still in use by an older fast-forward
     a.defer = 1; a.ff_rec = h->d_ff_rec[slot]; a.ff_flag = h->d_ff_flag[slot];
   }
@@ -1231,7 +1376,9 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
   } else TB_LAUNCH_STEP(TB_ENV_SWING, false, false);
 #undef TB_LAUNCH_STEP
   HIP_TRY(hipGetLastError());
-  if (may_park) {
+  if (int rc = launch_pending_ff(h)) return rc;  // the previous episode end's fast-forward: behind this launch (see launch_ff)
+  if (direct) { if (int rc = parked_direct(h, s)) return rc; }
+  else if (may_park) {
     if (T > 1) a.reward = reward + (size_t)(T - 1) * h->n;  // the fast-forward owes its reward to the step that parked: the last one
     if (int rc = launch_ff(h, slot, a, term, substeps, s)) return rc;
   }
@@ -1249,10 +1396,13 @@ int launch_policy_rollout(TbHandle* h, int T, const PolicyIO& pol, float* obs, f
   a.st_act = st[0]; a.st_raw = st[1]; a.st_logp = st[2]; a.st_val = st[3]; a.st_obs = st[4]; a.st_rew = st[5]; a.st_done = st[6];
   const bool swing = h->kind == TB_ENV_SWING;
   const bool may_park = swing && h->phase + T - 1 == 25;  // (the caller checked pipeline, lockstep phase and phase + T <= 26)
-  int slot = -1;
-  if (may_park) {
+  int slot = -1, rc_direct = TB_OK;
+  const bool direct = may_park && park_direct(h, a, nullptr, nullptr, s, &rc_direct);
+  if (rc_direct) return rc_direct;
+  if (may_park && !direct) {
     slot = h->next_slot;
     h->next_slot = (slot + 1) % TB_FF_SLOTS;
+    if (h->pend_valid && h->pend_slot == slot) { if (int rc = launch_pending_ff(h)) return rc; }
     if (h->ff_busy[slot]) HIP_TRY(hipStreamWaitEvent(s, h->ev_ff[slot], 0));
     a.defer = 1; a.ff_rec = h->d_ff_rec[slot]; a.ff_flag = h->d_ff_flag[slot];
   }
@@ -1272,7 +1422,9 @@ int launch_policy_rollout(TbHandle* h, int T, const PolicyIO& pol, float* obs, f
   else { if (narrow) TB_LAUNCH_PR(TB_ENV_TENNIS, 1); else TB_LAUNCH_PR(TB_ENV_TENNIS, 3); }
 #undef TB_LAUNCH_PR
   HIP_TRY(hipGetLastError());
-  if (may_park) {
+  if (int rc = launch_pending_ff(h)) return rc;
+  if (direct) { if (int rc = parked_direct(h, s)) return rc; }
+  else if (may_park) {
     a.reward = reward + (size_t)(T - 1) * st[5];  // the fast-forward owes its reward to the step that parked: the last one
     if (int rc = launch_ff(h, slot, a, nullptr, nullptr, s)) return rc;
   }
@@ -1305,6 +1457,8 @@ int tb_create(const TbParams* params, const TbOptions* options, int env_kind, in
     if (opt.ff_lanes_per_wave < 0 || opt.ff_lanes_per_wave > 64) return fail(TB_E_INVAL, "tb_create: TbOptions.ff_lanes_per_wave must be in [0, 64]");
     if (opt.ff_phases < 0 || opt.ff_phases > 3) return fail(TB_E_INVAL, "tb_create: TbOptions.ff_phases must be in [0, 3]");
     if (opt.policy_slices != 0 && opt.policy_slices != 1 && opt.policy_slices != 3) return fail(TB_E_INVAL, "tb_create: TbOptions.policy_slices must be 0, 1 or 3");
+    if (opt.ff_defer < -1 || opt.ff_defer > 2) return fail(TB_E_INVAL, "tb_create: TbOptions.ff_defer must be -1, 0, 1 or 2");
+    if (opt.ff_defer_margin < 0 || opt.ff_defer_margin > 800) return fail(TB_E_INVAL, "tb_create: TbOptions.ff_defer_margin must be in [0, 800]");
   }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -1385,6 +1539,13 @@ static void release_pipeline(TbHandle* h) {
     h->d_ff_rec[k] = nullptr; h->d_ff_flag[k] = nullptr; h->d_ff_sorted[k] = nullptr; h->d_ff_list[k][0] = nullptr; h->d_ff_list[k][1] = nullptr;
     h->d_ff_count[k] = nullptr; h->ev_step[k] = nullptr; h->ev_ff[k] = nullptr; h->side[k] = nullptr; h->ff_busy[k] = 0;
   }
+  if (h->d_pool) (void)hipFree(h->d_pool);
+  if (h->d_pool_dst) (void)hipFree(h->d_pool_dst);
+  if (h->d_pool_count) (void)hipFree(h->d_pool_count);
+  if (h->ev_pool) (void)hipEventDestroy(h->ev_pool);
+  if (h->ev_direct) (void)hipEventDestroy(h->ev_direct);
+  h->ev_pool = nullptr; h->ev_direct = nullptr; h->pool_ev_valid = 0; h->direct_ev_valid = 0; h->pool_episodes = 0;
+  h->d_pool = nullptr; h->d_pool_dst = nullptr; h->d_pool_count = nullptr; h->pool_cap = 0; h->pool_slack = 0; h->pool_pending = 0;
   h->pipeline = 0;
 }
 
@@ -1413,6 +1574,18 @@ static int alloc_pipeline(TbHandle* h) {
     }
     HIP_TRY(hipEventCreateWithFlags(&h->ev_step[k], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_ff[k], hipEventDisableTiming));
+  }
+  if (h->n <= TB_DEFER_MAX_ENVS && h->opt.ff_defer >= 0) {
+    // the stragglers' pool: 64 n records (two reference-sized rollouts of 1100 steps with EVERY env deferred) + the slack all
+    // resident fast-forward waves could overshoot it by (slots x n): 14 KB per env
+    h->pool_cap = 64 * h->n; h->pool_slack = TB_FF_SLOTS * h->n;
+    const size_t recs = (size_t)h->pool_cap + (size_t)h->pool_slack;
+    HIP_TRY(pipeline_malloc((void**)&h->d_pool, sizeof(float4) * (size_t)TB_FF_REC_MAX * recs));
+    HIP_TRY(pipeline_malloc((void**)&h->d_pool_dst, sizeof(float*) * recs));
+    HIP_TRY(pipeline_malloc((void**)&h->d_pool_count, sizeof(int)));
+    HIP_TRY(hipMemset(h->d_pool_count, 0, sizeof(int)));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_pool, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_direct, hipEventDisableTiming));
   }
   HIP_TRY(hipDeviceSynchronize());
   return TB_OK;
@@ -1450,6 +1623,8 @@ int tb_pipeline_sync(TbHandle* h, int host_wait) {
     if (host_wait && h->side[k]) HIP_TRY(hipStreamSynchronize(h->side[k]));
     h->ff_busy[k] = 0;
   }
+  h->pool_ev_valid = 0; h->direct_ev_valid = 0;  // (an event recorded on one side of a capture boundary means nothing on the other)
+  if (!host_wait) { if (int rc = launch_pending_ff(h)) return rc; }  // (cannot be pending: the capture ended with a flush)
   h->last_slot = -1;
   if (host_wait) {
     memset(h->ff_cap, 0, sizeof h->ff_cap);
@@ -1466,6 +1641,7 @@ int tb_pipeline_recover(TbHandle* h) {
   (void)hipGetLastError();  // the abandoned capture leaves a sticky hipErrorStreamCaptureInvalidated behind
   // the captured tb_step calls advanced the host's episode phase, but none of them ran
   h->phase = h->phase_at_capture; h->phase_valid = h->phase_valid_at_capture;
+  h->pool_ev_valid = 0; h->direct_ev_valid = 0;
   for (int k = 0; k < TB_FF_SLOTS; ++k) {
     h->ff_busy[k] = 0;
     if (!h->side[k]) continue;
@@ -1505,6 +1681,7 @@ int tb_mark_record(TbHandle* h, int k, void* stream) {
   DeviceGuard g(h->device);
   hipStream_t s = (hipStream_t)stream;
   if (!h->marks_on) return fail(TB_E_UNSUPPORTED, "tb_mark_record needs tb_mark_enable(h, 1) before the steps it covers (their fast-forwards must be counted)");
+  if (int rc = launch_pending_ff(h)) return rc;  // a mark counts the fast-forwards ENQUEUED before it
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   HIP_TRY(hipStreamIsCapturing(s, &st));
   hipLaunchKernelGGL(tb_mark_kernel, dim3(1), dim3(1), 0, s, h->h_marks + k);

@@ -423,6 +423,8 @@ class BatchedEnv:
         during the capture: the env (and the library's episode phase) are where they were, and the
         first replay() is the first time the steps happen."""
         t = self.torch
+        if self.pipeline:
+            self.flush()  # (also runs the pool of deferred stragglers, if any: nothing of this env may be pending across the capture boundary)
         t.cuda.current_stream(self.device).synchronize()
         _check(self.L, self.L.tb_pipeline_sync(self._h, 1), "tb_pipeline_sync")
         phase = self.L.tb_phase(self._h) if self.pipeline else -1

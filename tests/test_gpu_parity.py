@@ -1117,3 +1117,46 @@ def test_set_pipeline_failure_is_all_or_nothing(torch):
     c = env.counters()
     assert c["lockstep_violations"] == 0 and list(c.values()) == [int(x) for x in ref.counters()]
     env.close()
+
+
+@pytest.mark.parametrize("rg,n,episodes,margin", [(False, 4096, 3, 0), (True, 2048, 3, 0), (False, 64, 700, 1), (True, 1000, 2, 200),
+                                                  (False, 4096, 3, "all"), (True, 1000, 3, "all"), (False, 256, 70, "all")])
+def test_deferred_stragglers_are_bit_identical(torch, rg, n, episodes, margin):
+    """TbOptions.ff_defer: envs still running after their ballistic estimate + margin substeps leave their episode's fast-forward
+    kernel for a pool that ONE launch finishes at the join. Against an unpipelined twin: every reward, done flag, observation,
+    counter and the state bit for bit -- eagerly and through a replayed graph; with racket<->court contact (where it is the default);
+    and over 700 episodes without a join, so that the pool (64 n records) fills up and later stragglers finish in place."""
+    from tennisbot_rl_amd.rollout import RolloutBuffer
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    T = 26 * episodes
+    p = default_params(flags=F_DEFAULT | (F_RACKET_GROUND if rg else 0))
+    rng = np.random.default_rng(31 + n)
+    # margin "all": TbOptions.ff_defer = 2, every parked env straight into the pool (70 episodes without a join: more than its 64 regions)
+    opts = dict(ff_defer="all") if margin == "all" else dict(ff_defer=True, ff_defer_margin=margin)
+    a = BatchedEnv(ENV_SWING, n, seed=4, params=p, pipeline=True, track_terminal_obs=False, options=opts)
+    b = BatchedEnv(ENV_SWING, n, seed=4, params=p)
+    ba, bb = RolloutBuffer(ENV_SWING, T, n, "cuda:0").bind(a), RolloutBuffer(ENV_SWING, T, n, "cuda:0")
+    acts = torch.from_numpy(rng.uniform(-1, 1, (min(T, 104), n, 6)).astype(np.float32)).cuda()
+    for t in range(T):
+        ba.actions[t].copy_(acts[t % acts.shape[0]]); bb.actions[t].copy_(acts[t % acts.shape[0]])
+    a.reset(); b.reset()
+    ba.step_range(a, 0, T)  # no join in between: the pool collects the stragglers of every episode
+    a.flush()
+    for t in range(T):
+        bb.step_into(b, t)
+    torch.cuda.synchronize()
+    assert torch.equal(ba.rewards, bb.rewards) and torch.equal(ba.dones, bb.dones) and torch.equal(ba.obs, bb.obs)
+    ca, cb = a.counters(), b.counters()
+    assert ca == cb and ca["lockstep_violations"] == 0 and ca["episodes_finished"] == n * episodes
+    if episodes <= 3:  # the same rollout once more as a replayed graph (the pool run is its last kernel node)
+        g = a.capture(lambda: ba.step_range(a, 0, T))
+        for rep in range(2):
+            g.replay()
+            for t in range(T):
+                bb.step_into(b, t)
+            torch.cuda.synchronize()
+            assert torch.equal(ba.rewards, bb.rewards) and torch.equal(ba.obs, bb.obs)
+        assert a.counters() == b.counters()
+    wa, da = a.get_state_words(); wb, db = b.get_state_words()
+    assert torch.equal(wa, wb) and torch.equal(da, db)
+    a.close(); b.close()

@@ -40,6 +40,16 @@ for label in ("untrained", "reference_policy"):
         sync(); t0 = time.perf_counter(); tr.collect(); sync(); ts.append(time.perf_counter() - t0)
     med["collect_call_ms"] = float(np.median(ts)) * 1e3
     med["collect_call_steps_per_s_M"] = 4096 * 1100 / float(np.median(ts)) / 1e6
+    # ... and inside the training loop: the collect that follows an update() (1.4 s of library GEMMs and elementwise kernels),
+    # and the one after that
+    adv, ret = tr.advantages(tr.last_value)
+    after, second = [], []
+    for rep in range(3):
+        tr.update(adv, ret); sync()
+        t0 = time.perf_counter(); tr.collect(); sync(); after.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); tr.collect(); sync(); second.append(time.perf_counter() - t0)
+    med["collect_after_update_ms"] = float(np.median(after)) * 1e3
+    med["collect_after_that_ms"] = float(np.median(second)) * 1e3
     c = tr.env.counters()
     med["substeps_per_step"] = c["substeps"] / max(1, c["episodes_finished"] * 26)
     out[label] = med
