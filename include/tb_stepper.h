@@ -186,9 +186,6 @@ typedef struct TbOptions {
                              * plain kernels are faster; tennisbot_rl_amd.ppo turns it on: struck balls fly long). Results do not change. Not
                              * used while progress marks are enabled or terminal-observation / substep outputs are asked for. */
   int32_t ff_defer_margin;  /* substeps beyond the estimate before an env is deferred (auto: 16) */
-  int32_t ff_eager_launch;  /* 1: enqueue an episode end's fast-forward right behind the parking launch, as rounds 1-2 did (auto: one launch
-                             * later, so that in a captured graph the NEXT STEP is the parking node's first successor and the chain of steps
-                             * stays on one hardware queue: csrc/tb_stepper.hip launch_ff) */
   int32_t policy_slices;    /* tb_policy_rollout: 16-env slices per workgroup, 1 (three waves per 16 envs) or 3 (seven waves per 48 envs) (auto: 1 up to 4096 envs) */
 } TbOptions;
 

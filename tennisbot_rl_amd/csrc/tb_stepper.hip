@@ -1089,11 +1089,6 @@ struct TbHandle {
   int pool_ev_valid, direct_ev_valid;
   hipEvent_t ev_step[TB_FF_SLOTS], ev_ff[TB_FF_SLOTS];
   int ff_busy[TB_FF_SLOTS], next_slot;
-  // the fast-forward whose enqueue waits for the next step launch (launch_ff)
-  int pend_valid, pend_slot;
-  KArgs pend_args;
-  const void *pend_term, *pend_sub;
-  hipStream_t pend_stream;
   // progress marks (tb_mark_record). h_marks: pinned host counters written by tb_mark_kernel -- [k] firings of mark k
   // (a kernel on the caller's own stream), [TB_MAX_MARKS] fast-forwards finished (a kernel behind every tb_ff_kernel on
   // its side stream). No extra streams, no extra graph edges: a mark never makes anything wait. What a mark still has
@@ -1152,9 +1147,7 @@ int upload_hull(TbHandle* h, hipStream_t s) {
 }
 
 // make `s` wait for every fast-forward still running on the side stream
-int launch_pending_ff(TbHandle* h);
 int wait_side(TbHandle* h, hipStream_t s) {
-  if (int rc = launch_pending_ff(h)) return rc;
   for (int k = 0; k < TB_FF_SLOTS; ++k)
     if (h->ff_busy[k]) HIP_TRY(hipStreamWaitEvent(s, h->ev_ff[k], 0));
   return TB_OK;
@@ -1166,30 +1159,11 @@ bool extended_contacts(const KParams& kp) {
 }
 
 // finish the lanes parked in `slot` on that slot's side stream, ordered after everything issued to `s` so far
-int launch_ff_now(TbHandle* h, int slot, const KArgs& a_in, const void* term, const void* substeps, hipStream_t s);
-
-// The fast-forward of an episode end is ENQUEUED one launch late: its dependency is fixed now (the event behind the parking
-// launch), but its kernel goes to the side stream only after the NEXT step kernel has been issued (launch_pending_ff; or at a
-// flush / mark, whichever comes first). Eagerly that costs it ~5 us. Under stream capture it decides the ORDER IN WHICH THE
-// PARKING NODE GETS ITS TWO SUCCESSORS: the next step first, the fast-forward second -- a replayed graph keeps a node's first
-// successor on its own internal stream and moves the second to another one, and with the fast-forward captured first it was
-// the CHAIN OF STEPS that changed hardware queues at every episode end (step kernels spread 572 / 520 / 520 / 520 over the four
-// queues, ~10 us from the parking kernel to the next step against ~2.5 us between other steps: profiles/r03_contact_off_inversion.md).
-int launch_ff(TbHandle* h, int slot, const KArgs& a, const void* term, const void* substeps, hipStream_t s) {
-  HIP_TRY(hipEventRecord(h->ev_step[slot], s));
-  if (!h->phase_valid || h->opt.ff_eager_launch > 0) return launch_ff_now(h, slot, a, term, substeps, s);
-  if (h->pend_valid) { if (int rc = launch_ff_now(h, h->pend_slot, h->pend_args, h->pend_term, h->pend_sub, h->pend_stream)) return rc; }
-  h->pend_valid = 1; h->pend_slot = slot; h->pend_args = a; h->pend_term = term; h->pend_sub = substeps; h->pend_stream = s;
-  h->ff_busy[slot] = 1;  // (taken from now on; its completion event is recorded when the kernel is enqueued, before anybody can wait for it)
-  return TB_OK;
-}
-int launch_pending_ff(TbHandle* h) {
-  if (!h->pend_valid) return TB_OK;
-  h->pend_valid = 0;
-  return launch_ff_now(h, h->pend_slot, h->pend_args, h->pend_term, h->pend_sub, h->pend_stream);
-}
-
-int launch_ff_now(TbHandle* h, int slot, const KArgs& a_in, const void* term, const void* substeps, hipStream_t s) {
+// (Measured and dropped in round 3: enqueueing the fast-forward one launch LATE, so that under stream capture the next step -- not
+//  the fast-forward -- is the parking node's first successor. It does what was hoped for the chain -- all 2132 step kernels of two
+//  replays on ONE hardware queue instead of 572 / 520 / 520 / 520 -- but a replayed graph then puts every second successor on the same
+//  second queue: 79 of 82 fast-forwards in line behind each other, 209 M env steps/s instead of 700.)
+int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const void* substeps, hipStream_t s) {
   KArgs a = a_in;
   hipStream_t side = h->side[slot];
   // lockstep episodes (every env parks in the same launch): sorted, or a few envs per wave; without the host knowing the
@@ -1197,7 +1171,8 @@ int launch_ff_now(TbHandle* h, int slot, const KArgs& a_in, const void* term, co
   const bool sort = h->ff_sort && h->phase_valid;
   a.ff_lanes = sort || !h->phase_valid ? 64 : h->ff_lanes;
   const int groups = (h->n + TB_FF_SORT_BLOCK - 1) / TB_FF_SORT_BLOCK;
-  HIP_TRY(hipStreamWaitEvent(side, h->ev_step[slot], 0));  // (recorded behind the parking launch by launch_ff)
+  HIP_TRY(hipEventRecord(h->ev_step[slot], s));
+  HIP_TRY(hipStreamWaitEvent(side, h->ev_step[slot], 0));
   // two fast-forwards that write the same terminal-obs / substeps buffer must finish in order
   if (h->last_slot >= 0 && h->last_slot != slot && ((term && term == h->last_term) || (substeps && substeps == h->last_sub)))
     HIP_TRY(hipStreamWaitEvent(side, h->ev_ff[h->last_slot], 0));
@@ -1227,6 +1202,10 @@ int launch_ff_now(TbHandle* h, int slot, const KArgs& a_in, const void* term, co
     }
     if (ph + 1 < phases) { k.ff_next = h->d_ff_list[slot][ph]; k.ff_next_count = h->d_ff_count[slot] + ph; }
     if (defer) {
+      // with racket<->court contact every lane is on a path of its own (rackets land at different times, manifolds of different
+      // sizes, solves of different lengths) and a wave pays for the union: 16 envs per wave (4096 envs, same box: 84-86 M env
+      // steps/s with 64, 92-96 with 32, 94-98 with 16, 93-97 with 8, 89 with 4)
+      if (rg && !h->opt.ff_lanes_per_wave && k.ff_lanes > 16) { k.ff_lanes = 16; grid = dim3((unsigned)((a.n + 15) / 16)); }
       k.ff_next = h->d_pool; k.ff_next_count = h->d_pool_count; k.ff_cap = h->pool_cap; k.pool_dst_out = h->d_pool_dst;
       k.ff_extra = h->opt.ff_defer_margin ? h->opt.ff_defer_margin : 16;
       h->pool_pending = 1;
@@ -1335,7 +1314,6 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
   if (may_park && !direct) {
     slot = h->next_slot;
     h->next_slot = (slot + 1) % TB_FF_SLOTS;
-    if (h->pend_valid && h->pend_slot == slot) { if (int rc = launch_pending_ff(h)) return rc; }
     if (h->ff_busy[slot]) HIP_TRY(hipStreamWaitEvent(s, h->ev_ff[slot], 0));  // slot still in use by an older fast-forward
     a.defer = 1; a.ff_rec = h->d_ff_rec[slot]; a.ff_flag = h->d_ff_flag[slot];
   }
@@ -1376,7 +1354,6 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
   } else TB_LAUNCH_STEP(TB_ENV_SWING, false, false);
 #undef TB_LAUNCH_STEP
   HIP_TRY(hipGetLastError());
-  if (int rc = launch_pending_ff(h)) return rc;  // the previous episode end's fast-forward: behind this launch (see launch_ff)
   if (direct) { if (int rc = parked_direct(h, s)) return rc; }
   else if (may_park) {
     if (T > 1) a.reward = reward + (size_t)(T - 1) * h->n;  // the fast-forward owes its reward to the step that parked: the last one
@@ -1402,7 +1379,6 @@ int launch_policy_rollout(TbHandle* h, int T, const PolicyIO& pol, float* obs, f
   if (may_park && !direct) {
     slot = h->next_slot;
     h->next_slot = (slot + 1) % TB_FF_SLOTS;
-    if (h->pend_valid && h->pend_slot == slot) { if (int rc = launch_pending_ff(h)) return rc; }
     if (h->ff_busy[slot]) HIP_TRY(hipStreamWaitEvent(s, h->ev_ff[slot], 0));
     a.defer = 1; a.ff_rec = h->d_ff_rec[slot]; a.ff_flag = h->d_ff_flag[slot];
   }
@@ -1422,7 +1398,6 @@ int launch_policy_rollout(TbHandle* h, int T, const PolicyIO& pol, float* obs, f
   else { if (narrow) TB_LAUNCH_PR(TB_ENV_TENNIS, 1); else TB_LAUNCH_PR(TB_ENV_TENNIS, 3); }
 #undef TB_LAUNCH_PR
   HIP_TRY(hipGetLastError());
-  if (int rc = launch_pending_ff(h)) return rc;
   if (direct) { if (int rc = parked_direct(h, s)) return rc; }
   else if (may_park) {
     a.reward = reward + (size_t)(T - 1) * st[5];  // the fast-forward owes its reward to the step that parked: the last one
@@ -1624,7 +1599,6 @@ int tb_pipeline_sync(TbHandle* h, int host_wait) {
     h->ff_busy[k] = 0;
   }
   h->pool_ev_valid = 0; h->direct_ev_valid = 0;  // (an event recorded on one side of a capture boundary means nothing on the other)
-  if (!host_wait) { if (int rc = launch_pending_ff(h)) return rc; }  // (cannot be pending: the capture ended with a flush)
   h->last_slot = -1;
   if (host_wait) {
     memset(h->ff_cap, 0, sizeof h->ff_cap);
@@ -1681,7 +1655,6 @@ int tb_mark_record(TbHandle* h, int k, void* stream) {
   DeviceGuard g(h->device);
   hipStream_t s = (hipStream_t)stream;
   if (!h->marks_on) return fail(TB_E_UNSUPPORTED, "tb_mark_record needs tb_mark_enable(h, 1) before the steps it covers (their fast-forwards must be counted)");
-  if (int rc = launch_pending_ff(h)) return rc;  // a mark counts the fast-forwards ENQUEUED before it
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   HIP_TRY(hipStreamIsCapturing(s, &st));
   hipLaunchKernelGGL(tb_mark_kernel, dim3(1), dim3(1), 0, s, h->h_marks + k);
