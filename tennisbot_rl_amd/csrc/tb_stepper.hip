@@ -816,7 +816,7 @@ __global__ void __launch_bounds__(TB_FF_SORT_BLOCK) tb_ff_sort_kernel(KArgs A, f
 // all resident waves can hold, and the pool is allocated with that much slack.
 template <bool RG, bool BIG, bool ESC = false, bool POOL = false>
 __global__ void __launch_bounds__(64, (ESC && !RG) ? 4 : 1) tb_ff_kernel(KArgs A) {
-  static_assert(!POOL || (!BIG && !ESC), "deferred stragglers are a small-batch scheme");
+  static_assert(!POOL || !ESC, "the pool has no hand-over phase behind it");
   constexpr int TB_FF_REC = ff_rec<RG>();
   __shared__ float4 s_hull[TB_HULL_LDS];
   const int lane = threadIdx.x & 63;
@@ -1251,7 +1251,12 @@ int flush_all(TbHandle* h, hipStream_t s) {
     int g = (h->pool_cap + h->pool_slack + 63) / 64;
     g = g < 1024 ? 1024 : g > 16384 ? 16384 : g;  // (workgroups beyond the pool's fill exit at once; grid-stride beyond 1 M records)
     (void)hipGetLastError();
+    // whole episodes in the pool (ff_defer = 2) make it a LARGE batch -- 43 episodes x 4096 envs = 2752 waves: the instantiation
+    // built for occupancy (161 VGPRs, three waves per SIMD, wave-shared outline sweep) holds them all at once, the small-batch
+    // one (196 VGPRs, two per SIMD) ran them in two rounds
+    const bool big = !rg && (long long)h->pool_episodes * h->n >= 131072;
     if (rg) hipLaunchKernelGGL((tb_ff_kernel<true, false, false, true>), dim3((unsigned)g), dim3(64), dyn_lds(false, true, 64), s, k);
+    else if (big) hipLaunchKernelGGL((tb_ff_kernel<false, true, false, true>), dim3((unsigned)g), dim3(64), dyn_lds(false, false, 64), s, k);
     else hipLaunchKernelGGL((tb_ff_kernel<false, false, false, true>), dim3((unsigned)g), dim3(64), dyn_lds(false, false, 64), s, k);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(h->d_pool_count, 0, sizeof(int), s));

@@ -56,9 +56,9 @@ def main(d, out):
             wb = sum(fw[g] * nff[g] for g in fw) / nff[n] * 1024.0 / write_ratio
             res["workloads"]["%s_%d" % (env, n)]["ff_kernel"] = {
                 "launches": {str(g): nff[g] for g in nff}, "fetch_bytes_per_episode_end": fb, "write_bytes_per_episode_end": wb,
-                "traffic_bytes_per_env_per_episode_end": (fb + wb) / n, "algorithmic_bytes_per_env_per_episode_end": 200,
-                "excess_bytes_per_env_per_episode_end": (fb + wb) / n - 200.0,
-                "note": "per episode end (26 tb_step_kernel launches): reads each parked env's 192-byte record (state + racket<->court cache), writes its reward and clears its parked flag (4 + 4 B). The excess at 4096 envs (one kernel, no hand-overs) is table staging, counters and partial lines; with phases an env handed from one phase kernel to the next (it outlived its budget, or -- first phase of the large-batch chain -- its ball reached the racket) is written and read once more, 192 B each way: at 1 M envs roughly 0.3 hand-overs per env"}
+                "traffic_bytes_per_env_per_episode_end": (fb + wb) / n, "algorithmic_bytes_per_env_per_episode_end": 136,
+                "excess_bytes_per_env_per_episode_end": (fb + wb) / n - 136.0,
+                "note": "per episode end (26 tb_step_kernel launches): reads each parked env's 128-byte record (the state; 192 B with the racket<->court cache in the RG instantiations, and in every kernel until round 3), writes its reward and clears its parked flag (4 + 4 B). The excess at 4096 envs (one kernel, no hand-overs) is table staging, counters and partial lines; with phases an env handed from one phase kernel to the next (it outlived its budget, or -- first phase of the large-batch chain -- its ball reached the racket) is written and read once more, 128 B each way: at 1 M envs roughly 0.3 hand-overs per env"}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
