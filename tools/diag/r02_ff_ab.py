@@ -70,6 +70,9 @@ def main():
     if which == "lanes":  # parked envs per fast-forward wave at the headline batch size
         for o in ({}, dict(ff_lanes_per_wave=32), dict(ff_lanes_per_wave=16), {}, dict(ff_lanes_per_wave=32), dict(ff_lanes_per_wave=48)):
             out.append(measure(4096, 1040, o, flags=flags)); print(json.dumps(out[-1]), flush=True)
+    if which == "one":
+        for o in ({}, {}, {}):
+            out.append(measure(4096, 1040, o, flags=flags)); print(json.dumps(out[-1]), flush=True)
     if which == "lanes_few":  # ... fewer still (racket<->court contact with deferred stragglers: every lane is on a path of its own)
         for o in (dict(ff_lanes_per_wave=16), dict(ff_lanes_per_wave=8), dict(ff_lanes_per_wave=4), dict(ff_lanes_per_wave=16), dict(ff_lanes_per_wave=8), dict(ff_lanes_per_wave=4),
                   dict(ff_lanes_per_wave=8, ff_defer_margin=1), dict(ff_lanes_per_wave=8, ff_defer_margin=64)):
