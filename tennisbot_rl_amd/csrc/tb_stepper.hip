@@ -1621,6 +1621,8 @@ int tb_pipeline_recover(TbHandle* h) {
   // the captured tb_step calls advanced the host's episode phase, but none of them ran
   h->phase = h->phase_at_capture; h->phase_valid = h->phase_valid_at_capture;
   h->pool_ev_valid = 0; h->direct_ev_valid = 0;
+  // episode ends that the abandoned capture "parked" into the pool never ran: nothing is pending on their account
+  h->pool_episodes = 0; h->pool_pending = 0;
   for (int k = 0; k < TB_FF_SLOTS; ++k) {
     h->ff_busy[k] = 0;
     if (!h->side[k]) continue;
