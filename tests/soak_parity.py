@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Lockstep soak at BASELINE's full batch sizes (run on the GPU box; the suite's largest lockstep case is 200 003 envs):
 N envs stepped `steps` times with random actions, every observation / done / reward / substep counter and the final state
-words compared BIT FOR BIT with the f32 CPU oracle (16 host threads). usage: tests/soak_parity.py <swing|tennis> <n_envs> <steps> [rg]"""
+words compared BIT FOR BIT with the f32 CPU oracle (16 host threads). usage: tests/soak_parity.py <swing|tennis> <n_envs> <steps> [rg] [defer|defer_all]"""
 import os
 import sys
 import time
@@ -28,7 +28,9 @@ def main():
     n, steps = int(sys.argv[2]), int(sys.argv[3])
     flags = F_DEFAULT | (F_RACKET_GROUND if "rg" in sys.argv[4:] else 0)
     p = default_params(flags=flags)
-    env = BatchedEnv(kind, n, device="cuda:0", seed=77, params=p, pipeline=kind == ENV_SWING, track_terminal_obs=False)
+    # "defer" / "defer_all": TbOptions.ff_defer = 1 / 2 (deferred stragglers; auto-on with rg up to 131072 envs)
+    opts = dict(ff_defer="all") if "defer_all" in sys.argv[4:] else dict(ff_defer=True) if "defer" in sys.argv[4:] else None
+    env = BatchedEnv(kind, n, device="cuda:0", seed=77, params=p, pipeline=kind == ENV_SWING, track_terminal_obs=False, options=opts)
     pf = p.copy(); pf.flags |= F_AUTO_RESET
     ref = OracleBatch(pf, kind, n, seed=77, precision="f32")
     ref.L.tbo_set_threads(ref.h, 16)
@@ -44,7 +46,7 @@ def main():
         t_gpu += t1 - t0; t_cpu += time.perf_counter() - t1
         same(obs_h, o2, "obs at step %d" % t); same(done_h, d2, "done at step %d" % t)
         if kind == ENV_SWING:
-            late.append((rew.clone(), r2.copy()))  # terminal rewards arrive late from the side streams
+            late.append((rew, r2.copy()))  # terminal rewards arrive late from the side streams (deferred stragglers: at the flush), into THIS buffer
         else:
             same(rew.cpu().numpy(), r2, "reward at step %d" % t)
         compared += n
@@ -58,8 +60,8 @@ def main():
     got, want = env.counters(), [int(x) for x in ref.counters()]
     if list(got.values()) != want:
         raise SystemExit("MISMATCH counters: %r vs %r" % (got, want))
-    print("%s, %d envs x %d steps (flags 0x%x): %d env-steps, %d substeps, %d episode ends, every output and the final state bit-identical to the f32 oracle "
-          "(host loop incl. copies: GPU %.1f s, oracle on 16 threads %.1f s)" % (sys.argv[1], n, steps, flags, compared, got["substeps"], got["episodes_finished"], t_gpu, t_cpu))
+    print("%s, %d envs x %d steps (flags 0x%x%s): %d env-steps, %d substeps, %d episode ends, every output and the final state bit-identical to the f32 oracle "
+          "(host loop incl. copies: GPU %.1f s, oracle on 16 threads %.1f s)" % (sys.argv[1], n, steps, flags, ", " + " ".join(sys.argv[5:] if "rg" in sys.argv[4:5] else sys.argv[4:]) if opts else "", compared, got["substeps"], got["episodes_finished"], t_gpu, t_cpu))
 
 
 if __name__ == "__main__":

@@ -84,7 +84,7 @@ def test_bad_arguments_are_rejected(lib):
     bad.n_hull = 2
     assert lib.tb_create(ctypes.byref(bad), None, ENV_SWING, 16, 0, 0, 0, ctypes.byref(h)) == -3
     assert b"n_hull" in lib.tb_last_error()
-    # kernel-selection options travel through the ABI (v3), not through environment variables
+    # kernel-selection options travel through the ABI (since v3), not through environment variables
     assert lib.tb_abi_version() == 4
     o = make_options(block=96)
     assert lib.tb_create(ctypes.byref(p), ctypes.byref(o), ENV_SWING, 16, 0, 0, 0, ctypes.byref(h)) == -1 and b"block" in lib.tb_last_error()
