@@ -654,7 +654,8 @@ def main():
                 + (" + rolling-friction rows" if args.rolling_friction else "")
                 + (" + Magnus k=%g, spin<=%g rad/s (extension, not in the reference)" % (args.magnus, args.spin_max) if (args.magnus or args.spin_max) else ""),
                 T_roll, "%d episodes" % (T_roll // 26) if kind == ENV_SWING else "steady state",
-                ", fast-forward pipelined on side streams" if pipeline else "", ", one hipGraph replay per rollout" if R.graph is not None else ", steps issued from the host",
+                {"none": "", "slots": ", one fast-forward kernel per episode end on a side stream", "slots+pool": ", one fast-forward kernel per episode end on a side stream (stragglers deferred to the join)",
+                 "pool": ", episode ends parked and run to their end by ONE fast-forward launch at the join"}[R.env.pipeline_form()], ", one hipGraph replay per rollout" if R.graph is not None else ", steps issued from the host",
                 gather_note),
                 "envs_per_gpu": N, "global_envs": world * N, "parallelism": "env-sharded x%d" % world},
             "substeps_per_s": timed_substeps / wall_max,

@@ -176,15 +176,17 @@ typedef struct TbOptions {
   int32_t ff_sort;          /* order parked envs by their ball's ballistic flight estimate before the fast-forward: 1 on (auto: off --
                              * with random actions the flight lengths are decided by events inside the loop, not by the parked state) */
   int32_t ff_phases;        /* the fast-forward as 1, 2 or 3 kernels: budgeted loop, then its compacted survivors (auto: 3 from 262144 envs on, else 1; from 131072 envs on the first of several also hands over every env whose ball reaches the racket) */
-  int32_t ff_defer;         /* deferred stragglers (SwingRacket-v0 pipeline, up to 131072 envs): a parked env still running after its ballistic
-                             * flight estimate + ff_defer_margin substeps moves on to a pool shared by all episodes, which ONE kernel launch runs
-                             * to its end when the caller joins (tb_flush and every call that flushes) -- hundreds of stragglers side by side
-                             * instead of one or two holding up each episode's fast-forward kernel. 1 on, -1 off, 2 = EVERY parked env goes
-                             * straight to the pool (no fast-forward kernel per episode at all: up to 64 episodes per join; what a PPO
-                             * collect wants, whose rollout kernels then run undisturbed and whose flights are long) (auto: 1 with
-                             * TB_F_RACKET_GROUND, whose resting stacks run to the 800-substep limit; off otherwise -- with random actions the
-                             * plain kernels are faster; tennisbot_rl_amd.ppo turns it on: struck balls fly long). Results do not change. Not
-                             * used while progress marks are enabled or terminal-observation / substep outputs are asked for. */
+  int32_t ff_defer;         /* deferred fast-forwards (SwingRacket-v0 pipeline, up to 131072 envs). A fast-forward kernel lasts as long as its
+                             * slowest env, at most four run at once (one per hardware queue), and every one is a FORK in a replayed graph that
+                             * moves the chain of steps to another queue. 2: every episode end is parked straight into a pool (up to 64 episodes
+                             * between two joins) and ONE launch runs all of them to their end when the caller joins (tb_flush and every call
+                             * that flushes): the rollout is a single chain of step kernels. 1: each episode keeps its own fast-forward kernel,
+                             * but an env still running after its ballistic flight estimate (capped at an un-struck ball's) + ff_defer_margin
+                             * substeps moves on to the pool. -1: off. 0 = auto: 2 up to 16384 envs (4096 envs: 679 -> 871 M env steps/s; with
+                             * racket<->court contact 92 -> 115-127 M), above that 1 with TB_F_RACKET_GROUND, else off (large batches run their
+                             * fast-forwards beside the steps, in phases). Results do not change; terminal rewards are complete after the join,
+                             * as with every pipelined path. Not used while progress marks are enabled (a mark promises final steps) or
+                             * terminal-observation / substep outputs are asked for. */
   int32_t ff_defer_margin;  /* substeps beyond the estimate before an env is deferred (auto: 16) */
   int32_t policy_slices;    /* tb_policy_rollout: 16-env slices per workgroup, 1 (three waves per 16 envs) or 3 (seven waves per 48 envs) (auto: 1 up to 4096 envs) */
 } TbOptions;
@@ -372,6 +374,11 @@ int tb_pipeline_sync(TbHandle *h, int host_wait);
  * tb_set_state re-derives the phase from the step-count row when every env agrees. */
 int tb_phase(TbHandle *h);
 int tb_phase_advance(TbHandle *h, int n_steps);
+/* Which form the SwingRacket pipeline takes on this handle as it stands (TbOptions.ff_defer, the batch size, the contact flags,
+ * progress marks on or off) for steps that ask for no terminal-observation / substep outputs: 0 = no pipeline (the fast-forward runs
+ * inside the 26th step's kernel), 1 = one fast-forward kernel per episode end on a side stream, 2 = the same, its stragglers moving on
+ * to the pool, 3 = every episode end parked into the pool, one fast-forward launch at the join. For reports (bench.py names it). */
+int tb_pipeline_form(TbHandle *h);
 /* After a capture that contained tb_step calls was ABANDONED (it failed, e.g. because something else
  * in it was not capturable): the handle's side streams were forked into that capture and stay
  * invalidated, and the host's episode-phase hint ran ahead of the device. Replaces the side streams

@@ -1163,6 +1163,7 @@ bool extended_contacts(const KParams& kp) {
 //  the fast-forward -- is the parking node's first successor. It does what was hoped for the chain -- all 2132 step kernels of two
 //  replays on ONE hardware queue instead of 572 / 520 / 520 / 520 -- but a replayed graph then puts every second successor on the same
 //  second queue: 79 of 82 fast-forwards in line behind each other, 209 M env steps/s instead of 700.)
+int defer_mode(const TbHandle* h);
 int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const void* substeps, hipStream_t s) {
   KArgs a = a_in;
   hipStream_t side = h->side[slot];
@@ -1189,8 +1190,7 @@ int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const 
   // deferred stragglers: on request (TbOptions.ff_defer > 0), or by default with racket<->court contact, whose resting stacks run
   // to the 800-substep limit. Not with progress marks (a mark promises that the steps before it are FINAL), not with late-written
   // terminal observations / substep counts (the pool keeps one destination per record: the reward's)
-  const bool defer = h->d_pool && phases == 1 && h->phase_valid && !sort && !h->marks_on && !term && !substeps &&
-                     (h->opt.ff_defer == 1 || (h->opt.ff_defer == 0 && (h->kp.flags & TB_F_RACKET_GROUND)));
+  const bool defer = h->d_pool && phases == 1 && h->phase_valid && !sort && !h->marks_on && !term && !substeps && defer_mode(h) == 1;
   if (phases > 1) HIP_TRY(hipMemsetAsync(h->d_ff_count[slot], 0, 2 * sizeof(int), side));
   for (int ph = 0; ph < phases; ++ph) {
     KArgs k = a;
@@ -1270,9 +1270,22 @@ int flush_all(TbHandle* h, hipStream_t s) {
 // k-th such launch since the last flush -- and no fast-forward kernel of its own follows: the pool run at the join does all of
 // them at once. Returns whether `a` was set up that way (not with progress marks / late-written outputs / a full pool: then the
 // ordinary slot + tb_ff_kernel path serves the launch).
+// What TbOptions.ff_defer = 0 (auto) means for this handle: 2 -- every episode end straight into the pool -- up to 16384 envs, where
+// the rollout is a chain of launch-bound step kernels and every fork of a replayed graph costs the CHAIN (the next step moves to
+// another hardware queue: ~10 us per episode end, and 1.7-2.8 us between all other steps instead of ~1.2 us in a graph that is one
+// single list): 4096 envs, same box, 679 -> 871 M env steps/s (1024: 160 -> 225 M, 8192: 1.30 -> 1.49 G, 16384: 2.58 -> 2.63 G, 32768:
+// 4.80 -> 4.26 G; racket<->court contact at 4096 envs: 92 -> 115-127 M). Above that: 1 (stragglers only) with racket<->court contact up
+// to the pool's size limit, else 0 -- large batches run their fast-forwards beside the steps, in phases.
+int defer_mode(const TbHandle* h) {
+  if (!h->d_pool || h->opt.ff_defer < 0) return 0;
+  if (h->opt.ff_defer > 0) return h->opt.ff_defer;
+  if (h->n <= 16384) return 2;
+  return (h->kp.flags & TB_F_RACKET_GROUND) ? 1 : 0;
+}
+
 bool park_direct(TbHandle* h, KArgs& a, const void* term, const void* substeps, hipStream_t s, int* rc) {
   *rc = TB_OK;
-  if (!(h->d_pool && h->opt.ff_defer == 2 && h->phase_valid && !h->marks_on && !term && !substeps && h->pool_episodes < h->pool_cap / h->n)) return false;
+  if (!(h->d_pool && defer_mode(h) == 2 && h->phase_valid && !h->marks_on && !term && !substeps && h->pool_episodes < h->pool_cap / h->n)) return false;
   if (h->pool_ev_valid) {  // behind the last pool run (which may have been enqueued on another stream)
     hipError_t e = hipStreamWaitEvent(s, h->ev_pool, 0);
     if (e != hipSuccess) { *rc = fail((int)e, "hipStreamWaitEvent(s, h->ev_pool, 0)"); return false; }
@@ -1649,6 +1662,13 @@ int tb_flush(TbHandle* h, void* stream) {
 int tb_phase(TbHandle* h) {
   if (!h) return fail(TB_E_INVAL, "tb_phase: null handle");
   return h->phase_valid ? h->phase : -1;
+}
+
+int tb_pipeline_form(TbHandle* h) {
+  if (!h) return fail(TB_E_INVAL, "tb_pipeline_form: null handle");
+  if (h->kind != TB_ENV_SWING || !h->pipeline) return 0;
+  const int mode = h->marks_on ? 0 : defer_mode(h);
+  return mode == 2 ? 3 : mode == 1 && h->ff_phases == 1 && !h->ff_sort ? 2 : 1;
 }
 
 int tb_phase_advance(TbHandle* h, int n_steps) {

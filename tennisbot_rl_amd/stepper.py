@@ -86,6 +86,8 @@ def load_library():
     L.tb_phase.restype = i32
     L.tb_phase_advance.argtypes = [vp, i32]
     L.tb_phase_advance.restype = i32
+    L.tb_pipeline_form.argtypes = [vp]
+    L.tb_pipeline_form.restype = i32
     L.tb_params_generation.argtypes = [vp]
     L.tb_params_generation.restype = i32
     L.tb_set_racket_scale.argtypes = [vp, ctypes.c_float, vp]
@@ -513,6 +515,13 @@ class BatchedEnv:
     def phase(self):
         """agent steps since the last common reset modulo 26, or -1 when the envs are not in lockstep"""
         return int(self.L.tb_phase(self._h))
+
+    PIPELINE_FORMS = ("none", "slots", "slots+pool", "pool")
+
+    def pipeline_form(self):
+        """tb_pipeline_form as a word: "none" (fast-forward inside the 26th step), "slots" (one fast-forward kernel per episode end on a
+        side stream), "slots+pool" (its stragglers deferred to the join), "pool" (every episode end parked, ONE fast-forward at the join)"""
+        return self.PIPELINE_FORMS[int(self.L.tb_pipeline_form(self._h))]
 
     # ------------------------------------------------------------------ state save / restore
     def get_state_words(self):

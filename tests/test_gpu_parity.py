@@ -343,14 +343,20 @@ def test_rollout_equals_repeated_steps(torch):
         e1.close(); e2.close()
 
 
-def test_pipelined_rollout_equals_repeated_steps(torch):
+# The pipeline's two forms: ff_defer=False -- one fast-forward kernel per episode end, on a side stream ("slots"); None -- the automatic
+# choice, which up to 16384 envs parks every episode end into the pool and runs ONE fast-forward at the join (TbOptions.ff_defer = 2)
+BOTH_PIPELINES = pytest.mark.parametrize("defer", [False, None], ids=["slots", "auto"])
+
+
+@BOTH_PIPELINES
+def test_pipelined_rollout_equals_repeated_steps(torch, defer):
     """tb_rollout with the pipeline on: launches that end where the episodes end (<= 26 steps each),
-    fast-forwards on the side streams -- from any starting phase, also captured in a hipGraph"""
+    fast-forwards on the side streams or at the join -- from any starting phase, also captured in a hipGraph"""
     from tennisbot_rl_amd.stepper import BatchedEnv
     n, T = 1000, 75
     rng = np.random.default_rng(13)
     acts = torch.from_numpy(rng.uniform(-1, 1, (T + 9, n, 6)).astype(np.float32)).cuda()
-    e1 = BatchedEnv(ENV_SWING, n, seed=4, pipeline=True, track_terminal_obs=False)
+    e1 = BatchedEnv(ENV_SWING, n, seed=4, pipeline=True, track_terminal_obs=False, options=dict(ff_defer=defer))
     e2 = BatchedEnv(ENV_SWING, n, seed=4)
     e1.reset(); e2.reset()
     for t in range(9):  # start the rollout in the middle of an episode
@@ -733,7 +739,8 @@ def test_hipgraph_replay_equals_eager(torch):
         a.close(); b.close()
 
 
-def test_graph_is_refused_at_another_phase_or_after_set_params(torch):
+@BOTH_PIPELINES
+def test_graph_is_refused_at_another_phase_or_after_set_params(torch, defer):
     """a pipelined SwingRacket graph bakes in which of its steps end an episode; K % 26 != 0 moves the phase, and
     a second replay would let episode ends fall into launches without a fast-forward slot (terminal rewards lost).
     StepGraph refuses that instead (and a graph captured before set_params, whose launches carry the old block);
@@ -743,7 +750,7 @@ def test_graph_is_refused_at_another_phase_or_after_set_params(torch):
     n, T = 1000, 30
     rng = np.random.default_rng(44)
     acts = torch.from_numpy(rng.uniform(-1, 1, (T, n, 6)).astype(np.float32)).cuda()
-    a = BatchedEnv(ENV_SWING, n, seed=9, pipeline=True, track_terminal_obs=False)
+    a = BatchedEnv(ENV_SWING, n, seed=9, pipeline=True, track_terminal_obs=False, options=dict(ff_defer=defer))
     b = BatchedEnv(ENV_SWING, n, seed=9)
     ba, bb = RolloutBuffer(ENV_SWING, T, n, "cuda:0").bind(a), RolloutBuffer(ENV_SWING, T, n, "cuda:0")
     ba.actions.copy_(acts); bb.actions.copy_(acts)
@@ -808,7 +815,8 @@ def test_curriculum_scale_reaches_replayed_graphs(torch):
     env.close()
 
 
-def test_restored_lockstep_state_rearms_the_pipeline(torch):
+@BOTH_PIPELINES
+def test_restored_lockstep_state_rearms_the_pipeline(torch, defer):
     """tb_set_state re-derives the episode phase when every injected env is running at the same step count:
     a checkpoint restored into a fresh handle can go on with whole-episode launches (tb_policy_rollout needs
     the phase) -- and ragged step counts leave the phase unknown"""
@@ -816,8 +824,8 @@ def test_restored_lockstep_state_rearms_the_pipeline(torch):
     n = 700
     rng = np.random.default_rng(45)
     acts = torch.from_numpy(rng.uniform(-1, 1, (60, n, 6)).astype(np.float32)).cuda()
-    a = BatchedEnv(ENV_SWING, n, seed=10, pipeline=True, track_terminal_obs=False)
-    b = BatchedEnv(ENV_SWING, n, seed=10, pipeline=True, track_terminal_obs=False)
+    a = BatchedEnv(ENV_SWING, n, seed=10, pipeline=True, track_terminal_obs=False, options=dict(ff_defer=defer))
+    b = BatchedEnv(ENV_SWING, n, seed=10, pipeline=True, track_terminal_obs=False, options=dict(ff_defer=defer))
     twin = BatchedEnv(ENV_SWING, n, seed=10)
     a.reset(); twin.reset()
     for t in range(33):
@@ -904,7 +912,8 @@ def test_racket_ground_contact_opt_in(torch):
     env.close()
 
 
-def test_step_sequence_equals_per_step_calls_and_chunked_gather_views(torch):
+@BOTH_PIPELINES
+def test_step_sequence_equals_per_step_calls_and_chunked_gather_views(torch, defer):
     """tb_step_sequence (one host call for a run of rollout slots) against step_into per slot, with the
     pipelined fast-forward on; and the chunked-gather bookkeeping on a single rank (no collective)"""
     from tennisbot_rl_amd.rollout import RolloutBuffer
@@ -914,7 +923,7 @@ def test_step_sequence_equals_per_step_calls_and_chunked_gather_views(torch):
     acts = torch.from_numpy(rng.uniform(-1, 1, (T, n, 6)).astype(np.float32)).cuda()
     bufs = []
     for mode in ("per_step", "sequence"):
-        env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=21, track_terminal_obs=False, pipeline=True)
+        env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=21, track_terminal_obs=False, pipeline=True, options=dict(ff_defer=defer))
         buf = RolloutBuffer(ENV_SWING, T, n, "cuda:0").bind(env)
         buf.actions.copy_(acts)
         env.reset()
@@ -930,7 +939,7 @@ def test_step_sequence_equals_per_step_calls_and_chunked_gather_views(torch):
         with pytest.raises(ValueError):
             buf.step_range(env, 10, T + 1)
     assert torch.equal(bufs[0].raw, bufs[1].raw)
-    assert float(bufs[0].dones.sum()) == 3 * n  # three whole episodes went through the side streams
+    assert float(bufs[0].dones.sum()) == 3 * n  # three whole episodes went through the side streams / the pool
     buf = bufs[1]
     buf.begin_gather(3)
     for c in range(3):
@@ -1003,9 +1012,10 @@ from tennisbot_rl_amd.stepper import BatchedEnv
 n = 512
 rng = np.random.default_rng(8)
 acts = torch.from_numpy(rng.uniform(-1, 1, (60, n, 6)).astype(np.float32)).cuda()
-# argv[1] = "all": the episode end inside the abandoned capture was "parked" straight into the stragglers' pool (TbOptions.ff_defer = 2)
-# by a launch that never ran -- nothing may be pending on its account afterwards
-env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=4, track_terminal_obs=False, pipeline=True, options=dict(ff_defer=sys.argv[1]) if len(sys.argv) > 1 else None)
+# argv[1] = "all" (what the automatic choice is at this size): the episode end inside the abandoned capture was "parked" straight into
+# the pool (TbOptions.ff_defer = 2) by a launch that never ran -- nothing may be pending on its account afterwards; "slots": one
+# fast-forward kernel per episode end, whose side stream the capture had forked
+env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=4, track_terminal_obs=False, pipeline=True, options=dict(ff_defer=False if sys.argv[1] == "slots" else sys.argv[1]))
 twin = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=4, track_terminal_obs=False, pipeline=True)
 env.reset(); twin.reset()
 for t in range(20):
@@ -1037,7 +1047,7 @@ print("survived")
 """
 
 
-@pytest.mark.parametrize("defer", [None, "all"])
+@pytest.mark.parametrize("defer", ["slots", "all"])
 def test_abandoned_capture_leaves_the_env_usable(torch, defer):
     """a capture that fails half-way (here: a host synchronisation inside it) must not poison the
     handle: tb_pipeline_recover replaces the forked side streams and restores the phase hint, and
@@ -1047,7 +1057,7 @@ def test_abandoned_capture_leaves_the_env_usable(torch, defer):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", _ABANDONED_CAPTURE_CASE] + ([defer] if defer else []), cwd=root, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, "-c", _ABANDONED_CAPTURE_CASE, defer], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "survived" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
@@ -1062,7 +1072,7 @@ def test_replay_orders_itself_behind_unflushed_eager_fast_forwards(torch):
     rng = np.random.default_rng(77)
     acts = torch.from_numpy(rng.uniform(-1, 1, (T, n, 6)).astype(np.float32)).cuda()
     eager = torch.from_numpy(rng.uniform(-1, 1, (E, n, 6)).astype(np.float32)).cuda()
-    a = BatchedEnv(ENV_SWING, n, seed=3, params=p, pipeline=True, track_terminal_obs=False)
+    a = BatchedEnv(ENV_SWING, n, seed=3, params=p, pipeline=True, track_terminal_obs=False, options=dict(ff_defer=False))  # slots: kernels in flight
     b = BatchedEnv(ENV_SWING, n, seed=3, params=p)
     ba, bb = RolloutBuffer(ENV_SWING, T, n, "cuda:0").bind(a), RolloutBuffer(ENV_SWING, T, n, "cuda:0")
     ea = RolloutBuffer(ENV_SWING, E, n, "cuda:0").bind(a)
@@ -1120,6 +1130,26 @@ def test_set_pipeline_failure_is_all_or_nothing(torch):
     c = env.counters()
     assert c["lockstep_violations"] == 0 and list(c.values()) == [int(x) for x in ref.counters()]
     env.close()
+
+
+def test_pipeline_form_follows_size_flags_and_marks(torch):
+    """tb_pipeline_form: what TbOptions.ff_defer = 0 (auto) resolves to -- every episode end into the pool up to 16384 envs, the
+    stragglers only above that with racket<->court contact, plain slots otherwise and whenever progress marks are on"""
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    rgp = default_params(flags=F_DEFAULT | F_RACKET_GROUND)
+    cases = [(ENV_SWING, 1000, None, {}, True, "pool"), (ENV_SWING, 16384, rgp, {}, True, "pool"), (ENV_SWING, 16385, None, {}, True, "slots"),
+             (ENV_SWING, 16385, rgp, {}, True, "slots+pool"), (ENV_SWING, 1000, None, dict(ff_defer=False), True, "slots"),
+             (ENV_SWING, 1000, None, dict(ff_defer=True), True, "slots+pool"), (ENV_SWING, 40000, None, dict(ff_defer="all"), True, "pool"),
+             (ENV_SWING, 1000, None, {}, False, "none"), (ENV_TENNIS, 1000, None, {}, False, "none")]
+    for kind, n, p, opts, piped, want in cases:
+        env = BatchedEnv(kind, n, seed=1, params=p, pipeline=piped, track_terminal_obs=False, options=opts)
+        assert env.pipeline_form() == want, (kind, n, opts, piped, env.pipeline_form(), want)
+        if want == "pool":
+            assert env.L.tb_mark_enable(env._h, 1) == 0
+            assert env.pipeline_form() == "slots"
+            assert env.L.tb_mark_enable(env._h, 0) == 0
+            assert env.pipeline_form() == "pool"
+        env.close()
 
 
 @pytest.mark.parametrize("rg,n,episodes,margin", [(False, 4096, 3, 0), (True, 2048, 3, 0), (False, 64, 700, 1), (True, 1000, 2, 200),

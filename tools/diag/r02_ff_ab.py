@@ -70,6 +70,13 @@ def main():
     if which == "lanes":  # parked envs per fast-forward wave at the headline batch size
         for o in ({}, dict(ff_lanes_per_wave=32), dict(ff_lanes_per_wave=16), {}, dict(ff_lanes_per_wave=32), dict(ff_lanes_per_wave=48)):
             out.append(measure(4096, 1040, o, flags=flags)); print(json.dumps(out[-1]), flush=True)
+    if which == "defer":  # the random-action headline with the stragglers' pool: off (auto), margin form, every episode end deferred (a pure chain of steps)
+        for o in ({}, dict(ff_defer=True), dict(ff_defer="all"), {}, dict(ff_defer=True), dict(ff_defer="all")):
+            out.append(measure(4096, 1040, o, flags=flags)); print(json.dumps(out[-1]), flush=True)
+    if which == "defer_ladder":  # where does deferring every episode end to one pool run at the join stop paying?
+        for n in (1024, 4096, 8192, 16384, 32768, 65536, 131072):
+            for o in ({}, dict(ff_defer="all"), dict(ff_defer=False)):
+                out.append(measure(n, 1040 if n <= 32768 else 104, o, reps=3, flags=flags)); print(json.dumps(out[-1]), flush=True)
     if which == "one":
         for o in ({}, {}, {}):
             out.append(measure(4096, 1040, o, flags=flags)); print(json.dumps(out[-1]), flush=True)
