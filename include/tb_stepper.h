@@ -185,8 +185,9 @@ typedef struct TbOptions {
                              * substeps moves on to the pool. -1: off. 0 = auto: 2 up to 16384 envs (4096 envs: 679 -> 871 M env steps/s; with
                              * racket<->court contact 92 -> 115-127 M), above that 1 with TB_F_RACKET_GROUND, else off (large batches run their
                              * fast-forwards beside the steps, in phases). Results do not change; terminal rewards are complete after the join,
-                             * as with every pipelined path. Not used while progress marks are enabled (a mark promises final steps) or
-                             * terminal-observation / substep outputs are asked for. */
+                             * as with every pipelined path. Progress marks (a mark promises final steps): form 2 gives the episodes parked since the
+                             * previous mark their launch at tb_mark_record, on a side stream; form 1 is not used while marks are enabled. Neither
+                             * is used for steps that ask for terminal-observation / substep outputs. */
   int32_t ff_defer_margin;  /* substeps beyond the estimate before an env is deferred (auto: 16) */
   int32_t policy_slices;    /* tb_policy_rollout: 16-env slices per workgroup, 1 (three waves per 16 envs) or 3 (seven waves per 48 envs) (auto: 1 up to 4096 envs) */
 } TbOptions;
@@ -343,7 +344,8 @@ int tb_flush(TbHandle *h, void *stream);
  * kernel that counts it as finished in pinned host memory (off by default: plain graphs carry nothing extra);
  * call it before issuing -- or capturing -- the steps that marks will cover.
  * tb_mark_record(h, k, stream): the same one-thread kernel on `stream`, incrementing counter k; the library
- * remembers how many fast-forwards were enqueued before the mark. Captured into a graph these are ordinary kernel nodes: every replay fires them again.
+ * remembers how many fast-forwards were enqueued before the mark (with TbOptions.ff_defer form 2 it first enqueues, on a side
+ * stream, the ONE fast-forward launch of the episodes parked since the previous mark). Captured into a graph these are ordinary kernel nodes: every replay fires them again.
  * tb_mark_begin(h): snapshot of the counters; call it right before launching the work that contains the marks,
  * with nothing of this handle in flight (e.g. after a stream synchronize).
  * tb_mark_host_wait(h, k, timeout_ms): spin on the host until mark k has fired since tb_mark_begin and the
@@ -377,7 +379,8 @@ int tb_phase_advance(TbHandle *h, int n_steps);
 /* Which form the SwingRacket pipeline takes on this handle as it stands (TbOptions.ff_defer, the batch size, the contact flags,
  * progress marks on or off) for steps that ask for no terminal-observation / substep outputs: 0 = no pipeline (the fast-forward runs
  * inside the 26th step's kernel), 1 = one fast-forward kernel per episode end on a side stream, 2 = the same, its stragglers moving on
- * to the pool, 3 = every episode end parked into the pool, one fast-forward launch at the join. For reports (bench.py names it). */
+ * to the pool, 3 = every episode end parked into the pool, one fast-forward launch at the join (and at each progress mark). For
+ * reports (bench.py names it). */
 int tb_pipeline_form(TbHandle *h);
 /* After a capture that contained tb_step calls was ABANDONED (it failed, e.g. because something else
  * in it was not capturable): the handle's side streams were forked into that capture and stay

@@ -1083,6 +1083,7 @@ struct TbHandle {
   float** d_pool_dst;             // [pool_cap + pool_slack] where each deferred env's terminal reward goes
   int* d_pool_count;
   int pool_cap, pool_slack, pool_pending;  // pending: records may be waiting (the next flush runs the pool kernel)
+  int pool_run_upto;              // ... of which the first pool_run_upto have had their launch already (at a progress mark)
   int pool_episodes;              // ff_defer = 2: episodes parked straight into the pool since the last flush (records [k n, (k + 1) n) each)
   hipEvent_t ev_direct;           // ... and the latest launch that did so (a flush on another stream waits for it)
   hipEvent_t ev_pool;             // the last pool run (+ the reset of its counter): later fast-forwards append behind it, whatever stream flushed
@@ -1236,33 +1237,71 @@ int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const 
   return TB_OK;
 }
 
+// ONE launch for what the pool holds: the whole episodes parked straight into it (ff_defer = 2) that no launch has been given to yet
+// -- regions [pool_run_upto, pool_episodes): the host knows how many records -- or, without any, the stragglers that the episodes'
+// own fast-forward kernels moved on to it (ff_defer = 1: their number is the pool's device counter)
+int run_pool(TbHandle* h, hipStream_t q) {
+  KArgs k = base_args(h);
+  const bool rg = extended_contacts(h->kp);
+  k.ff_rec = h->d_pool; k.ff_flag = nullptr; k.ff_src_count = h->d_pool_count; k.ff_lanes = 64;
+  k.ff_cap = h->pool_cap + h->pool_slack; k.pool_dst_in = h->d_pool_dst;
+  long long records = (long long)h->pool_cap + h->pool_slack;
+  if (h->pool_episodes > 0) {
+    const size_t first = (size_t)h->pool_run_upto * h->n;
+    records = (long long)(h->pool_episodes - h->pool_run_upto) * h->n;
+    k.ff_src_count = nullptr; k.n = (int)records;
+    k.ff_rec = h->d_pool + first * (rg ? TB_FF_REC_MAX : 8); k.pool_dst_in = h->d_pool_dst + first;
+  }
+  long long g = (records + 63) / 64;
+  g = g < 1024 ? 1024 : g > 16384 ? 16384 : g;  // (workgroups beyond the pool's fill exit at once; grid-stride beyond 1 M records)
+  (void)hipGetLastError();
+  // whole episodes in the pool make it a LARGE batch -- 43 episodes x 4096 envs = 2752 waves: the instantiation built for occupancy
+  // (161 VGPRs, three waves per SIMD, wave-shared outline sweep) holds them all at once, the small-batch one (196 VGPRs, two per
+  // SIMD) ran them in two rounds
+  const bool big = !rg && h->pool_episodes > 0 && records >= 131072;
+  if (rg) hipLaunchKernelGGL((tb_ff_kernel<true, false, false, true>), dim3((unsigned)g), dim3(64), dyn_lds(false, true, 64), q, k);
+  else if (big) hipLaunchKernelGGL((tb_ff_kernel<false, true, false, true>), dim3((unsigned)g), dim3(64), dyn_lds(false, false, 64), q, k);
+  else hipLaunchKernelGGL((tb_ff_kernel<false, false, false, true>), dim3((unsigned)g), dim3(64), dyn_lds(false, false, 64), q, k);
+  HIP_TRY(hipGetLastError());
+  h->pool_run_upto = h->pool_episodes;
+  return TB_OK;
+}
+
 // every result of every fast-forward is in place once `s` gets past this point
 int flush_all(TbHandle* h, hipStream_t s) {
   if (int rc = wait_side(h, s)) return rc;
-  if (h->pool_pending) {  // the deferred stragglers of every episode since the last flush, side by side in one launch
-    KArgs k = base_args(h);
-    k.ff_rec = h->d_pool; k.ff_flag = nullptr; k.ff_src_count = h->d_pool_count; k.ff_lanes = 64;
-    k.ff_cap = h->pool_cap + h->pool_slack; k.pool_dst_in = h->d_pool_dst;
-    if (h->pool_episodes > 0) {  // whole episodes parked straight into the pool: the host knows how many records there are
-      k.ff_src_count = nullptr; k.n = h->pool_episodes * h->n;
-      if (h->direct_ev_valid) HIP_TRY(hipStreamWaitEvent(s, h->ev_direct, 0));  // (a flush on another stream than the steps')
+  if (h->pool_pending) {  // what the episodes since the last flush left in the pool, side by side in one launch
+    if (h->pool_episodes > 0 && h->direct_ev_valid) HIP_TRY(hipStreamWaitEvent(s, h->ev_direct, 0));  // (a flush on another stream than the steps')
+    if (h->pool_episodes == 0 || h->pool_run_upto < h->pool_episodes) {
+      if (int rc = run_pool(h, s)) return rc;
     }
-    const bool rg = extended_contacts(h->kp);
-    int g = (h->pool_cap + h->pool_slack + 63) / 64;
-    g = g < 1024 ? 1024 : g > 16384 ? 16384 : g;  // (workgroups beyond the pool's fill exit at once; grid-stride beyond 1 M records)
-    (void)hipGetLastError();
-    // whole episodes in the pool (ff_defer = 2) make it a LARGE batch -- 43 episodes x 4096 envs = 2752 waves: the instantiation
-    // built for occupancy (161 VGPRs, three waves per SIMD, wave-shared outline sweep) holds them all at once, the small-batch
-    // one (196 VGPRs, two per SIMD) ran them in two rounds
-    const bool big = !rg && (long long)h->pool_episodes * h->n >= 131072;
-    if (rg) hipLaunchKernelGGL((tb_ff_kernel<true, false, false, true>), dim3((unsigned)g), dim3(64), dyn_lds(false, true, 64), s, k);
-    else if (big) hipLaunchKernelGGL((tb_ff_kernel<false, true, false, true>), dim3((unsigned)g), dim3(64), dyn_lds(false, false, 64), s, k);
-    else hipLaunchKernelGGL((tb_ff_kernel<false, false, false, true>), dim3((unsigned)g), dim3(64), dyn_lds(false, false, 64), s, k);
-    HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(h->d_pool_count, 0, sizeof(int), s));
     HIP_TRY(hipEventRecord(h->ev_pool, s));
-    h->pool_pending = 0; h->pool_ev_valid = 1; h->pool_episodes = 0;
+    h->pool_pending = 0; h->pool_ev_valid = 1; h->pool_episodes = 0; h->pool_run_upto = 0;
   }
+  return TB_OK;
+}
+
+// Progress marks with ff_defer = 2: a mark promises that the steps before it are FINAL, so the episodes parked since the last mark
+// (or flush) get their pool launch now -- on a side stream, beside the steps of the next chunk, counted like any fast-forward kernel.
+// A graph of C chunks forks C times instead of once per episode.
+int run_pool_for_mark(TbHandle* h, hipStream_t s) {
+  if (!(h->pool_episodes > h->pool_run_upto)) return TB_OK;
+  const int slot = h->next_slot;
+  h->next_slot = (slot + 1) % TB_FF_SLOTS;
+  hipStream_t side = h->side[slot];
+  HIP_TRY(hipEventRecord(h->ev_step[slot], s));
+  HIP_TRY(hipStreamWaitEvent(side, h->ev_step[slot], 0));
+  if (int rc = run_pool(h, side)) return rc;
+  if (h->h_marks && h->marks_on) {
+    hipLaunchKernelGGL(tb_mark_kernel, dim3(1), dim3(1), 0, side, h->h_marks + TB_MAX_MARKS + slot);
+    HIP_TRY(hipGetLastError());
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    HIP_TRY(hipStreamIsCapturing(s, &st));
+    if (st == hipStreamCaptureStatusActive) h->ff_cap[slot]++; else h->ff_eager[slot]++;
+  }
+  HIP_TRY(hipEventRecord(h->ev_ff[slot], side));
+  h->ff_busy[slot] = 1; h->last_slot = slot; h->last_term = nullptr; h->last_sub = nullptr;
   return TB_OK;
 }
 
@@ -1285,7 +1324,7 @@ int defer_mode(const TbHandle* h) {
 
 bool park_direct(TbHandle* h, KArgs& a, const void* term, const void* substeps, hipStream_t s, int* rc) {
   *rc = TB_OK;
-  if (!(h->d_pool && defer_mode(h) == 2 && h->phase_valid && !h->marks_on && !term && !substeps && h->pool_episodes < h->pool_cap / h->n)) return false;
+  if (!(h->d_pool && defer_mode(h) == 2 && h->phase_valid && !term && !substeps && h->pool_episodes < h->pool_cap / h->n)) return false;
   if (h->pool_ev_valid) {  // behind the last pool run (which may have been enqueued on another stream)
     hipError_t e = hipStreamWaitEvent(s, h->ev_pool, 0);
     if (e != hipSuccess) { *rc = fail((int)e, "hipStreamWaitEvent(s, h->ev_pool, 0)"); return false; }
@@ -1537,7 +1576,7 @@ static void release_pipeline(TbHandle* h) {
   if (h->d_pool_count) (void)hipFree(h->d_pool_count);
   if (h->ev_pool) (void)hipEventDestroy(h->ev_pool);
   if (h->ev_direct) (void)hipEventDestroy(h->ev_direct);
-  h->ev_pool = nullptr; h->ev_direct = nullptr; h->pool_ev_valid = 0; h->direct_ev_valid = 0; h->pool_episodes = 0;
+  h->ev_pool = nullptr; h->ev_direct = nullptr; h->pool_ev_valid = 0; h->direct_ev_valid = 0; h->pool_episodes = 0; h->pool_run_upto = 0;
   h->d_pool = nullptr; h->d_pool_dst = nullptr; h->d_pool_count = nullptr; h->pool_cap = 0; h->pool_slack = 0; h->pool_pending = 0;
   h->pipeline = 0;
 }
@@ -1635,7 +1674,7 @@ int tb_pipeline_recover(TbHandle* h) {
   h->phase = h->phase_at_capture; h->phase_valid = h->phase_valid_at_capture;
   h->pool_ev_valid = 0; h->direct_ev_valid = 0;
   // episode ends that the abandoned capture "parked" into the pool never ran: nothing is pending on their account
-  h->pool_episodes = 0; h->pool_pending = 0;
+  h->pool_episodes = 0; h->pool_run_upto = 0; h->pool_pending = 0;
   for (int k = 0; k < TB_FF_SLOTS; ++k) {
     h->ff_busy[k] = 0;
     if (!h->side[k]) continue;
@@ -1667,7 +1706,7 @@ int tb_phase(TbHandle* h) {
 int tb_pipeline_form(TbHandle* h) {
   if (!h) return fail(TB_E_INVAL, "tb_pipeline_form: null handle");
   if (h->kind != TB_ENV_SWING || !h->pipeline) return 0;
-  const int mode = h->marks_on ? 0 : defer_mode(h);
+  const int mode = h->marks_on && defer_mode(h) != 2 ? 0 : defer_mode(h);
   return mode == 2 ? 3 : mode == 1 && h->ff_phases == 1 && !h->ff_sort ? 2 : 1;
 }
 
@@ -1684,6 +1723,7 @@ int tb_mark_record(TbHandle* h, int k, void* stream) {
   if (!h->marks_on) return fail(TB_E_UNSUPPORTED, "tb_mark_record needs tb_mark_enable(h, 1) before the steps it covers (their fast-forwards must be counted)");
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   HIP_TRY(hipStreamIsCapturing(s, &st));
+  if (int rc = run_pool_for_mark(h, s)) return rc;  // (counted among the fast-forwards enqueued before the mark)
   hipLaunchKernelGGL(tb_mark_kernel, dim3(1), dim3(1), 0, s, h->h_marks + k);
   HIP_TRY(hipGetLastError());
   h->mark_in_capture[k] = st == hipStreamCaptureStatusActive;

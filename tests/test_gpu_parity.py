@@ -948,8 +948,9 @@ def test_step_sequence_equals_per_step_calls_and_chunked_gather_views(torch, def
     assert len(shards) == 1 and torch.equal(shards[0][0][0], buf.obs)
 
 
-@pytest.mark.parametrize("kind,n_chunks", [(ENV_SWING, 4), (ENV_SWING, 13), (ENV_TENNIS, 8)])
-def test_progress_marks_release_each_chunk_of_one_graph(torch, kind, n_chunks):
+@pytest.mark.parametrize("kind,n_chunks,defer", [(ENV_SWING, 4, False), (ENV_SWING, 13, False), (ENV_SWING, 4, None), (ENV_SWING, 13, None), (ENV_TENNIS, 8, None)],
+                         ids=["swing-4-slots", "swing-13-slots", "swing-4-pool", "swing-13-pool", "tennis-8"])
+def test_progress_marks_release_each_chunk_of_one_graph(torch, kind, n_chunks, defer):
     """RolloutBuffer.capture_marked: the whole rollout is ONE hipGraph; mark c (tb_mark_record: a counter in
     pinned host memory, bumped by a kernel node behind chunk c's steps; the fast-forwards the chunk is owed are
     counted the same way) tells the host that chunk c's records are final while the graph is still stepping. A copy issued on a
@@ -964,7 +965,8 @@ def test_progress_marks_release_each_chunk_of_one_graph(torch, kind, n_chunks):
     piped = kind == ENV_SWING
     ref_env = BatchedEnv(kind, n, device="cuda:0", seed=8, track_terminal_obs=False, pipeline=piped)
     ref = RolloutBuffer(kind, T, n, "cuda:0").bind(ref_env)
-    env = BatchedEnv(kind, n, device="cuda:0", seed=8, track_terminal_obs=False, pipeline=piped)
+    env = BatchedEnv(kind, n, device="cuda:0", seed=8, track_terminal_obs=False, pipeline=piped, options=dict(ff_defer=defer))
+    assert env.pipeline_form() == ("none" if not piped else "slots" if defer is False else "pool")
     buf = RolloutBuffer(kind, T, n, "cuda:0").bind(env)
     ref.actions.copy_(acts); buf.actions.copy_(acts)
     main, side = torch.cuda.Stream(), torch.cuda.Stream()
@@ -1134,7 +1136,7 @@ def test_set_pipeline_failure_is_all_or_nothing(torch):
 
 def test_pipeline_form_follows_size_flags_and_marks(torch):
     """tb_pipeline_form: what TbOptions.ff_defer = 0 (auto) resolves to -- every episode end into the pool up to 16384 envs, the
-    stragglers only above that with racket<->court contact, plain slots otherwise and whenever progress marks are on"""
+    stragglers only above that with racket<->court contact, plain slots otherwise"""
     from tennisbot_rl_amd.stepper import BatchedEnv
     rgp = default_params(flags=F_DEFAULT | F_RACKET_GROUND)
     cases = [(ENV_SWING, 1000, None, {}, True, "pool"), (ENV_SWING, 16384, rgp, {}, True, "pool"), (ENV_SWING, 16385, None, {}, True, "slots"),
@@ -1144,11 +1146,11 @@ def test_pipeline_form_follows_size_flags_and_marks(torch):
     for kind, n, p, opts, piped, want in cases:
         env = BatchedEnv(kind, n, seed=1, params=p, pipeline=piped, track_terminal_obs=False, options=opts)
         assert env.pipeline_form() == want, (kind, n, opts, piped, env.pipeline_form(), want)
-        if want == "pool":
+        if want in ("pool", "slots+pool"):  # a mark promises final steps: stragglers are not deferred past it; the pool form runs at each mark
             assert env.L.tb_mark_enable(env._h, 1) == 0
-            assert env.pipeline_form() == "slots"
+            assert env.pipeline_form() == ("pool" if want == "pool" else "slots")
             assert env.L.tb_mark_enable(env._h, 0) == 0
-            assert env.pipeline_form() == "pool"
+            assert env.pipeline_form() == want
         env.close()
 
 
