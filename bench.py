@@ -237,6 +237,18 @@ class Rollouts:
         return time.perf_counter() - t0, ev0.elapsed_time(ev1) * 1e-3
 
 
+def timed_pipeline_form(env, marked):
+    """tb_pipeline_form of the graph that was timed: a marked graph (chunked exchange) was captured with progress marks enabled, and
+    the library's automatic choice differs there"""
+    if not marked:
+        return env.pipeline_form()
+    env.mark_enable(True)
+    try:
+        return env.pipeline_form()
+    finally:
+        env.mark_enable(False)
+
+
 def init_distributed(torch, dev, world, rehearsal=False, force_collective=False):
     """One process group per run: RCCL ("nccl") over xGMI. Returns None, or -- SURVEY.md 8e's fallback, labelled, never silent -- the
     reason why RCCL cannot be used on this node: the ranks then step their shards as replicas (no rollout exchange) and only
@@ -678,7 +690,7 @@ def main():
                 + (" + Magnus k=%g, spin<=%g rad/s (extension, not in the reference)" % (args.magnus, args.spin_max) if (args.magnus or args.spin_max) else ""),
                 T_roll, "%d episodes" % (T_roll // 26) if kind == ENV_SWING else "steady state",
                 {"none": "", "slots": ", one fast-forward kernel per episode end on a side stream", "slots+pool": ", one fast-forward kernel per episode end on a side stream (stragglers deferred to the join)",
-                 "pool": ", episode ends parked and run to their end by ONE fast-forward launch at %s" % ("the end of each exchanged chunk, on a side stream" if R.chunks > 1 and not picked_single else "the join")}[R.env.pipeline_form()], ", one hipGraph replay per rollout" if R.graph is not None else ", steps issued from the host",
+                 "pool": ", episode ends parked and run to their end by ONE fast-forward launch at %s" % ("the end of each exchanged chunk, on a side stream" if R.chunks > 1 and not picked_single else "the join")}[timed_pipeline_form(R.env, R.chunks > 1 and not picked_single)], ", one hipGraph replay per rollout" if R.graph is not None else ", steps issued from the host",
                 gather_note),
                 "envs_per_gpu": N, "global_envs": world * N, "parallelism": "env-sharded x%d" % world},
             "substeps_per_s": timed_substeps / wall_max,

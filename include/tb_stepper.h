@@ -185,9 +185,10 @@ typedef struct TbOptions {
                              * substeps moves on to the pool. -1: off. 0 = auto: 2 up to 16384 envs (4096 envs: 679 -> 871 M env steps/s; with
                              * racket<->court contact 92 -> 115-127 M), above that 1 with TB_F_RACKET_GROUND, else off (large batches run their
                              * fast-forwards beside the steps, in phases). Results do not change; terminal rewards are complete after the join,
-                             * as with every pipelined path. Progress marks (a mark promises final steps): form 2 gives the episodes parked since the
-                             * previous mark their launch at tb_mark_record, on a side stream; form 1 is not used while marks are enabled. Neither
-                             * is used for steps that ask for terminal-observation / substep outputs. */
+                             * as with every pipelined path. Progress marks (a mark promises final steps): an explicit 2 gives the episodes parked since
+                             * the previous mark their launch at tb_mark_record, on a side stream; auto and 1 fall back to one kernel per episode
+                             * end while marks are enabled (measured: faster beside the chunks' all-gathers). Neither form is used for steps that
+                             * ask for terminal-observation / substep outputs. */
   int32_t ff_defer_margin;  /* substeps beyond the estimate before an env is deferred (auto: 16) */
   int32_t policy_slices;    /* tb_policy_rollout: 16-env slices per workgroup, 1 (three waves per 16 envs) or 3 (seven waves per 48 envs) (auto: 1 up to 4096 envs) */
 } TbOptions;

@@ -1191,7 +1191,7 @@ int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const 
   // deferred stragglers: on request (TbOptions.ff_defer > 0), or by default with racket<->court contact, whose resting stacks run
   // to the 800-substep limit. Not with progress marks (a mark promises that the steps before it are FINAL), not with late-written
   // terminal observations / substep counts (the pool keeps one destination per record: the reward's)
-  const bool defer = h->d_pool && phases == 1 && h->phase_valid && !sort && !h->marks_on && !term && !substeps && defer_mode(h) == 1;
+  const bool defer = h->d_pool && phases == 1 && h->phase_valid && !sort && !term && !substeps && defer_mode(h) == 1;
   if (phases > 1) HIP_TRY(hipMemsetAsync(h->d_ff_count[slot], 0, 2 * sizeof(int), side));
   for (int ph = 0; ph < phases; ++ph) {
     KArgs k = a;
@@ -1315,9 +1315,13 @@ int run_pool_for_mark(TbHandle* h, hipStream_t s) {
 // single list): 4096 envs, same box, 679 -> 871 M env steps/s (1024: 160 -> 225 M, 8192: 1.30 -> 1.49 G, 16384: 2.58 -> 2.63 G, 32768:
 // 4.80 -> 4.26 G; racket<->court contact at 4096 envs: 92 -> 115-127 M). Above that: 1 (stragglers only) with racket<->court contact up
 // to the pool's size limit, else 0 -- large batches run their fast-forwards beside the steps, in phases.
+// With progress marks on, the automatic choice stays with one kernel per episode end: a graph of 8 marked chunks whose chunks are
+// all-gathered beside it (one rank, 4096 envs, same box) replays in 6.3 ms that way and in 6.6-7.1 ms with the pool run at each mark
+// (ff_defer = 2 asks for that); form 1 never runs under marks (a mark promises final steps).
 int defer_mode(const TbHandle* h) {
   if (!h->d_pool || h->opt.ff_defer < 0) return 0;
-  if (h->opt.ff_defer > 0) return h->opt.ff_defer;
+  if (h->opt.ff_defer > 0) return h->marks_on && h->opt.ff_defer == 1 ? 0 : h->opt.ff_defer;
+  if (h->marks_on) return 0;
   if (h->n <= 16384) return 2;
   return (h->kp.flags & TB_F_RACKET_GROUND) ? 1 : 0;
 }
@@ -1706,7 +1710,7 @@ int tb_phase(TbHandle* h) {
 int tb_pipeline_form(TbHandle* h) {
   if (!h) return fail(TB_E_INVAL, "tb_pipeline_form: null handle");
   if (h->kind != TB_ENV_SWING || !h->pipeline) return 0;
-  const int mode = h->marks_on && defer_mode(h) != 2 ? 0 : defer_mode(h);
+  const int mode = defer_mode(h);
   return mode == 2 ? 3 : mode == 1 && h->ff_phases == 1 && !h->ff_sort ? 2 : 1;
 }
 

@@ -948,7 +948,7 @@ def test_step_sequence_equals_per_step_calls_and_chunked_gather_views(torch, def
     assert len(shards) == 1 and torch.equal(shards[0][0][0], buf.obs)
 
 
-@pytest.mark.parametrize("kind,n_chunks,defer", [(ENV_SWING, 4, False), (ENV_SWING, 13, False), (ENV_SWING, 4, None), (ENV_SWING, 13, None), (ENV_TENNIS, 8, None)],
+@pytest.mark.parametrize("kind,n_chunks,defer", [(ENV_SWING, 4, False), (ENV_SWING, 13, False), (ENV_SWING, 4, "all"), (ENV_SWING, 13, "all"), (ENV_TENNIS, 8, None)],
                          ids=["swing-4-slots", "swing-13-slots", "swing-4-pool", "swing-13-pool", "tennis-8"])
 def test_progress_marks_release_each_chunk_of_one_graph(torch, kind, n_chunks, defer):
     """RolloutBuffer.capture_marked: the whole rollout is ONE hipGraph; mark c (tb_mark_record: a counter in
@@ -1146,9 +1146,9 @@ def test_pipeline_form_follows_size_flags_and_marks(torch):
     for kind, n, p, opts, piped, want in cases:
         env = BatchedEnv(kind, n, seed=1, params=p, pipeline=piped, track_terminal_obs=False, options=opts)
         assert env.pipeline_form() == want, (kind, n, opts, piped, env.pipeline_form(), want)
-        if want in ("pool", "slots+pool"):  # a mark promises final steps: stragglers are not deferred past it; the pool form runs at each mark
+        if want in ("pool", "slots+pool"):  # a mark promises final steps: nothing is deferred past it unless the pool form was asked for (it runs at each mark)
             assert env.L.tb_mark_enable(env._h, 1) == 0
-            assert env.pipeline_form() == ("pool" if want == "pool" else "slots")
+            assert env.pipeline_form() == ("pool" if opts.get("ff_defer") == "all" else "slots")
             assert env.L.tb_mark_enable(env._h, 0) == 0
             assert env.pipeline_form() == want
         env.close()
