@@ -1065,6 +1065,7 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
     // same quaternion: done together, two per packed instruction
     vec3 l0;
     rotate_inv2(rk.q, d0, rk.w, l0, wb0);
+    TB_LANES(2, reach);  // (census: this instantiation's near_racket below is constant false)
     if (__any(reach)) {
       vec3 ql = mk(0.0f, 0.0f, 0.0f);
       float qax = 0.0f;

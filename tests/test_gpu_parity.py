@@ -1134,6 +1134,57 @@ def test_set_pipeline_failure_is_all_or_nothing(torch):
     env.close()
 
 
+@pytest.mark.parametrize("n,options", [(4096, dict(ff_defer=False)), (4096, dict(ff_defer="all")), (1000, dict(ff_defer=True, ff_defer_margin=3)),
+                                       (140000, dict(ff_phases=3)), (140000, dict(ff_phases=2, ff_lanes_per_wave=16))],
+                         ids=["slots", "pool", "stragglers", "big-3-phases", "big-2-phases"])
+def test_fast_forward_with_balls_thrown_at_a_spinning_racket(torch, n, options):
+    """random-action episodes enter the fast-forward with the ball next to the racket and strike it, if at all, in its first substeps.
+    Here every env enters it (step 26) with the ball 0.6-1.3 m OUTSIDE the bounding sphere of a spinning, falling racket, thrown at
+    where the racket will be: most come into reach 5-150 substeps into the loop, a good part strike the racket -- late racket
+    contacts, resting balls that run to the 800-substep limit, lanes that the first phase of the large-batch form hands over
+    long after its start. Rewards, substep counts and the counters bit-exact against the oracle through every form of the
+    fast-forward (its own kernel per episode, the pool, stragglers parked again, the large-batch phases)."""
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    rng = np.random.default_rng(1234 + n)
+    p = default_params()
+    env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=5, params=p, pipeline=True, track_terminal_obs=False, options=options)
+    pf = p.copy(); pf.flags |= F_AUTO_RESET
+    ref = OracleBatch(pf, ENV_SWING, n, seed=5, precision="f32")
+    ref.L.tbo_set_threads(ref.h, 16)
+    q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    rp = np.stack([rng.uniform(8, 10, n), rng.uniform(-2, 2, n), rng.uniform(1.5, 4.0, n)], 1)
+    rv = rng.uniform(-1.5, 1.5, (n, 3))
+    u = rng.normal(size=(n, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    dist = rng.uniform(1.2, 1.9, n)  # the sphere's radius is ~0.6
+    bp = rp + u * dist[:, None]
+    bp[:, 2] = np.maximum(bp[:, 2], 0.3)
+    tof = rng.uniform(0.05, 0.6, n)  # aim at where a racket in free fall will be after `tof` seconds
+    target = rp + rv * tof[:, None] + np.array([0.0, 0.0, -0.5 * 9.81])[None, :] * (tof ** 2)[:, None]
+    bv = (target - bp) / tof[:, None] + np.array([0.0, 0.0, 0.5 * 9.81])[None, :] * tof[:, None] + rng.normal(scale=0.3, size=(n, 3))
+    fields = dict(racket_pos=rp, racket_quat=q, racket_vel=rv, racket_angvel=rng.uniform(-9, 9, (n, 3)), ball_pos=bp, ball_vel=bv,
+                  ball_angvel=rng.uniform(-30, 30, (n, 3)), goal=np.stack([rng.uniform(-11, -4, n), rng.uniform(-4, 4, n)], 1), spawn_pos=(9, 0, 0.6),
+                  init_dist=rng.uniform(8, 20, n), step_count=25)
+    w, d = make_words(ENV_SWING, n, **fields)
+    env.set_state_words(torch.from_numpy(w.view(np.int32)).cuda(), torch.from_numpy(d).cuda()); ref.set_state_words(w, d)
+    assert env.phase() == 25
+    outs = []
+    for t in range(27):  # the step that parks everything, then a whole ordinary episode behind it
+        a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
+        obs, rew, done = env.step(torch.from_numpy(a).cuda())
+        o2, r2, d2, s2 = ref.step(a)
+        same(done.cpu().numpy(), d2, "done %d" % t); same(obs.cpu().numpy(), o2, "obs %d" % t)
+        outs.append((rew, r2))
+        if t == 0:
+            assert d2.all() and 0.2 * n < (s2 > 30).sum()
+    env.flush()
+    for t, (rew, r2) in enumerate(outs):
+        same(rew.cpu().numpy(), r2, "reward %d" % t)
+    got, want = env.counters(), ref.counters()
+    assert list(got.values()) == [int(x) for x in want], (got, want)
+    assert got["racket_ball_contact_substeps"] > n // 20 and got["nonfinite_states"] == 0 and got["lockstep_violations"] == 0
+    env.close()
+
+
 def test_pipeline_form_follows_size_flags_and_marks(torch):
     """tb_pipeline_form: what TbOptions.ff_defer = 0 (auto) resolves to -- every episode end into the pool up to 16384 envs, the
     stragglers only above that with racket<->court contact, plain slots otherwise"""

@@ -20,6 +20,7 @@ def measure(n, T, opts, reps=5, flags=None, kind=None):
     dev = torch.device("cuda", 0)
     env = BatchedEnv(ENV_SWING, n, device=dev, seed=0, params=default_params(flags=F_DEFAULT if flags is None else flags), track_terminal_obs=False, pipeline=kind is None, options=opts)
     buf = RolloutBuffer(ENV_SWING, T, n, dev)
+    torch.manual_seed(0)  # the same actions for every variant: their counters must agree
     buf.actions.uniform_(-1.0, 1.0)
     buf.bind(env)
     env.reset()
