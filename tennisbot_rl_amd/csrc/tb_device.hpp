@@ -1123,7 +1123,7 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
   if (__any(!(zlow >= P.static_top + 1.0e-3f))) {
     near_g = near_ground(P, zlow); near_n = near_net(P, b, zlow); near_c = near_goal<KIND>(P, zlow);
   }
-  TB_DIAG_ABLATE_NARROW(near_g); TB_DIAG_ABLATE_NARROW(near_n); TB_DIAG_ABLATE_NARROW(near_c);
+  TB_DIAG_ABLATE_STATICS(near_g); TB_DIAG_ABLATE_STATICS(near_n); TB_DIAG_ABLATE_STATICS(near_c);
   TB_LANES(6, near_g | near_n | near_c);  // [6] lanes near a static shape, [7] wave-substeps with one
   if (__any(near_g | near_n | near_c)) {
     if (near_g) hg = sphere_vs_box(P, P.ground_half[0], P.ground_half[1], P.ground_half[2], b.p);

@@ -10,7 +10,7 @@
 //   -DTB_DIAG_TRACE          entry / exit real-time of every step-kernel launch into g_diag_trace (tools/diag/r03_cadence_probe.py)
 //   -DTB_DIAG_LANES          lane census of the substep's wave votes into g_diag_lanes[16]
 //                            (tools/diag/diag_lanes.py)
-//   -DTB_DIAG_NO_ANGULAR / _NO_ORIENT / _NO_NARROW
+//   -DTB_DIAG_NO_ANGULAR / _NO_ORIENT / _NO_NARROW (/ _NO_RACKET / _NO_STATICS: its halves)
 //                            timing-only ablations (tools/diag/diag_substep.py); RESULTS ARE WRONG
 //   -DTB_DIAG_SWEEP_HELPERS=k  helper lanes of the wave-cooperative outline sweep (default 8)
 //
@@ -90,11 +90,22 @@ TB_DEV void diag_flush_stamps(const Stamps& st) {
 // inside a graph replay WITHOUT a profiler serialising them, at two scalar instructions and one atomic per launch
 // (tools/diag/r03_cadence_probe.py)
 #if defined(TB_DIAG_TRACE) || defined(TB_DIAG_STAMPS)
+// (-DTB_DIAG_TRACE alone also logs, per launch, when the LAST workgroup of the launch before it left: every workgroup's first
+//  thread raises g_diag_last_exit on its way out, the next launch's first thread collects it)
 __device__ unsigned long long g_diag_trace[2 * 8192];
+__device__ unsigned long long g_diag_trace_prev_all_out[8192];
+__device__ unsigned long long g_diag_last_exit;
 __device__ unsigned int g_diag_trace_n;
+#ifdef TB_DIAG_TRACE
+#define TB_DIAG_TRACE_ALL_OUT(tr) g_diag_trace_prev_all_out[tr] = atomicExch(&g_diag_last_exit, 0ull)
+#define TB_DIAG_TRACE_LEAVE() do { if (threadIdx.x == 0) atomicMax(&g_diag_last_exit, (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
+#else
+#define TB_DIAG_TRACE_ALL_OUT(tr) do { } while (0)
+#define TB_DIAG_TRACE_LEAVE() do { } while (0)
+#endif
 #define TB_DIAG_TRACE_ENTRY(tr) unsigned int tr = 0xffffffffu; do { if (blockIdx.x == 0 && threadIdx.x == 0) { \
-  tr = atomicAdd(&g_diag_trace_n, 1u) & 8191u; g_diag_trace[2 * tr] = __builtin_amdgcn_s_memrealtime(); } } while (0)
-#define TB_DIAG_TRACE_EXIT(tr) do { if (tr != 0xffffffffu) g_diag_trace[2 * tr + 1] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  tr = atomicAdd(&g_diag_trace_n, 1u) & 8191u; g_diag_trace[2 * tr] = __builtin_amdgcn_s_memrealtime(); TB_DIAG_TRACE_ALL_OUT(tr); } } while (0)
+#define TB_DIAG_TRACE_EXIT(tr) do { if (tr != 0xffffffffu) g_diag_trace[2 * tr + 1] = __builtin_amdgcn_s_memrealtime(); TB_DIAG_TRACE_LEAVE(); } while (0)
 #else
 #define TB_DIAG_TRACE_ENTRY(tr) do { } while (0)
 #define TB_DIAG_TRACE_EXIT(tr) do { } while (0)
@@ -111,10 +122,15 @@ __device__ unsigned int g_diag_trace_n;
 #else
 #define TB_DIAG_ABLATE_ORIENT(w2) do { } while (0)
 #endif
-#ifdef TB_DIAG_NO_NARROW
+#if defined(TB_DIAG_NO_NARROW) || defined(TB_DIAG_NO_RACKET)  // (_NO_RACKET / _NO_STATICS: one half of _NO_NARROW each)
 #define TB_DIAG_ABLATE_NARROW(flag) flag = false
 #else
 #define TB_DIAG_ABLATE_NARROW(flag) do { } while (0)
+#endif
+#if defined(TB_DIAG_NO_NARROW) || defined(TB_DIAG_NO_STATICS)
+#define TB_DIAG_ABLATE_STATICS(flag) flag = false
+#else
+#define TB_DIAG_ABLATE_STATICS(flag) do { } while (0)
 #endif
 
 #endif  // TB_DIAG_HPP_DEVICE
@@ -137,6 +153,13 @@ int tb_diag_read_trace(unsigned long long* out_pairs, int max_pairs, int reset) 
   if (k > max_pairs) k = max_pairs;
   if (k > 0) HIP_TRY(hipMemcpyFromSymbol(out_pairs, HIP_SYMBOL(g_diag_trace), sizeof(unsigned long long) * 2 * (size_t)k));
   if (reset) { unsigned int z = 0; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_diag_trace_n), &z, sizeof z)); }
+  return k;
+}
+// per traced launch: when the last workgroup of the launch BEFORE it left (0: unknown)
+int tb_diag_read_trace_all_out(unsigned long long* out, int max_entries) {
+  HIP_TRY(hipDeviceSynchronize());
+  const int k = max_entries < 8192 ? max_entries : 8192;
+  if (k > 0) HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_trace_prev_all_out), sizeof(unsigned long long) * (size_t)k));
   return k;
 }
 #endif

@@ -21,6 +21,8 @@ L = stepper.load_library()
 if STAMPS:
     L.tb_diag_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 L.tb_diag_read_trace.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+if not STAMPS:
+    L.tb_diag_read_trace_all_out.argtypes = [ctypes.c_void_p, ctypes.c_int]
 dev = torch.device("cuda", 0)
 T = 1040
 out = {}
@@ -42,14 +44,24 @@ for name, kind, flags in (("swing_full", ENV_SWING, F_DEFAULT), ("swing_contact_
     L.tb_diag_read_trace(tr, 8192, 1)
     g.replay(); torch.cuda.synchronize()
     if STAMPS: L.tb_diag_read_stamps(st, 1)
+    allout = (ctypes.c_ulonglong * 8192)()
+    if not STAMPS:
+        L.tb_diag_read_trace_all_out(allout, 8192)
     n = L.tb_diag_read_trace(tr, 8192, 1)
     a = np.array(list(tr[: 2 * n]), dtype=np.float64).reshape(n, 2) * 0.01  # microseconds
-    a = a[np.argsort(a[:, 0])]
+    ao = np.array(list(allout[:n]), dtype=np.float64) * 0.01
+    order = np.argsort(a[:, 0])
+    a, ao = a[order], ao[order]
     dur = a[:, 1] - a[:, 0]
     s2s = np.diff(a[:, 0])
     gap = a[1:, 0] - a[:-1, 1]
     res = {"rate_M": 4096 * T / ts[len(ts) // 2] / 1e6, "launches_traced": int(n), "replay_span_us": float(a[-1, 1] - a[0, 0]),
            "duration_us_mean": float(dur.mean()), "start_to_start_us_mean": float(s2s.mean()), "gap_us_mean": float(gap.mean()), "gap_us_p50": float(np.median(gap))}
+    if not STAMPS:
+        ok = ao[1:] > 0
+        # launch k+1's first thread saw when the LAST workgroup of launch k left: how long the launch's slowest workgroup outlives its first,
+        # and what is left of the gap once every workgroup has gone
+        res.update(last_workgroup_after_first_us_mean=float((ao[1:] - a[:-1, 1])[ok].mean()), gap_after_last_workgroup_us_mean=float((a[1:, 0] - ao[1:])[ok].mean()))
     if STAMPS:
         res.update(shader_clock_GHz=st[8] / max(st[14], 1) * 0.1, kernel_cycles_per_wave=st[8] / max(st[9], 1))
     if kind == ENV_SWING and n == T:

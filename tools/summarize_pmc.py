@@ -50,6 +50,17 @@ def main(d, out):
         ff, nff = per_kernel(os.path.join(d, "%s_FETCH_SIZE_counter_collection.csv" % tag), "FETCH_SIZE", "tb_ff_kernel")
         fw, _ = per_kernel(os.path.join(d, "%s_WRITE_SIZE_counter_collection.csv" % tag), "WRITE_SIZE", "tb_ff_kernel")
         for n in f:
+            if n not in ff and ff and env == "swing" and len(f) == 1:
+                # the pool form (up to 16384 envs): ONE fast-forward launch per rollout over every episode end parked since the last
+                # join, on a grid of its own -- all of its bytes over the episode ends the step launches of the same pass produced
+                episodes = nf[n] / 26.0
+                fb = sum(ff[g] * nff[g] for g in ff) * 1024.0 / fetch_ratio / episodes
+                wb = sum(fw[g] * nff[g] for g in fw) * 1024.0 / write_ratio / episodes
+                res["workloads"]["%s_%d" % (env, n)]["ff_kernel"] = {
+                    "launches": {str(g): nff[g] for g in nff}, "form": "pool: one launch per rollout", "fetch_bytes_per_episode_end": fb, "write_bytes_per_episode_end": wb,
+                    "traffic_bytes_per_env_per_episode_end": (fb + wb) / n, "algorithmic_bytes_per_env_per_episode_end": 140,
+                    "note": "per episode end: reads each parked env's 128-byte record and its 8-byte destination pointer, writes its reward (4 B); the parking step wrote both"}
+                continue
             if n not in ff:
                 continue
             fb = sum(ff[g] * nff[g] for g in ff) / nff[n] * 1024.0 / fetch_ratio   # all phase kernels, per episode end
