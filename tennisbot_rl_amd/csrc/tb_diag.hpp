@@ -13,6 +13,8 @@
 //   -DTB_DIAG_NO_ANGULAR / _NO_ORIENT / _NO_NARROW (/ _NO_RACKET / _NO_STATICS: its halves)
 //                            timing-only ablations (tools/diag/diag_substep.py); RESULTS ARE WRONG
 //   -DTB_DIAG_SWEEP_HELPERS=k  helper lanes of the wave-cooperative outline sweep (default 8)
+//   -DTB_DIAG_LDS_PAD        (host side, tb_stepper.hip dyn_lds) pad every step launch's dynamic LDS by $TB_DIAG_LDS_PAD bytes:
+//                            fewer workgroups per CU (tools/diag/r03_occupancy_probe.py)
 //
 // Included twice by design: once near the top of tb_device.hpp (device side, inside namespace tb)
 // and once at the end of tb_stepper.hip with TB_DIAG_HOST_SECTION defined (the C entry points

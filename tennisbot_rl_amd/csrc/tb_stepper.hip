@@ -1110,7 +1110,14 @@ namespace {
 int words_of(int kind) { return kind == TB_ENV_SWING ? TB_SWING_WORDS : TB_TENNIS_WORDS; }
 
 // dynamic LDS of a stepping kernel (see init_manifold): per lane, the static rows unless in registers + the cache if RG
-size_t dyn_lds(bool regrows, bool rg, unsigned lanes) { return sizeof(float) * lanes * ((regrows ? 0 : TB_ROWS_LDS) + (rg ? TB_MANI_LDS : 0)); }
+size_t dyn_lds(bool regrows, bool rg, unsigned lanes) {
+#ifdef TB_DIAG_LDS_PAD  // (tools/diag/r03_occupancy_probe.py: fewer workgroups per CU through a padded dynamic LDS request)
+  static const size_t pad = getenv("TB_DIAG_LDS_PAD") ? (size_t)atol(getenv("TB_DIAG_LDS_PAD")) : 0;
+#else
+  constexpr size_t pad = 0;
+#endif
+  return pad + sizeof(float) * lanes * ((regrows ? 0 : TB_ROWS_LDS) + (rg ? TB_MANI_LDS : 0));
+}
 
 int ensure_marks(TbHandle* h) {
   if (h->h_marks) return TB_OK;

@@ -1,17 +1,23 @@
 #!/usr/bin/env python3
 """Does an HBM-bound step kernel keep its rate when it only gets one or two wave slots per SIMD (the room a co-resident fast-forward
-leaves)? EXPERIMENT build: TB_EXP_LDS_PAD pads every step launch's dynamic LDS so that fewer workgroups fit a CU. Tennisbot, 1 M envs,
+leaves)? Diagnostic build (-DTB_DIAG_LDS_PAD): the environment variable TB_DIAG_LDS_PAD pads every step launch's dynamic LDS so that fewer workgroups fit a CU. Tennisbot, 1 M envs,
 64-thread workgroups, replayed 104-step graphs. usage: r03_occupancy_probe.py  (run on the GPU box; spawns itself per setting)"""
 import json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 if len(sys.argv) == 1:
     for pad, label in ((0, "unrestricted"), (19000, "8 waves per CU = 2 per SIMD"), (39000, "4 waves per CU = 1 per SIMD"), (0, "unrestricted")):
-        env = dict(os.environ, TB_EXP_LDS_PAD=str(pad))
+        env = dict(os.environ, TB_DIAG_LDS_PAD=str(pad))
         r = subprocess.run([sys.executable, __file__, label], env=env, capture_output=True, text=True)
         print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-500:], flush=True)
     sys.exit(0)
 import torch
+from tennisbot_rl_amd import stepper
+from tennisbot_rl_amd.build import HIPCC_FLAGS, SOURCES, hipcc
+lib = "/tmp/libtb_ldspad.so"
+if not os.path.exists(lib):
+    subprocess.check_call([hipcc()] + HIPCC_FLAGS + ["-DTB_DIAG_LDS_PAD", "-o", lib] + SOURCES)
+stepper.use_library(lib)
 from tennisbot_rl_amd.params import ENV_TENNIS, default_params
 from tennisbot_rl_amd.rollout import RolloutBuffer
 from tennisbot_rl_amd.stepper import BatchedEnv
@@ -27,4 +33,4 @@ ts = []
 for k in range(5):
     torch.cuda.synchronize(); t0 = time.perf_counter(); g.replay(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
 ts.sort()
-print(json.dumps({"setting": sys.argv[1], "lds_pad": os.environ.get("TB_EXP_LDS_PAD"), "rate_G": n * T / ts[2] / 1e9, "us_per_step": ts[2] / T * 1e6, "TB_per_s": 263 * n / (ts[2] / T) / 1e12}))
+print(json.dumps({"setting": sys.argv[1], "lds_pad": os.environ.get("TB_DIAG_LDS_PAD"), "rate_G": n * T / ts[2] / 1e9, "us_per_step": ts[2] / T * 1e6, "TB_per_s": 263 * n / (ts[2] / T) / 1e12}))
