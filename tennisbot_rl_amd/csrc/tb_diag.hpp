@@ -13,7 +13,7 @@
 //   -DTB_DIAG_NO_ANGULAR / _NO_ORIENT / _NO_NARROW (/ _NO_RACKET / _NO_STATICS: its halves)
 //                            timing-only ablations (tools/diag/diag_substep.py); RESULTS ARE WRONG
 //   -DTB_DIAG_SWEEP_HELPERS=k  helper lanes of the wave-cooperative outline sweep (default 8)
-//   -DTB_DIAG_LDS_PAD        (host side, tb_stepper.hip dyn_lds) pad every step launch's dynamic LDS by $TB_DIAG_LDS_PAD bytes:
+//   -DTB_DIAG_LDS_PAD        (host side, tb_stepper.hip dyn_lds) pad every step launch's dynamic LDS by tb_diag_set_lds_pad(bytes):
 //                            fewer workgroups per CU (tools/diag/r03_occupancy_probe.py)
 //
 // Included twice by design: once near the top of tb_device.hpp (device side, inside namespace tb)
@@ -164,6 +164,9 @@ int tb_diag_read_trace_all_out(unsigned long long* out, int max_entries) {
   if (k > 0) HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_trace_prev_all_out), sizeof(unsigned long long) * (size_t)k));
   return k;
 }
+#endif
+#ifdef TB_DIAG_LDS_PAD
+int tb_diag_set_lds_pad(long bytes) { g_diag_lds_pad = bytes > 0 ? (size_t)bytes : 0; return TB_OK; }
 #endif
 #ifdef TB_DIAG_LANES
 int tb_diag_read_lanes(unsigned long long* out16, int reset) {

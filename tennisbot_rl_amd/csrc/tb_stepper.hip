@@ -1110,14 +1110,12 @@ namespace {
 int words_of(int kind) { return kind == TB_ENV_SWING ? TB_SWING_WORDS : TB_TENNIS_WORDS; }
 
 // dynamic LDS of a stepping kernel (see init_manifold): per lane, the static rows unless in registers + the cache if RG
-size_t dyn_lds(bool regrows, bool rg, unsigned lanes) {
-#ifdef TB_DIAG_LDS_PAD  // (tools/diag/r03_occupancy_probe.py: fewer workgroups per CU through a padded dynamic LDS request)
-  static const size_t pad = getenv("TB_DIAG_LDS_PAD") ? (size_t)atol(getenv("TB_DIAG_LDS_PAD")) : 0;
+#ifdef TB_DIAG_LDS_PAD  // (tools/diag/r03_occupancy_probe.py: fewer workgroups per CU through a padded dynamic LDS request; tb_diag_set_lds_pad)
+size_t g_diag_lds_pad = 0;
 #else
-  constexpr size_t pad = 0;
+constexpr size_t g_diag_lds_pad = 0;
 #endif
-  return pad + sizeof(float) * lanes * ((regrows ? 0 : TB_ROWS_LDS) + (rg ? TB_MANI_LDS : 0));
-}
+size_t dyn_lds(bool regrows, bool rg, unsigned lanes) { return g_diag_lds_pad + sizeof(float) * lanes * ((regrows ? 0 : TB_ROWS_LDS) + (rg ? TB_MANI_LDS : 0)); }
 
 int ensure_marks(TbHandle* h) {
   if (h->h_marks) return TB_OK;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Does an HBM-bound step kernel keep its rate when it only gets one or two wave slots per SIMD (the room a co-resident fast-forward
-leaves)? Diagnostic build (-DTB_DIAG_LDS_PAD): the environment variable TB_DIAG_LDS_PAD pads every step launch's dynamic LDS so that fewer workgroups fit a CU. Tennisbot, 1 M envs,
+leaves)? Diagnostic build (-DTB_DIAG_LDS_PAD): tb_diag_set_lds_pad(bytes) pads every step launch's dynamic LDS so that fewer workgroups fit a CU. Tennisbot, 1 M envs,
 64-thread workgroups, replayed 104-step graphs. usage: r03_occupancy_probe.py  (run on the GPU box; spawns itself per setting)"""
 import json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,6 +18,7 @@ lib = "/tmp/libtb_ldspad.so"
 if not os.path.exists(lib):
     subprocess.check_call([hipcc()] + HIPCC_FLAGS + ["-DTB_DIAG_LDS_PAD", "-o", lib] + SOURCES)
 stepper.use_library(lib)
+stepper.load_library().tb_diag_set_lds_pad(int(os.environ.get("TB_DIAG_LDS_PAD", "0")))
 from tennisbot_rl_amd.params import ENV_TENNIS, default_params
 from tennisbot_rl_amd.rollout import RolloutBuffer
 from tennisbot_rl_amd.stepper import BatchedEnv
