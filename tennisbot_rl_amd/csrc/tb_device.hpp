@@ -1140,6 +1140,7 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
   TB_LANES(8, bits != 0);     // [8] lanes with a contact, [9] wave-substeps with one
   TB_LANES(10, hr.hit);       // [10] lanes with a racket contact, [11] wave-substeps with one
   if (__any(bits != 0)) {
+    TB_DIAG_ADD_LEADER(6, 1);  // wave-substeps that enter the solver
     if (bits) {  // only lanes that touch something enter the solver
       const KParams& PC = COLD ? *reinterpret_cast<const KParams*>(hull + TB_HULL_KP) : P;
       Rows<RG> R;
