@@ -237,6 +237,14 @@ class Rollouts:
         return time.perf_counter() - t0, ev0.elapsed_time(ev1) * 1e-3
 
 
+def pick_exchange_form(chunked_wall, chunked_ok, single_wall, single_ok):
+    """which of the two timed exchange forms `value` reports: the faster one whose gathered shards checked out (both were run over the
+    same K steps between the same barriers; the max-over-ranks times are identical on every rank, so every rank answers alike)"""
+    if single_ok and (not chunked_ok or single_wall < chunked_wall):
+        return "single_all_gather"
+    return "chunked"
+
+
 def timed_pipeline_form(env, marked):
     """tb_pipeline_form of the graph that was timed: a marked graph (chunked exchange) was captured with progress marks enabled, and
     the library's automatic choice differs there"""
@@ -636,7 +644,7 @@ def main():
     # Two complete forms of the same job were timed the same way (K steps each, barrier + synchronize on both sides, max over ranks):
     # `value` is the FASTER one on this node, named in config.workload and in exchange.timed_form; the other stays beside it.
     # (All ranks hold the same two max-over-ranks times, so all of them pick the same form.)
-    picked_single = single is not None and bool(ok1.item() > 0.5) and float(w1_t[0].item()) < float(wall_t.item())
+    picked_single = single is not None and pick_exchange_form(float(wall_t.item()), gather_ok, float(w1_t[0].item()), bool(ok1.item() > 0.5)) == "single_all_gather"
     if picked_single:
         chunked = {"form": exch["form"], "value": world * N * steps_timed / float(wall_t.item()), "ms_per_rollout": float(wall_t.item()) / rollouts * 1e3,
                    "rollouts_timed": rollouts, "gather_ok": gather_ok}

@@ -126,6 +126,19 @@ def test_bench_launches_its_own_ranks_on_one_gpu():
     assert "cpu_baseline" not in d and "sweep" not in d  # N = 1 only
 
 
+def test_bench_reports_the_faster_valid_exchange_form():
+    """with N > 1 bench.py times the chunked, overlapped exchange and ONE all-gather after the rollout and reports the faster as `value`
+    -- never a form whose gathered shards failed their check"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    pick = bench.pick_exchange_form
+    assert pick(7.0, True, 5.5, True) == "single_all_gather" and pick(5.0, True, 5.5, True) == "chunked"
+    assert pick(7.0, True, 5.5, False) == "chunked" and pick(5.0, False, 5.5, True) == "single_all_gather"
+    assert pick(5.0, False, 5.5, False) == "chunked"  # (reported as invalid by the caller)
+
+
 def test_bench_workload_constants_match_the_oracle():
     """what bench.py refuses a value against: the random-action SwingRacket workload's substeps per agent step (whole episodes),
     re-measured here on the CPU oracle; and the reference's own wall-clock record it quotes next to the CPU baseline"""
