@@ -804,7 +804,10 @@ __global__ void __launch_bounds__(TB_FF_SORT_BLOCK) tb_ff_sort_kernel(KArgs A, f
 // (ESC without the extended contact set is also built for four waves per SIMD: 125 VGPRs -- no spills -- and, with the
 //  two-slot static rows of substep<ESC>, 9.5 KB of LDS per wave: 16 waves per CU instead of 12; 1 M envs, same box: 9.3-9.4 ->
 //  10.0 G env steps/s)
-// POOL (small batches, opt-in: TbOptions.ff_defer): DEFERRED STRAGGLERS. A fast-forward kernel lasts as long as its slowest env, and
+// POOL (up to 131 072 envs, TbOptions.ff_defer): THE POOL. Two uses of the same instantiation: (1) the POOL RUN -- whole episodes
+// that the step kernels parked straight into the pool (ff_defer = 2: the automatic choice up to 16 384 envs, see defer_mode), or
+// stragglers that earlier launches moved on to it, finished by ONE launch when the caller joins: A.pool_dst_in gives every record its
+// destination; (2) ff_defer = 1, DEFERRED STRAGGLERS: a fast-forward kernel lasts as long as its slowest env, and
 // at most four of them run at once (one per hardware queue). With random actions that is 370 us for a mean flight of 108 substeps;
 // under a trained policy struck balls fly 300-775 substeps (0.9-2.5 ms per kernel: the PPO collect was bound by it, 229 M env
 // steps/s), and with racket<->court contact a ball at rest on a grounded racket runs to the 800-substep limit at 12-20 us per
