@@ -191,10 +191,6 @@ typedef struct TbOptions {
                              * ask for terminal-observation / substep outputs. */
   int32_t ff_defer_margin;  /* substeps beyond the estimate before an env is deferred (auto: 16) */
   int32_t policy_slices;    /* tb_policy_rollout: 16-env slices per workgroup, 1 (three waves per 16 envs) or 3 (seven waves per 48 envs) (auto: 1 up to 4096 envs) */
-  int32_t kernel_build;     /* the library holds its kernels in two builds, with and without the compiler's packed-fp32 (SLP) vectorisation:
-                             * fewer instructions against fewer registers (tb_stepper.hip, TbAltTable). 1: packed for every launch, 2: unpacked
-                             * for every launch, 3: packed step kernels, unpacked fast-forward / pool / policy kernels; 0 = auto: 3 for
-                             * SwingRacket up to 32768 envs without the extended contact set, else 2. Bit-identical results. */
 } TbOptions;
 
 /* library identity / shape queries (host only, no device touched) */

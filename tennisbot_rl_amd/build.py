@@ -28,35 +28,14 @@ def needs_build():
     return any(os.path.getmtime(f) > t for f in SOURCES + HEADERS)
 
 
-# The product library holds the kernels twice (csrc/tb_stepper.hip, TbAltTable): the source as it stands, and once more without
-# clang's SLP (packed fp32) vectoriser -- two objects from one source, linked into one shared library. A single-command build
-# ([hipcc()] + HIPCC_FLAGS + ["-o", lib] + SOURCES: the diagnostic variants of tools/diag) is the first build alone.
-ALT_FLAGS = ["-fno-slp-vectorize", "-DTB_TU_ALT"]
-
-
-def build_library(force=False, verbose=False, extra_flags=(), output=None):
-    out = output or OUTPUT
-    if output is None and not force and not needs_build():
-        return out
-    compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags) + ["-DTB_DUAL_TU", "-c"]
-    objs = [out + ".packed.o", out + ".unpacked.o"]
-    cmds = [[hipcc()] + compile_flags + ["-o", objs[0]] + SOURCES,
-            [hipcc()] + compile_flags + ALT_FLAGS + ["-o", objs[1]] + SOURCES]
-    procs = []
-    for cmd in cmds:  # (side by side: each takes ~40 s)
-        if verbose:
-            print(" ".join(cmd))
-        procs.append(subprocess.Popen(cmd))
-    rcs = [p.wait() for p in procs]
-    if any(rcs):
-        raise subprocess.CalledProcessError(max(rcs), cmds[rcs.index(max(rcs))])
-    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
+def build_library(force=False, verbose=False, extra_flags=()):
+    if not force and not needs_build():
+        return OUTPUT
+    cmd = [hipcc()] + HIPCC_FLAGS + list(extra_flags) + ["-o", OUTPUT] + SOURCES
     if verbose:
-        print(" ".join(link))
-    subprocess.check_call(link)
-    for o in objs:
-        os.remove(o)
-    return out
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUTPUT
 
 
 if __name__ == "__main__":

@@ -959,12 +959,6 @@ __global__ void __launch_bounds__(64) tb_diag_idle_kernel(unsigned long long tic
 
 // ------------------------------------------------------------------------------------------
 // host side
-#ifdef TB_TU_ALT
-}  // namespace
-extern "C" int tb_internal_fail(int code, const char* what);  // (the first translation unit's: tb_last_error reads its buffer)
-namespace {
-int fail(int code, const char* what) { return tb_internal_fail(code, what); }
-#else
 thread_local char g_err[512] = "";
 
 int fail(int code, const char* what) {
@@ -972,7 +966,6 @@ int fail(int code, const char* what) {
   else snprintf(g_err, sizeof g_err, "%s", what);
   return code;
 }
-#endif
 #define HIP_TRY(expr)                                              \
   do {                                                             \
     hipError_t _e = (expr);                                        \
@@ -1115,44 +1108,7 @@ struct TbHandle {
   int mark_in_capture[TB_MAX_MARKS];
 };
 
-// THE KERNELS ARE BUILT TWICE (tennisbot_rl_amd/build.py, -DTB_DUAL_TU): this file as it stands, and once more with
-// -fno-slp-vectorize -DTB_TU_ALT -- the same kernels and the same launch code without clang's SLP vectoriser. Packed fp32
-// (v_pk_mul / v_pk_fma, two IEEE operations per instruction: the same bits) halves the instructions of the vector arithmetic
-// it catches, at the price of operand pairs that must sit in aligned register pairs: +30-40 VGPRs and a v_mov per operand.
-// Small batches are latency-bound -- one wave per SIMD, fewer instructions win (SwingRacket 4096 envs: 871 M packed, 855 M
-// not; 32768: 4.57 against 4.13 G) -- large ones and everything with long loops are bound by registers and issue slots (1 M envs:
-// SwingRacket 9.8 -> 10.6 G, Tennisbot 18.7 -> 19.7 G; racket<->court contact +5 %; PPO collect under a trained policy +5 %;
-// the large-batch step kernels drop from 119 / 118 to 100 / 94 VGPRs). Every launch of a handle goes to one build or the other
-// (kernel_build, TbOptions.kernel_build); results are bit-identical either way (the lockstep tests run both).
-struct TbAltTable {
-  int (*launch_step)(void* h, int T, const float* actions, float* obs, float* reward, uint8_t* done, float* term, int32_t* substeps, hipStream_t s,
-                     const void* pol, bool lean_multi);
-  int (*launch_policy_rollout)(void* h, int T, const void* pol, float* obs, float* reward, uint8_t* done, const size_t* st, hipStream_t s);
-  int (*launch_ff)(void* h, int slot, const void* kargs, const void* term, const void* substeps, hipStream_t s);
-  int (*run_pool)(void* h, hipStream_t q);
-};
-#if defined(TB_DUAL_TU) && !defined(TB_TU_ALT)
-extern "C" const TbAltTable tb_alt_table;  // (defined by the second translation unit)
-#endif
-
 namespace {
-
-// which build serves a launch of this handle: 0 = this translation unit's (packed), 1 = the other's
-enum { TB_LAUNCH_STEPS = 0, TB_LAUNCH_FF = 1, TB_LAUNCH_POLICY = 2 };
-bool use_alt(const TbHandle* h, int what) {
-#if defined(TB_DUAL_TU) && !defined(TB_TU_ALT)
-  if (h->opt.kernel_build == 1) return false;
-  if (h->opt.kernel_build == 2) return true;
-  if (h->opt.kernel_build == 3) return what != TB_LAUNCH_STEPS;
-  // auto: the fast-forward / pool kernels and the fused policy kernels always (loops: registers and issue slots count); the step
-  // kernels unless the batch is a small SwingRacket one without the extended contact set (latency-bound: see above)
-  if (what != TB_LAUNCH_STEPS) return true;
-  return h->kind == TB_ENV_TENNIS || h->n > 32768 || (h->kp.flags & TB_F_RACKET_GROUND) || h->kp.roll_racket > 0.0f || h->kp.roll_court > 0.0f || h->kp.roll_goal > 0.0f;
-#else
-  (void)h; (void)what;
-  return false;
-#endif
-}
 
 int words_of(int kind) { return kind == TB_ENV_SWING ? TB_SWING_WORDS : TB_TENNIS_WORDS; }
 
@@ -1218,9 +1174,6 @@ bool extended_contacts(const KParams& kp) {
 //  second queue: 79 of 82 fast-forwards in line behind each other, 209 M env steps/s instead of 700.)
 int defer_mode(const TbHandle* h);
 int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const void* substeps, hipStream_t s) {
-#if defined(TB_DUAL_TU) && !defined(TB_TU_ALT)
-  if (use_alt(h, TB_LAUNCH_FF)) return tb_alt_table.launch_ff(h, slot, &a_in, term, substeps, s);
-#endif
   KArgs a = a_in;
   hipStream_t side = h->side[slot];
   // lockstep episodes (every env parks in the same launch): sorted, or a few envs per wave; without the host knowing the
@@ -1296,9 +1249,6 @@ int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const 
 // -- regions [pool_run_upto, pool_episodes): the host knows how many records -- or, without any, the stragglers that the episodes'
 // own fast-forward kernels moved on to it (ff_defer = 1: their number is the pool's device counter)
 int run_pool(TbHandle* h, hipStream_t q) {
-#if defined(TB_DUAL_TU) && !defined(TB_TU_ALT)
-  if (use_alt(h, TB_LAUNCH_FF)) return tb_alt_table.run_pool(h, q);
-#endif
   KArgs k = base_args(h);
   const bool rg = extended_contacts(h->kp);
   k.ff_rec = h->d_pool; k.ff_flag = nullptr; k.ff_src_count = h->d_pool_count; k.ff_lanes = 64;
@@ -1412,9 +1362,6 @@ struct PolicyIO {  // non-null weights = fused policy step
 // pipelined kernel (no in-kernel fast-forward) can run several steps per launch too.
 int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* reward, uint8_t* done, float* term, int32_t* substeps, hipStream_t s,
                 const PolicyIO* pol = nullptr, bool lean_multi = false) {
-#if defined(TB_DUAL_TU) && !defined(TB_TU_ALT)
-  if (use_alt(h, pol ? TB_LAUNCH_POLICY : TB_LAUNCH_STEPS)) return tb_alt_table.launch_step(h, T, actions, obs, reward, done, term, substeps, s, pol, lean_multi);
-#endif
   KArgs a = base_args(h);
   if (pol) {
     a.pol_weights = pol->weights; a.pol_obs = pol->obs_in; a.pol_actions = pol->actions; a.pol_raw = pol->raw; a.pol_logp = pol->logp;
@@ -1488,9 +1435,6 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
 // one launch of tb_policy_rollout_kernel over T steps; SwingRacket: T ends where the episode does
 int launch_policy_rollout(TbHandle* h, int T, const PolicyIO& pol, float* obs, float* reward, uint8_t* done, const size_t* st /*element strides*/,
                           hipStream_t s) {
-#if defined(TB_DUAL_TU) && !defined(TB_TU_ALT)
-  if (use_alt(h, TB_LAUNCH_POLICY)) return tb_alt_table.launch_policy_rollout(h, T, &pol, obs, reward, done, st, s);
-#endif
   KArgs a = base_args(h);
   a.pol_weights = pol.weights; a.pol_obs = pol.obs_in; a.pol_actions = pol.actions; a.pol_raw = pol.raw; a.pol_logp = pol.logp;
   a.pol_value = pol.value; a.pol_seed = pol.seed; a.pol_deterministic = pol.deterministic;
@@ -1534,28 +1478,8 @@ int launch_policy_rollout(TbHandle* h, int T, const PolicyIO& pol, float* obs, f
 
 }  // namespace
 
-#ifdef TB_TU_ALT
-// the second translation unit exports nothing but its launch functions (see TbAltTable)
-namespace {
-int alt_launch_step(void* h, int T, const float* actions, float* obs, float* reward, uint8_t* done, float* term, int32_t* substeps, hipStream_t s, const void* pol, bool lean_multi) {
-  return launch_step(static_cast<TbHandle*>(h), T, actions, obs, reward, done, term, substeps, s, static_cast<const PolicyIO*>(pol), lean_multi);
-}
-int alt_launch_policy_rollout(void* h, int T, const void* pol, float* obs, float* reward, uint8_t* done, const size_t* st, hipStream_t s) {
-  return launch_policy_rollout(static_cast<TbHandle*>(h), T, *static_cast<const PolicyIO*>(pol), obs, reward, done, st, s);
-}
-int alt_launch_ff(void* h, int slot, const void* kargs, const void* term, const void* substeps, hipStream_t s) {
-  return launch_ff(static_cast<TbHandle*>(h), slot, *static_cast<const KArgs*>(kargs), term, substeps, s);
-}
-int alt_run_pool(void* h, hipStream_t q) { return run_pool(static_cast<TbHandle*>(h), q); }
-}  // namespace
-#ifndef __HIP_DEVICE_COMPILE__  // (host data: the device pass must not emit a table of host functions)
-extern "C" const TbAltTable tb_alt_table = {alt_launch_step, alt_launch_policy_rollout, alt_launch_ff, alt_run_pool};
-#endif
-#else
-
 extern "C" {
 
-int tb_internal_fail(int code, const char* what) { return fail(code, what); }  // (not in the header: the second translation unit's errors)
 int tb_abi_version(void) { return TB_ABI_VERSION; }
 int tb_obs_dim(int k) { return k == TB_ENV_SWING ? TB_SWING_OBS_DIM : k == TB_ENV_TENNIS ? TB_TENNIS_OBS_DIM : TB_E_INVAL; }
 int tb_act_dim(int k) { return k == TB_ENV_SWING ? TB_SWING_ACT_DIM : k == TB_ENV_TENNIS ? TB_TENNIS_ACT_DIM : TB_E_INVAL; }
@@ -1578,7 +1502,6 @@ int tb_create(const TbParams* params, const TbOptions* options, int env_kind, in
     if (opt.ff_phases < 0 || opt.ff_phases > 3) return fail(TB_E_INVAL, "tb_create: TbOptions.ff_phases must be in [0, 3]");
     if (opt.policy_slices != 0 && opt.policy_slices != 1 && opt.policy_slices != 3) return fail(TB_E_INVAL, "tb_create: TbOptions.policy_slices must be 0, 1 or 3");
     if (opt.ff_defer < -1 || opt.ff_defer > 2) return fail(TB_E_INVAL, "tb_create: TbOptions.ff_defer must be -1, 0, 1 or 2");
-    if (opt.kernel_build < 0 || opt.kernel_build > 3) return fail(TB_E_INVAL, "tb_create: TbOptions.kernel_build must be 0, 1, 2 or 3");
     if (opt.ff_defer_margin < 0 || opt.ff_defer_margin > 800) return fail(TB_E_INVAL, "tb_create: TbOptions.ff_defer_margin must be in [0, 800]");
   }
   int ndev = 0;
@@ -2100,4 +2023,3 @@ int tb_counters_reset(TbHandle* h, void* stream) {
 }
 
 }  // extern "C"
-#endif  // TB_TU_ALT

@@ -1185,42 +1185,6 @@ def test_fast_forward_with_balls_thrown_at_a_spinning_racket(torch, n, options):
     env.close()
 
 
-@pytest.mark.parametrize("kind,n,build,flags", [(ENV_SWING, 4097, 1, F_DEFAULT), (ENV_SWING, 4097, 2, F_DEFAULT), (ENV_SWING, 4097, 3, F_DEFAULT), (ENV_TENNIS, 1000, 1, F_DEFAULT),
-                                                (ENV_TENNIS, 1000, 2, F_DEFAULT), (ENV_SWING, 1000, 1, F_DEFAULT | F_RACKET_GROUND), (ENV_SWING, 1000, 2, F_DEFAULT | F_RACKET_GROUND),
-                                                (ENV_SWING, 140000, 1, F_DEFAULT), (ENV_SWING, 140000, 2, F_DEFAULT), (ENV_TENNIS, 140000, 1, F_DEFAULT)])
-def test_both_builds_of_the_kernels_in_lockstep_with_the_oracle(torch, kind, n, build, flags):
-    """the library holds every kernel twice -- with and without the compiler's packed-fp32 vectorisation (TbOptions.kernel_build; the
-    automatic choice goes by batch size, env and contact set) -- and both must give the oracle's bits: pipelined SwingRacket through an
-    episode end, Tennisbot past its first arrivals, racket<->court contact, small and large-batch instantiations"""
-    from tennisbot_rl_amd.stepper import BatchedEnv
-    p = default_params(flags=flags)
-    piped = kind == ENV_SWING
-    env = BatchedEnv(kind, n, device="cuda:0", seed=17, params=p, pipeline=piped, track_terminal_obs=False, options=dict(kernel_build=build))
-    pf = p.copy(); pf.flags |= F_AUTO_RESET
-    ref = OracleBatch(pf, kind, n, seed=17, precision="f32")
-    ref.L.tbo_set_threads(ref.h, 16)
-    rng = np.random.default_rng(build)
-    same(env.reset().cpu().numpy(), ref.reset(), "reset obs")
-    steps = 30 if kind == ENV_SWING else (160 if n <= 5000 else 60)
-    outs = []
-    for t in range(steps):
-        a = rng.uniform(-1, 1, (n, env.act_dim)).astype(np.float32)
-        obs, rew, done = env.step(torch.from_numpy(a).cuda())
-        o2, r2, d2, s2 = ref.step(a)
-        same(obs.cpu().numpy(), o2, "obs %d" % t); same(done.cpu().numpy(), d2, "done %d" % t)
-        if piped:
-            outs.append((rew, r2))
-        else:
-            same(rew.cpu().numpy(), r2, "reward %d" % t)
-    env.flush()
-    for t, (rew, r2) in enumerate(outs):
-        same(rew.cpu().numpy(), r2, "reward %d" % t)
-    compare_state(env, ref, "final state")
-    got, want = env.counters(), ref.counters()
-    assert list(got.values()) == [int(x) for x in want], (got, want)
-    env.close()
-
-
 def test_pipeline_form_follows_size_flags_and_marks(torch):
     """tb_pipeline_form: what TbOptions.ff_defer = 0 (auto) resolves to -- every episode end into the pool up to 16384 envs, the
     stragglers only above that with racket<->court contact, plain slots otherwise"""

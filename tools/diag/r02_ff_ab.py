@@ -58,7 +58,7 @@ def main():
     if other:
         from tennisbot_rl_amd import stepper
         stepper.use_library(other[0])
-    extra = [x for x in sys.argv[2:] if x.startswith(("-D", "-f", "-m"))]  # (-f... / -m...: compiler flags, e.g. -fno-slp-vectorize, -mllvm ...)
+    extra = [x for x in sys.argv[2:] if x.startswith("-D")]
     if extra:  # extra hipcc flags: build that variant of the library into /tmp and measure it instead (same-box A/B)
         import subprocess
         from tennisbot_rl_amd import stepper
