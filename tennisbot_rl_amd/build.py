@@ -11,7 +11,15 @@ OUTPUT = os.path.join(_HERE, "libtb_stepper.so")
 
 # -ffp-contract=off: the only fused multiply-adds are the explicit __builtin_fmaf calls
 # (DESIGN.md "Arithmetic contract"); IEEE divide / sqrt are hipcc's default.
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+# -fno-slp-vectorize, -amdgpu-sched-strategy=max-ilp: measured, tools/diag/r03_flag_ab.py (profiles/EXPERIMENTS.md, round 3). clang's SLP
+# vectoriser packs pairs of fp32 operations (v_pk_mul / v_pk_fma: the same bits) -- fewer instructions, but operand pairs need
+# aligned register pairs: +30-40 VGPRs per kernel and a v_mov per operand; without it the large-batch step kernels drop from 119 /
+# 118 to 100 / 94 VGPRs and the kernels with loops gain a wave per SIMD. The max-ILP scheduling strategy then orders the unpacked
+# code for a lone wave's latency, which is what small batches are bound by. Same box, M env steps/s, packed / packed+ILP /
+# unpacked / unpacked+ILP: SwingRacket 4096 envs 861 / 815 / 859 / 924, 32768: 4428 / 4544 / 4270 / 5174, 131072: 5777 / 5862 /
+# 7996 / 8239, 1 M: 9779 / 9503 / 10613 / 10797; Tennisbot 4096: 651 / 668 / 655 / 687, 1 M: 19396 / 19581 / 20344 / 20125.
+# Neither flag changes a result: every lockstep test runs on this build.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-fPIC", "-shared"]
 
 
 def hipcc():

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Same-box A/B of compiler flags: two single-translation-unit builds of the library into /tmp (HIPCC_FLAGS + <A> / + <B>), each
+workload in a process of its own per build. usage: r03_flag_ab.py "<flags A>" "<flags B>" [workload ...]   (run on the GPU box)
+e.g. r03_flag_ab.py "" "-fno-slp-vectorize" swing4096 swing1m   -- how the two kernel builds of the product were chosen"""
+import json, os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+WORK = {"swing4096": (0, 4096, 1040, 0), "swing32k": (0, 32768, 1040, 0), "swing128k": (0, 131072, 104, 0), "swing1m": (0, 1048576, 104, 0),
+        "tennis4096": (1, 4096, 1040, 0), "tennis1m": (1, 1048576, 104, 0), "rg4096": (0, 4096, 1040, 1)}
+if len(sys.argv) > 2 and sys.argv[1] == "--child":
+    lib, what = sys.argv[2], sys.argv[3]
+    import torch
+    from tennisbot_rl_amd import stepper
+    stepper.use_library(lib)
+    from tennisbot_rl_amd.params import ENV_SWING, ENV_TENNIS, F_DEFAULT, F_RACKET_GROUND, default_params
+    from tennisbot_rl_amd.rollout import RolloutBuffer
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    dev = torch.device("cuda", 0)
+    k, n, T, rg = WORK[what]
+    kind = ENV_TENNIS if k else ENV_SWING
+    env = BatchedEnv(kind, n, device=dev, seed=0, params=default_params(flags=F_DEFAULT | (F_RACKET_GROUND if rg else 0)), track_terminal_obs=False, pipeline=kind == ENV_SWING)
+    buf = RolloutBuffer(kind, T, n, dev); torch.manual_seed(0); buf.actions.uniform_(-1, 1); buf.bind(env); env.reset()
+    for t in range(T): buf.step_into(env, t)
+    env.flush()
+    g = env.capture(lambda: buf.step_range(env, 0, T))
+    t_end = time.perf_counter() + (1.0 if n <= 32768 else 0.2)
+    while time.perf_counter() < t_end: g.replay(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(9 if n <= 32768 else 5):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); g.replay(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    ts.sort()
+    print(json.dumps({"rate_M": round(n * T / ts[len(ts) // 2] / 1e6, 1)})); sys.exit(0)
+from tennisbot_rl_amd.build import HIPCC_FLAGS, SOURCES, hipcc
+A, B = sys.argv[1].split(), sys.argv[2].split()
+libs = {"A: " + sys.argv[1]: "/tmp/libtb_ab_a.so", "B: " + sys.argv[2]: "/tmp/libtb_ab_b.so"}
+procs = [subprocess.Popen([hipcc()] + HIPCC_FLAGS + f + ["-o", lib] + SOURCES) for f, lib in zip((A, B), libs.values())]
+assert all(p.wait() == 0 for p in procs)
+for what in sys.argv[3:] or list(WORK):
+    row = {}
+    for name, lib in libs.items():
+        r = subprocess.run([sys.executable, __file__, "--child", lib, what], capture_output=True, text=True)
+        try:
+            row[name] = json.loads(r.stdout.strip().splitlines()[-1])["rate_M"]
+        except Exception:
+            row[name] = "failed: " + r.stderr[-300:]
+    print(what, json.dumps(row), flush=True)
