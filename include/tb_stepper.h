@@ -171,7 +171,7 @@ typedef struct TbOptions {
   uint32_t struct_size;     /* sizeof(TbOptions): lets a newer library read an older caller's struct */
   int32_t block;            /* threads per workgroup of the step kernels: 64, 128 or 256 (auto: 128; 64 for SwingRacket-v0 between 49152 and 131072 envs) */
   int32_t tennis_reg_rows;  /* Tennisbot static contact rows in registers: 1 on, -1 off (auto: on) */
-  int32_t swing_reg_rows;   /* the same for the pipelined SwingRacket step kernel: 1 on, -1 off (auto: on up to 131072 envs) */
+  int32_t swing_reg_rows;   /* the same for the pipelined SwingRacket step kernel: 1 on, -1 off (auto: on) */
   int32_t ff_lanes_per_wave; /* parked envs per wave in the first fast-forward phase, 1..64 (auto: 64 from 4096 envs on, fewer below) */
   int32_t ff_sort;          /* order parked envs by their ball's ballistic flight estimate before the fast-forward: 1 on (auto: off --
                              * with random actions the flight lengths are decided by events inside the loop, not by the parked state) */

@@ -818,7 +818,10 @@ __global__ void __launch_bounds__(TB_FF_SORT_BLOCK) tb_ff_sort_kernel(KArgs A, f
 // full (ff_cap records) finishes its loop here instead; lanes that pass that check together may overshoot the capacity by what
 // all resident waves can hold, and the pool is allocated with that much slack.
 template <bool RG, bool BIG, bool ESC = false, bool POOL = false>
-__global__ void __launch_bounds__(64, (ESC && !RG) ? 4 : 1) tb_ff_kernel(KArgs A) {
+#ifndef TB_ESC_WAVES
+#define TB_ESC_WAVES 4
+#endif
+__global__ void __launch_bounds__(64, (ESC && !RG) ? TB_ESC_WAVES : 1) tb_ff_kernel(KArgs A) {
   static_assert(!POOL || !ESC, "the pool has no hand-over phase behind it");
   constexpr int TB_FF_REC = ff_rec<RG>();
   __shared__ float4 s_hull[TB_HULL_LDS];
@@ -1520,7 +1523,9 @@ int tb_create(const TbParams* params, const TbOptions* options, int env_kind, in
   // +8 % at 256 K, +16 % at 1 M, +12 % at 4 M; only the contact-free first episode after a common reset, where the
   // kernel runs at 70 % of HBM peak and occupancy counts, loses 3 % at 1 M envs
   h->reg_rows = env_kind == TB_ENV_TENNIS && (opt.tennis_reg_rows ? opt.tennis_reg_rows > 0 : 1);
-  h->swing_reg_rows = env_kind == TB_ENV_SWING && (opt.swing_reg_rows ? opt.swing_reg_rows > 0 : n_envs <= 131072);
+  // (with the unpacked build of round 3 the register-row step kernel is 154 VGPRs, three waves per SIMD: it wins at every size now --
+  //  131072 envs 8.13 against 7.68 G env steps/s, 262144: 8.35 / 8.21, 1 M: 11.64 / 11.11; until then it was chosen up to 131072 envs)
+  h->swing_reg_rows = env_kind == TB_ENV_SWING && (opt.swing_reg_rows ? opt.swing_reg_rows > 0 : 1);
   // fast-forward: sort the lanes of large batches by predicted flight length; below 4096 envs a few envs per wave
   h->ff_sort = opt.ff_sort > 0;  // opt-in: pays when flight lengths can be told from the parked state (a trained policy's struck balls)
   // measured on one box: 3 phases +11 % at 1 M envs, +-0 at 256 K, -16 % at 32 K and 4096 (two more kernels in every episode's chain)

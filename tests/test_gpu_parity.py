@@ -493,7 +493,8 @@ def test_randomised_engine_parameters_stay_bit_exact(torch, kind):
 @pytest.mark.parametrize("kind,steps,piped,options,flags", [
     (ENV_SWING, 30, False, None, F_DEFAULT), (ENV_SWING, 30, True, None, F_DEFAULT), (ENV_TENNIS, 120, False, None, F_DEFAULT),
     (ENV_SWING, 30, True, dict(ff_phases=3), F_DEFAULT), (ENV_SWING, 30, True, dict(ff_phases=2), F_DEFAULT | F_RACKET_GROUND),
-    (ENV_SWING, 30, True, dict(ff_phases=3, ff_sort=True, ff_lanes_per_wave=16), F_DEFAULT)])
+    (ENV_SWING, 30, True, dict(ff_phases=3, ff_sort=True, ff_lanes_per_wave=16), F_DEFAULT),
+    (ENV_SWING, 30, True, dict(swing_reg_rows=False), F_DEFAULT)])  # (the step kernel with its static rows in LDS: the automatic choice until round 3's build flags)
 def test_large_batch_instantiations_in_lockstep_with_the_oracle(torch, kind, steps, piped, options, flags):
     """above 131 072 envs tb_create picks other launch shapes and kernel variants (128-thread workgroups, the fast-forward
     instantiation that re-reads its cull planes and shares the outline sweep): 200 003 envs -- ragged against every workgroup

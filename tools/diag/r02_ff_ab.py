@@ -78,6 +78,13 @@ def main():
         for n in (1024, 4096, 8192, 16384, 32768, 65536, 131072):
             for o in ({}, dict(ff_defer="all"), dict(ff_defer=False)):
                 out.append(measure(n, 1040 if n <= 32768 else 104, o, reps=3, flags=flags)); print(json.dumps(out[-1]), flush=True)
+    if which == "retune":  # the size thresholds of tb_create / defer_mode once more (after a change of build flags): static rows in registers, fast-forward phases
+        for n in (65536, 131072, 262144, 1048576):
+            for o in (dict(swing_reg_rows=True), dict(swing_reg_rows=False)):
+                out.append(measure(n, 104, o, reps=3, flags=flags)); print(json.dumps(out[-1]), flush=True)
+        for n in (65536, 131072, 262144):
+            for o in (dict(ff_phases=1), dict(ff_phases=2), dict(ff_phases=3)):
+                out.append(measure(n, 104, o, reps=3, flags=flags)); print(json.dumps(out[-1]), flush=True)
     if which == "one":
         for o in ({}, {}, {}):
             out.append(measure(4096, 1040, o, flags=flags)); print(json.dumps(out[-1]), flush=True)
@@ -93,7 +100,7 @@ def main():
         for o in (dict(), dict(tennis_reg_rows=False), dict(), dict(tennis_reg_rows=False), dict(block=256), dict(block=256, tennis_reg_rows=False), dict(block=64, tennis_reg_rows=False)):
             out.append(measure(1048576, 104, o, reps=3, flags=flags, kind=ENV_TENNIS)); print(json.dumps(out[-1]), flush=True)
     if which == "opts1m":
-        for o in (dict(), dict(swing_reg_rows=True), dict(block=128), dict(block=64), dict(swing_reg_rows=True, block=128)):
+        for o in (dict(), dict(swing_reg_rows=False), dict(block=128), dict(block=64), dict(block=256), dict(ff_lanes_per_wave=32), dict()):
             out.append(measure(1048576, 104, o, reps=3, flags=flags)); print(json.dumps(out[-1]), flush=True)
     if which.startswith("n="):  # any batch size, one phase against three
         n, _, T = which[2:].partition(":")  # n=<envs>[:<rollout steps>]
