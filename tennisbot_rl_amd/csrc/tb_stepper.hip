@@ -818,6 +818,15 @@ __global__ void __launch_bounds__(TB_FF_SORT_BLOCK) tb_ff_sort_kernel(KArgs A, f
 // full (ff_cap records) finishes its loop here instead; lanes that pass that check together may overshoot the capacity by what
 // all resident waves can hold, and the pool is allocated with that much slack.
 template <bool RG, bool BIG, bool ESC = false, bool POOL = false>
+#ifndef TB_PHASE_LANES
+#define TB_PHASE_LANES 64  // survivors per wave in the phase kernels behind the first (32 measured: see EXPERIMENTS.md)
+#endif
+#ifndef TB_PHASE_GRID_DIV
+#define TB_PHASE_GRID_DIV 256
+#endif
+#ifndef TB_BUDGET_MARGIN
+#define TB_BUDGET_MARGIN 8  // substeps beyond the ballistic estimate before a lane is handed to the next phase
+#endif
 #ifndef TB_ESC_WAVES
 #define TB_ESC_WAVES 4
 #endif
@@ -868,7 +877,7 @@ __global__ void __launch_bounds__(64, (ESC && !RG) ? TB_ESC_WAVES : 1) tb_ff_ker
       // most balls -- is finished with everybody else's long flights at the join, not four kernels at a time
       int budget = 0x7fffffff;
       if (A.ff_next) {
-        budget = 4 * predict_flight(A.P, e.b.p, e.b.v) + 8;
+        budget = 4 * predict_flight(A.P, e.b.p, e.b.v) + TB_BUDGET_MARGIN;
         if (POOL) budget = (budget < 112 ? budget : 112) + A.ff_extra;
       }
       const int ns0 = ns;
@@ -1208,8 +1217,8 @@ int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const 
     KArgs k = a;
     dim3 grid((unsigned)((a.n + a.ff_lanes - 1) / a.ff_lanes)), block(64);
     if (ph > 0) {  // survivors of phase ph: a compacted list of unknown length, walked by a fixed grid
-      k.ff_rec = h->d_ff_list[slot][ph - 1]; k.ff_flag = nullptr; k.ff_src_count = h->d_ff_count[slot] + (ph - 1); k.ff_lanes = 64;
-      int g = h->n / 256; g = g < 64 ? 64 : g;  // (1 M envs, same box: / 512 9.37, / 256 9.56, / 128 9.41, / 1024 9.19 G env steps/s)
+      k.ff_rec = h->d_ff_list[slot][ph - 1]; k.ff_flag = nullptr; k.ff_src_count = h->d_ff_count[slot] + (ph - 1); k.ff_lanes = TB_PHASE_LANES;
+      int g = h->n / TB_PHASE_GRID_DIV; g = g < 64 ? 64 : g;  // (1 M envs, same box: / 512 9.37, / 256 9.56, / 128 9.41, / 1024 9.19 G env steps/s)
       grid = dim3((unsigned)g);
     }
     if (ph + 1 < phases) { k.ff_next = h->d_ff_list[slot][ph]; k.ff_next_count = h->d_ff_count[slot] + ph; }
