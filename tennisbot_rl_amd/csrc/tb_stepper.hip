@@ -495,7 +495,9 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
   constexpr bool SEP = KIND == TB_ENV_TENNIS;
   const uint32_t* __restrict__ w_words = SEP ? k_words : A.words;
   const uint8_t* __restrict__ w_done = SEP ? k_done : A.done_state;
-  const float* __restrict__ w_actions = SEP ? k_actions : A.actions;
+  const float* __restrict__ w_actions = SEP ? k_actions : A.actions;  // (SwingRacket: the compiler loads this pointer inside the `live` branch, a
+                                                                     //  second scalar round trip in front of the action loads; forcing it into the first batch
+                                                                     //  of kernel-argument loads was measured: 925 -> 908 M env steps/s at 4096 envs)
   const float4* __restrict__ w_hull = SEP ? k_hull : A.hull;
   const int w_n = SEP ? k_n : A.n, w_nhull = SEP ? k_nhull : A.P.n_hull;
   const bool live = i < w_n;
