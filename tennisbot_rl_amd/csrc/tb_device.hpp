@@ -61,7 +61,9 @@ TB_DEV vec3 rotate_inv(quat q, vec3 v) {
 // IEEE operations per instruction): component for component the very operations of rotate_inv, in the same order -- same bits.
 // 21 packed instructions for what were 42; +1.1 % at 1 M envs. (The compiler packs much of the rest on its own -- 120 v_pk_* in the
 // large-batch fast-forward. Hand-packing more lost: racket and ball linear updates side by side -4 %, the quaternion product as
-// 8 packed instructions -20 % -- pair moves, and 40 bytes of scratch per lane that throttle the launch.)
+// 8 packed instructions -20 % -- pair moves, and 40 bytes of scratch per lane that throttle the launch. With the unpacked build of
+// round 3 -- no SLP vectoriser, this function the only packed code -- it is still worth +1.5 %; the linear updates side by side were
+// tried once more: the same instruction count, 36-40 bytes of scratch again.)
 typedef float f2 __attribute__((ext_vector_type(2)));
 TB_DEV f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 TB_DEV void rotate_inv2(quat q, vec3 a, vec3 b, vec3& ra, vec3& rb) {
