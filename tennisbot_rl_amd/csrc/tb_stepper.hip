@@ -803,7 +803,8 @@ __global__ void __launch_bounds__(TB_FF_SORT_BLOCK) tb_ff_sort_kernel(KArgs A, f
 // BIG: the instantiation for batches that fill the chip several times over (occupancy counts: cull planes re-read from
 // LDS, see racket_planes, and the outline sweep shared by the wave); below that the loop's latency counts and the planes stay in registers.
 // ESC: the first phase of a BIG fast-forward with a phase behind it also hands over every env whose ball reaches the racket (substep<ESC>).
-// (ESC without the extended contact set is also built for four waves per SIMD: 125 VGPRs -- no spills -- and, with the
+// (ESC without the extended contact set is also built for four waves per SIMD: 125 VGPRs without spills in rounds 1-2, 128 with 6
+//  spilled under round 3's build flags, where three waves at 129 VGPRs measure the same -- and, with the
 //  two-slot static rows of substep<ESC>, 9.5 KB of LDS per wave: 16 waves per CU instead of 12; 1 M envs, same box: 9.3-9.4 ->
 //  10.0 G env steps/s)
 // POOL (up to 131 072 envs, TbOptions.ff_defer): THE POOL. Two uses of the same instantiation: (1) the POOL RUN -- whole episodes
@@ -1278,7 +1279,7 @@ int run_pool(TbHandle* h, hipStream_t q) {
   g = g < 1024 ? 1024 : g > 16384 ? 16384 : g;  // (workgroups beyond the pool's fill exit at once; grid-stride beyond 1 M records)
   (void)hipGetLastError();
   // whole episodes in the pool make it a LARGE batch -- 43 episodes x 4096 envs = 2752 waves: the instantiation built for occupancy
-  // (161 VGPRs, three waves per SIMD, wave-shared outline sweep) holds them all at once, the small-batch one (196 VGPRs, two per
+  // (143 VGPRs, three waves per SIMD, wave-shared outline sweep) holds them all at once, the small-batch one (178 VGPRs, two per
   // SIMD) ran them in two rounds
   const bool big = !rg && h->pool_episodes > 0 && records >= 131072;
   if (rg) hipLaunchKernelGGL((tb_ff_kernel<true, false, false, true>), dim3((unsigned)g), dim3(64), dyn_lds(false, true, 64), q, k);
