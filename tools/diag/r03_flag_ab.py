@@ -6,7 +6,8 @@ import json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 WORK = {"swing4096": (0, 4096, 1040, 0), "swing32k": (0, 32768, 1040, 0), "swing128k": (0, 131072, 104, 0), "swing1m": (0, 1048576, 104, 0),
-        "tennis4096": (1, 4096, 1040, 0), "tennis1m": (1, 1048576, 104, 0), "rg4096": (0, 4096, 1040, 1)}
+        "tennis4096": (1, 4096, 1040, 0), "tennis1m": (1, 1048576, 104, 0), "rg4096": (0, 4096, 1040, 1),
+        "swing4m": (0, 4194304, 52, 0), "tennis4m": (1, 4194304, 52, 0), "tennis256k": (1, 262144, 104, 0), "swing256k": (0, 262144, 104, 0)}
 if len(sys.argv) > 2 and sys.argv[1] == "--child":
     lib, what = sys.argv[2], sys.argv[3]
     import torch
@@ -33,7 +34,14 @@ if len(sys.argv) > 2 and sys.argv[1] == "--child":
 from tennisbot_rl_amd.build import HIPCC_FLAGS, SOURCES, hipcc
 A, B = sys.argv[1].split(), sys.argv[2].split()
 libs = {"A: " + sys.argv[1]: "/tmp/libtb_ab_a.so", "B: " + sys.argv[2]: "/tmp/libtb_ab_b.so"}
-procs = [subprocess.Popen([hipcc()] + HIPCC_FLAGS + f + ["-o", lib] + SOURCES) for f, lib in zip((A, B), libs.values())]
+
+
+def flags(extra):  # "~flag" takes `flag` out of the product's HIPCC_FLAGS (e.g. "~-fno-slp-vectorize ~-mllvm ~-amdgpu-sched-strategy=max-ilp": the build of rounds 1-2)
+    drop = {x[1:] for x in extra if x.startswith("~")}
+    return [f for f in HIPCC_FLAGS if f not in drop] + [x for x in extra if not x.startswith("~")]
+
+
+procs = [subprocess.Popen([hipcc()] + flags(f) + ["-o", lib] + SOURCES) for f, lib in zip((A, B), libs.values())]
 assert all(p.wait() == 0 for p in procs)
 for what in sys.argv[3:] or list(WORK):
     row = {}
