@@ -1241,6 +1241,9 @@ int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const 
     }
     const bool big = h->n >= 131072;
     const bool esc = big && ph == 0 && phases > 1;
+#ifdef TB_ESC_GRID_CAP  // (A/B builds: the first phase as at most this many resident waves, see EXPERIMENTS.md)
+    if (esc && (int)grid.x > TB_ESC_GRID_CAP) grid = dim3((unsigned)TB_ESC_GRID_CAP);
+#endif
     const size_t lds = esc && !rg ? sizeof(float) * 64 * TB_ROWS_LDS_TWO : dyn_lds(false, rg, 64);
     if (esc) { if (rg) hipLaunchKernelGGL((tb_ff_kernel<true, true, true>), grid, block, lds, side, k); else hipLaunchKernelGGL((tb_ff_kernel<false, true, true>), grid, block, lds, side, k); }
     else if (rg) { if (big) hipLaunchKernelGGL((tb_ff_kernel<true, true>), grid, block, lds, side, k); else hipLaunchKernelGGL((tb_ff_kernel<true, false>), grid, block, lds, side, k); }

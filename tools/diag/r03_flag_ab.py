@@ -17,9 +17,12 @@ if len(sys.argv) > 2 and sys.argv[1] == "--child":
     from tennisbot_rl_amd.rollout import RolloutBuffer
     from tennisbot_rl_amd.stepper import BatchedEnv
     dev = torch.device("cuda", 0)
+    opts = {}
+    if what.endswith("_ldsrows"):  # (the step kernel with its static rows in LDS: 103 instead of 154 VGPRs)
+        what, opts = what[:-len("_ldsrows")], dict(swing_reg_rows=False)
     k, n, T, rg = WORK[what]
     kind = ENV_TENNIS if k else ENV_SWING
-    env = BatchedEnv(kind, n, device=dev, seed=0, params=default_params(flags=F_DEFAULT | (F_RACKET_GROUND if rg else 0)), track_terminal_obs=False, pipeline=kind == ENV_SWING)
+    env = BatchedEnv(kind, n, device=dev, seed=0, params=default_params(flags=F_DEFAULT | (F_RACKET_GROUND if rg else 0)), track_terminal_obs=False, pipeline=kind == ENV_SWING, options=opts)
     buf = RolloutBuffer(kind, T, n, dev); torch.manual_seed(0); buf.actions.uniform_(-1, 1); buf.bind(env); env.reset()
     for t in range(T): buf.step_into(env, t)
     env.flush()
