@@ -1050,8 +1050,14 @@ template <int KIND> TB_DEV bool near_goal(const KParams& P, float zlow) { return
 // phase kernel as a survivor, and that kernel repeats this substep with everything compiled in -- among lanes that mostly want
 // the same. Same arithmetic, same order per env: bit-identical.
 // REGGROUND: see solve_contacts (the looping small-batch kernels ask for it)
-template <int KIND, bool RG, bool REGROWS = false, bool COLD = false, bool RELOAD = false, bool ESC = false, bool REGGROUND = false>
-TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Manifold& M, vec3 Fr, vec3 Tr, vec3 Fb, float goal_x, float goal_y, float scale TB_STAMP_ARG) {
+// LAZYTAB (the pipelined SwingRacket step kernel: ONE substep per launch): `hull`, the LDS copy of the outline table, is EMPTY on
+// entry. Nothing reads it before a ball gets past the racket's slab test -- in the 25 short steps of a random-action episode none
+// does -- so the copy (2.5 KB from `table_mem`, by the wave that needs it, no barrier: a wave's LDS operations complete in order)
+// is made right there, behind a wave vote, instead of by every launch up front (0.4 us of a ~4 us launch, tools/diag/lanes_per_wave.hip).
+template <int KIND, bool RG, bool REGROWS = false, bool COLD = false, bool RELOAD = false, bool ESC = false, bool REGGROUND = false, bool LAZYTAB = false>
+TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Manifold& M, vec3 Fr, vec3 Tr, vec3 Fb, float goal_x, float goal_y, float scale TB_STAMP_ARG,
+                   const float4* table_mem = nullptr) {
+  static_assert(!LAZYTAB || (!ESC && !RELOAD && !COLD && !RG), "the lazily copied table serves the plain one-substep kernel only");
   int bits = 0;
   TB_STAMP(st, 0);  // everything between two substeps (loop control, env logic)
   constexpr bool TWO = ESC && !RG && !REGROWS;  // the static rows in two LDS slots, see load_row
@@ -1103,7 +1109,23 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
     vec3 ql = mk(0.0f, 0.0f, 0.0f);
     float qax = 0.0f;
     bool need = false;
-    if (near_racket) need = racket_cull<KIND == TB_ENV_TENNIS, RELOAD>(P, hull, lp, scale, ql, qax);
+    if constexpr (LAZYTAB) {
+      bool past_slab = false;
+      if (near_racket) past_slab = racket_slab<KIND == TB_ENV_TENNIS>(P, lp, scale, ql, qax);
+      if (__any(past_slab)) {  // the first reader of the table in this launch: this wave copies it (another wave of the workgroup may be
+                               // writing the same values to the same places)
+        float4* dst = const_cast<float4*>(hull);
+        const int lane = (int)(threadIdx.x & 63);
+        for (int k = lane; k < 2 * P.n_hull; k += 64) dst[k] = table_mem[k];
+        for (int k = TB_HULL_PLANES + lane; k < TB_HULL_LDS; k += 64) dst[k] = table_mem[k];
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // every lane's writes are in LDS before any lane reads another's
+        if (past_slab) {
+          TB_LANES_ADD1(12);
+          need = racket_planes<KIND == TB_ENV_TENNIS, false>(P, hull, ql, scale);
+          if (need) { TB_DIAG_ADD_EACH(10, 1); TB_DIAG_ADD_LEADER(11, 1); }
+        }
+      }
+    } else if (near_racket) need = racket_cull<KIND == TB_ENV_TENNIS, RELOAD>(P, hull, lp, scale, ql, qax);
     // the cooperative form where throughput counts (the large-batch fast-forward instantiation, RELOAD): +4.7 % at 1 M envs, same
     // box; at 4096 envs it shortens the fast-forward (0.47 -> 0.44 ms per lone episode) but its busier waves take more from the
     // step kernels beside them than that gives back (702 -> 655 M env steps/s), and in the loop-free step kernels its ballot masks

@@ -359,13 +359,14 @@ TB_DEV vec3 restoring_force(const EnvRegs& e) {  // swingracket_env.py:135-141
 //           next phase kernel resumes it from the saved state, with the restoring force recomputed from that state.
 // ESC     = first phase of the large-batch tb_ff_kernel: a lane that needs the racket's exact narrowphase leaves the loop BEFORE
 //           that substep (`parked` again, nothing of the substep applied); see substep<ESC>.
-template <bool RG, bool REGROWS = false, bool COLD = false, bool BUDGET = false, bool RELOAD = false, bool ESC = false, bool REGGROUND = false>
+// LAZYTAB   = see substep (the pipelined step kernel: `hull` is filled from `table_mem` by the first wave that reads it)
+template <bool RG, bool REGROWS = false, bool COLD = false, bool BUDGET = false, bool RELOAD = false, bool ESC = false, bool REGGROUND = false, bool LAZYTAB = false>
 TB_DEV float swing_loop(const KParams& P, const float4* hull, EnvRegs& e, Manifold& M, vec3 F, vec3 T, bool in_ff, bool defer, bool& parked,
-                        int& ns, uint32_t* cnt TB_STAMP_ARG, int budget = 0) {
+                        int& ns, uint32_t* cnt TB_STAMP_ARG, int budget = 0, const float4* table_mem = nullptr) {
   const vec3 zero = mk(0.0f, 0.0f, 0.0f);
   float reward = 0.0f;
   for (;;) {
-    int bits = substep<TB_ENV_SWING, RG, REGROWS, COLD, RELOAD, ESC, REGGROUND>(P, hull, e.r, e.b, M, F, T, zero, e.aux[0], e.aux[1], 1.0f TB_STAMP_PASS);  // :82 / :107
+    int bits = substep<TB_ENV_SWING, RG, REGROWS, COLD, RELOAD, ESC, REGGROUND, LAZYTAB>(P, hull, e.r, e.b, M, F, T, zero, e.aux[0], e.aux[1], 1.0f TB_STAMP_PASS, table_mem);  // :82 / :107
     if (ESC && (bits & CT_ESCAPE)) { parked = true; break; }
     e.step_count += 1; ns++;                                                                                   // :83 / :108
     if (bits & CT_RACKET) cnt[0]++;
@@ -386,8 +387,9 @@ TB_DEV float swing_loop(const KParams& P, const float4* hull, EnvRegs& e, Manifo
   return reward;
 }
 
-template <bool RG, bool REGROWS = false, bool COLD = false>
-TB_DEV float swing_step(const KParams& P, const float4* hull, EnvRegs& e, Manifold& M, const float* a, int& ns, uint32_t* cnt, bool defer, bool& parked TB_STAMP_ARG) {
+template <bool RG, bool REGROWS = false, bool COLD = false, bool LAZYTAB = false>
+TB_DEV float swing_step(const KParams& P, const float4* hull, EnvRegs& e, Manifold& M, const float* a, int& ns, uint32_t* cnt, bool defer, bool& parked TB_STAMP_ARG,
+                        const float4* table_mem = nullptr) {
   vec3 F = mk(a[0] * 400.0f, a[1] * 400.0f, FMA(a[2], 400.0f, 4.0f * 9.81f));  // :76-77
   vec3 T = mk(a[3] * 5.0f, a[4] * 5.0f, a[5] * 5.0f);                          // :78
   if (e.done == TB_DONE_PENDING_FORCE) {  // the force of :135-141 is still in the accumulator
@@ -395,7 +397,7 @@ TB_DEV float swing_step(const KParams& P, const float4* hull, EnvRegs& e, Manifo
     e.done = TB_DONE_YES;
   }
   ns = 0;
-  const float rew = swing_loop<RG, REGROWS, COLD>(P, hull, e, M, F, T, false, defer, parked, ns, cnt TB_STAMP_PASS);
+  const float rew = swing_loop<RG, REGROWS, COLD, false, false, false, false, LAZYTAB>(P, hull, e, M, F, T, false, defer, parked, ns, cnt TB_STAMP_PASS, 0, table_mem);
   if (!parked && M.n == 0) M.deep = 0;  // an empty cache is not kept between env.step() calls (a parked env's call is not over: its record keeps it)
   return rew;
 }
@@ -478,6 +480,12 @@ namespace {
 // one to two more waves per SIMD for the kernel every RL step launches.
 // POLICY: the actions are not read from memory but inferred in-kernel (tb_policy_step).
 // REGROWS (Tennisbot, small batches): the static contact rows in registers, see solve_contacts.
+#ifndef TB_LAZY_TABLE
+#define TB_LAZY_TABLE 1  // (0: A/B builds that copy the table in every launch of the pipelined SwingRacket step kernel)
+#endif
+#ifndef TB_TABLE_IN_MEMORY
+#define TB_TABLE_IN_MEMORY 1  // (0: A/B builds with the LDS copy in every kernel)
+#endif
 template <int KIND, bool LEAN, bool MULTI, bool RG, bool POLICY = false, bool REGROWS = false>
 __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict__ k_words, const uint8_t* __restrict__ k_done, const float* __restrict__ k_actions,
                                                       const float4* __restrict__ k_hull, int k_n, int k_nhull, KArgs A) {
@@ -486,7 +494,16 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
   // with cannot alias the stores it ends with. (Preloading them into SGPRs at wave launch,
   // -amdgpu-kernarg-preload-count, was measured too: no further gain for Tennisbot, -5 % for SwingRacket.)
   constexpr int NA = Dims<KIND>::A, NO = Dims<KIND>::O;
-  __shared__ float4 s_hull[TB_HULL_LDS];
+  // TABLE_IN_MEMORY (tb_step on Tennisbot): the outline table stays where it is. A launch that runs ONE substep reads an entry at
+  // most once, and most lanes read none (edges and cull planes are for balls at the racket, the parameter block's copy for
+  // resets) -- while copying 2.5 KB into LDS behind a barrier costs every launch up to 0.4 us (tools/diag/lanes_per_wave.hip).
+  // Tennisbot 4096 envs: 689 -> 727 M env steps/s, 1 M: 19.2 -> 19.5 G. The pipelined SwingRacket step kernel, at its SGPR limit,
+  // pays more for the table's addresses than the copy costs it (918 -> 899 M, 32768 envs 5.17 -> 4.80 G): it keeps the LDS copy,
+  // like every kernel that loops (fast-forward, tb_rollout, the fused policy).
+  constexpr bool TABLE_IN_MEMORY = !POLICY && !MULTI && KIND == TB_ENV_TENNIS && TB_TABLE_IN_MEMORY;
+  // LAZYTAB (tb_step on pipelined SwingRacket without the extended contact set): the LDS copy is made by the first wave that reads it (substep<LAZYTAB>)
+  constexpr bool LAZYTAB = !POLICY && !MULTI && KIND == TB_ENV_SWING && LEAN && !RG && TB_LAZY_TABLE;
+  __shared__ float4 s_lds_hull[TABLE_IN_MEMORY ? 1 : TB_HULL_LDS];
   __shared__ __attribute__((aligned(16))) float s_mean[POLICY ? 64 * 8 : 4];
   // POLICY: 256-thread workgroups, four waves per 64 envs, each running both towers of a 16-env slice (see policy_towers); wave 0 steps the envs
   const int i = POLICY ? blockIdx.x * 64 + (threadIdx.x & 63) : blockIdx.x * blockDim.x + threadIdx.x;
@@ -500,6 +517,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
                                                                      //  of kernel-argument loads was measured: 925 -> 908 M env steps/s at 4096 envs)
   const float4* __restrict__ w_hull = SEP ? k_hull : A.hull;
   const int w_n = SEP ? k_n : A.n, w_nhull = SEP ? k_nhull : A.P.n_hull;
+  const float4* const s_hull = TABLE_IN_MEMORY ? w_hull : s_lds_hull;
   const bool live = i < w_n;
   EnvRegs e;
   TB_DIAG_NOW(t_entry);
@@ -525,13 +543,13 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
     float4 row = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (has_row) row = w_hull[threadIdx.x];
     policy_towers<KIND>(A, s_mean);
-    if (has_row) s_hull[threadIdx.x] = row;
+    if (has_row) s_lds_hull[threadIdx.x] = row;
     __syncthreads();
     if (threadIdx.x >= 64) return;  // no barrier below this point
     if (live) policy_sample<KIND>(A, s_mean, i, e, a);
-  } else {
-    for (int k = threadIdx.x; k < 2 * w_nhull; k += blockDim.x) s_hull[k] = w_hull[k];
-    for (int k = TB_HULL_PLANES + threadIdx.x; k < TB_HULL_LDS; k += blockDim.x) s_hull[k] = w_hull[k];
+  } else if (!TABLE_IN_MEMORY && !LAZYTAB) {
+    for (int k = threadIdx.x; k < 2 * w_nhull; k += blockDim.x) s_lds_hull[k] = w_hull[k];
+    for (int k = TB_HULL_PLANES + threadIdx.x; k < TB_HULL_LDS; k += blockDim.x) s_lds_hull[k] = w_hull[k];
     __syncthreads();
   }
   TB_DIAG_WAIT_LOADS(live);
@@ -556,7 +574,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
       bool d, parked = false;
       float rew;
       if (KIND == TB_ENV_SWING) {
-        rew = swing_step<RG, REGROWS>(A.P, s_hull, e, M, a, ns, cnt, LEAN || A.defer != 0, parked TB_STAMP_PASS);
+        rew = swing_step<RG, REGROWS, false, LAZYTAB>(A.P, s_hull, e, M, a, ns, cnt, LEAN || A.defer != 0, parked TB_STAMP_PASS, w_hull);
         make_obs<TB_ENV_SWING>(e, o);
         d = e.done != TB_DONE_NO;  // swingracket_env.py:145 returns self.done
         if (parked) {
