@@ -441,7 +441,7 @@ TB_DEV bool finite3(vec3 v) { return isfinite(v.x) && isfinite(v.y) && isfinite(
 // wave-level sum of per-lane event counts; one atomic per wave and counter that is non-zero, into
 // one of TB_COUNTER_SHARDS copies (same-address atomics serialise at ~12 ns each: with one copy a
 // 1 M-env launch, 16 K waves, spent 200 us queueing on the substep counter alone). The mandatory
-// first substep of a step is not counted per wave: one lane of the launch adds n_envs * T.
+// first substep of a step is not counted on the device at all: the host adds n_envs * T per launch (count_first_substeps).
 TB_DEV void flush_counters(unsigned long long* counters, const uint32_t* cnt) {
   uint32_t any = 0u;
 #pragma unroll
@@ -619,8 +619,8 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
   }
   TB_DIAG_ADD_LANE0(7, t_loaded - t_entry);  // state + outline loads landed
   flush_counters(A.counters, cnt);
-  if (blockIdx.x == 0 && threadIdx.x == 0)  // the first substep of every env in every agent step of this launch
-    atomicAdd(&A.counters[6], (unsigned long long)A.n * (unsigned long long)(MULTI ? A.T : 1));
+  // (the first substep of every env in every agent step is counted by the HOST, see count_first_substeps: one atomic per launch
+  //  from one lane was 2.7 % of the 4096-env rate)
   TB_DIAG_STAMPS_END(st);
   TB_DIAG_ADD_LANE0(8, stamp_now() - t_kernel0);  // per-wave scalars: cycles in the kernel, waves, 100 MHz ticks
   TB_DIAG_ADD_LANE0(9, 1);
@@ -741,7 +741,6 @@ __global__ void __launch_bounds__((2 * S + 1) * 64) tb_policy_rollout_kernel(KAr
     if constexpr (RG) { if (M.n > 0 || had_contacts) store_manifold(A, i, M, had_contacts); }
   }
   flush_counters(A.counters, cnt);
-  if (blockIdx.x == 0 && lane == 0) atomicAdd(&A.counters[6], (unsigned long long)A.n * (unsigned long long)A.T);
 }
 
 // progress mark (tb_mark_record): one thread bumps a counter in pinned host memory. Relaxed on purpose: the kernels this
@@ -1113,6 +1112,7 @@ struct TbHandle {
   float4* d_ff_list[TB_FF_SLOTS][2];  // survivors of fast-forward phases 1 and 2 (worst case: every env), compacted
   int* d_ff_count[TB_FF_SLOTS];       // [2] their numbers
   int ff_phases;                      // 1 = one kernel runs every loop to its end; 2, 3 = budgeted phases + survivor kernels
+  unsigned long long first_substeps;  // counters[6], the host's share: n envs x agent steps of every launch that RAN (see count_first_substeps)
   int ff_lanes, ff_sort;          // how tb_ff_kernel hands records to lanes (TbOptions.ff_lanes_per_wave / ff_sort, or chosen from n)
   // deferred stragglers (tb_ff_kernel<.., POOL>; TbOptions.ff_defer): one pool for all episodes between two flushes
   float4* d_pool;                 // [pool_cap + pool_slack][TB_FF_REC_MAX]
@@ -1388,6 +1388,17 @@ int parked_direct(TbHandle* h, hipStream_t s) {
   return TB_OK;
 }
 
+// The substep counter's host share. Every agent step runs at least one substep of every env: n x T per launch, known to the host --
+// the kernels only count what goes beyond (fast-forward loops). Added when a launch is enqueued to run; a launch that is only being
+// CAPTURED runs nothing: whoever replays the graph reports the replayed steps through tb_phase_advance, as it must for the episode
+// phase anyway. (tb_counters joins the stream before it reads: what was enqueued has run by then.)
+int count_first_substeps(TbHandle* h, int T, hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  HIP_TRY(hipStreamIsCapturing(s, &st));
+  if (st == hipStreamCaptureStatusNone) h->first_substeps += (unsigned long long)h->n * (unsigned long long)T;
+  return TB_OK;
+}
+
 struct PolicyIO {  // non-null weights = fused policy step
   const float* weights; const float* obs_in; float* actions; float* raw; float* logp; float* value;
   unsigned long long seed; int deterministic;
@@ -1398,6 +1409,7 @@ struct PolicyIO {  // non-null weights = fused policy step
 // pipelined kernel (no in-kernel fast-forward) can run several steps per launch too.
 int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* reward, uint8_t* done, float* term, int32_t* substeps, hipStream_t s,
                 const PolicyIO* pol = nullptr, bool lean_multi = false) {
+  if (int rc = count_first_substeps(h, T, s)) return rc;
   KArgs a = base_args(h);
   if (pol) {
     a.pol_weights = pol->weights; a.pol_obs = pol->obs_in; a.pol_actions = pol->actions; a.pol_raw = pol->raw; a.pol_logp = pol->logp;
@@ -1471,6 +1483,7 @@ int launch_step(TbHandle* h, int T, const float* actions, float* obs, float* rew
 // one launch of tb_policy_rollout_kernel over T steps; SwingRacket: T ends where the episode does
 int launch_policy_rollout(TbHandle* h, int T, const PolicyIO& pol, float* obs, float* reward, uint8_t* done, const size_t* st /*element strides*/,
                           hipStream_t s) {
+  if (int rc = count_first_substeps(h, T, s)) return rc;
   KArgs a = base_args(h);
   a.pol_weights = pol.weights; a.pol_obs = pol.obs_in; a.pol_actions = pol.actions; a.pol_raw = pol.raw; a.pol_logp = pol.logp;
   a.pol_value = pol.value; a.pol_seed = pol.seed; a.pol_deterministic = pol.deterministic;
@@ -1763,6 +1776,7 @@ int tb_pipeline_form(TbHandle* h) {
 int tb_phase_advance(TbHandle* h, int n_steps) {
   if (!h || n_steps < 0) return fail(TB_E_INVAL, "tb_phase_advance: bad argument");
   if (h->phase_valid) h->phase = (h->phase + n_steps) % 26;
+  h->first_substeps += (unsigned long long)h->n * (unsigned long long)n_steps;  // the replayed steps' share of the substep counter
   return TB_OK;
 }
 
@@ -2027,6 +2041,7 @@ int tb_counters(TbHandle* h, uint64_t* out, void* stream) {
     out[k] = 0;
     for (int sh = 0; sh < TB_COUNTER_SHARDS; ++sh) out[k] += shards[sh][k];
   }
+  out[6] += h->first_substeps;
   return TB_OK;
 }
 
@@ -2057,6 +2072,7 @@ int tb_counters_reset(TbHandle* h, void* stream) {
   if (!h) return fail(TB_E_INVAL, "tb_counters_reset: null handle");
   DeviceGuard g(h->device);
   HIP_TRY(hipMemsetAsync(h->d_counters, 0, sizeof(uint64_t) * TB_N_COUNTERS * TB_COUNTER_SHARDS, (hipStream_t)stream));
+  h->first_substeps = 0;
   return TB_OK;
 }
 
