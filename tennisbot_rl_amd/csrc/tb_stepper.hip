@@ -437,6 +437,23 @@ TB_DEV float tennis_step(const KParams& P, const float4* hull, EnvRegs& e, Manif
 }
 
 TB_DEV bool finite3(vec3 v) { return isfinite(v.x) && isfinite(v.y) && isfinite(v.z); }
+// all 22 state values finite? x * 0 is (+-)0 for a finite x and NaN for an infinity or a NaN, and NaN survives every sum: four
+// short fma chains and ONE comparison instead of 22 class tests and the scalar ands between them (the same verdict for every input)
+TB_DEV bool state_is_finite(const EnvRegs& e) {
+#ifdef TB_AB_CLASS_FINITE
+  return finite3(e.r.p) && finite3(e.r.v) && finite3(e.r.w) && finite3(e.b.p) && finite3(e.b.v) && finite3(e.b.w) &&
+         isfinite(e.r.q.x) && isfinite(e.r.q.y) && isfinite(e.r.q.z) && isfinite(e.r.q.w);
+#else
+  float a0 = e.r.p.x * 0.0f, a1 = e.r.p.y * 0.0f, a2 = e.r.p.z * 0.0f, a3 = e.r.q.x * 0.0f;
+  a0 = FMA(e.r.q.y, 0.0f, a0); a1 = FMA(e.r.q.z, 0.0f, a1); a2 = FMA(e.r.q.w, 0.0f, a2); a3 = FMA(e.r.v.x, 0.0f, a3);
+  a0 = FMA(e.r.v.y, 0.0f, a0); a1 = FMA(e.r.v.z, 0.0f, a1); a2 = FMA(e.r.w.x, 0.0f, a2); a3 = FMA(e.r.w.y, 0.0f, a3);
+  a0 = FMA(e.r.w.z, 0.0f, a0); a1 = FMA(e.b.p.x, 0.0f, a1); a2 = FMA(e.b.p.y, 0.0f, a2); a3 = FMA(e.b.p.z, 0.0f, a3);
+  a0 = FMA(e.b.v.x, 0.0f, a0); a1 = FMA(e.b.v.y, 0.0f, a1); a2 = FMA(e.b.v.z, 0.0f, a2); a3 = FMA(e.b.w.x, 0.0f, a3);
+  a0 = FMA(e.b.w.y, 0.0f, a0); a1 = FMA(e.b.w.z, 0.0f, a1);
+  const float t = (a0 + a1) + (a2 + a3);
+  return t == t;
+#endif
+}
 
 // wave-level sum of per-lane event counts; one atomic per wave and counter that is non-zero, into
 // one of TB_COUNTER_SHARDS copies (same-address atomics serialise at ~12 ns each: with one copy a
@@ -596,8 +613,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
       }
       cnt[6] += (uint32_t)(ns - 1);  // substeps beyond the first of each agent step
       ns_total += ns;
-      if (!(finite3(e.r.p) && finite3(e.r.v) && finite3(e.r.w) && finite3(e.b.p) && finite3(e.b.v) && finite3(e.b.w) &&
-            isfinite(e.r.q.x) && isfinite(e.r.q.y) && isfinite(e.r.q.z) && isfinite(e.r.q.w)))
+      if (!state_is_finite(e))
         cnt[7]++;
       if (d && (A.P.flags & TB_F_AUTO_RESET)) {
         cnt[5]++;
@@ -716,8 +732,7 @@ __global__ void __launch_bounds__((2 * S + 1) * 64) tb_policy_rollout_kernel(KAr
         rew = tennis_step<RG, true, true>(A.P, s_hull, e, M, a, o, d, cnt TB_STAMP_PASS);
       }
       cnt[6] += (uint32_t)(ns - 1);
-      if (!(finite3(e.r.p) && finite3(e.r.v) && finite3(e.r.w) && finite3(e.b.p) && finite3(e.b.v) && finite3(e.b.w) &&
-            isfinite(e.r.q.x) && isfinite(e.r.q.y) && isfinite(e.r.q.z) && isfinite(e.r.q.w)))
+      if (!state_is_finite(e))
         cnt[7]++;
       if (d) {  // (rollouts require TB_F_AUTO_RESET)
         cnt[5]++;
@@ -912,8 +927,7 @@ __global__ void __launch_bounds__(64, (ESC && !RG) ? TB_ESC_WAVES : 1) tb_ff_ker
       }
       cnt[6] += (uint32_t)(ns - ns0);
       if (!unfinished) {
-        if (!(finite3(e.r.p) && finite3(e.r.v) && finite3(e.r.w) && finite3(e.b.p) && finite3(e.b.v) && finite3(e.b.w) &&
-              isfinite(e.r.q.x) && isfinite(e.r.q.y) && isfinite(e.r.q.z) && isfinite(e.r.q.w)))
+        if (!state_is_finite(e))
           cnt[7]++;
         float o[TB_SWING_OBS_DIM];
         make_obs<TB_ENV_SWING>(e, o);

@@ -1186,6 +1186,37 @@ def test_fast_forward_with_balls_thrown_at_a_spinning_racket(torch, n, options):
     env.close()
 
 
+@pytest.mark.parametrize("kind", [ENV_SWING, ENV_TENNIS])
+def test_nonfinite_states_are_counted_like_the_oracle_counts_them(torch, kind):
+    """the nonfinite_states counter with something to count: an infinity or a NaN injected into one of the 22 state values of every
+    tenth env (each value in turn, both signs), then stepped -- the kernels' one-comparison test (x * 0 summed: NaN for any
+    non-finite x) must give the verdict of the oracle's 22 isfinite() calls, step by step, without auto-reset (the state stays)"""
+    n = 660
+    env, ref = make_pair(torch, kind, n, auto_reset=False)
+    rng = np.random.default_rng(5)
+    same(env.reset().cpu().numpy(), ref.reset(), "reset obs")
+    A = env.act_dim
+    for t in range(3):
+        a = rng.uniform(-1, 1, (n, A)).astype(np.float32)
+        env.step(torch.from_numpy(a).cuda()); ref.step(a)
+    w, d = env.get_state_words()
+    w = w.cpu().numpy().view(np.uint32).copy(); d = d.cpu().numpy().copy()
+    bad = [np.float32(np.inf), np.float32(-np.inf), np.float32(np.nan)]
+    poisoned = 0
+    for i in range(0, n, 10):
+        row, val = (i // 10) % 22, bad[(i // 10) % 3]
+        w[row, i] = val.view(np.uint32)
+        poisoned += 1
+    env.set_state_words(w.view(np.int32), d); ref.set_state_words(w, d)
+    for t in range(2):
+        a = rng.uniform(-1, 1, (n, A)).astype(np.float32)
+        env.step(torch.from_numpy(a).cuda()); ref.step(a)
+        got, want = env.counters(), [int(x) for x in ref.counters()]
+        assert list(got.values()) == want, (t, got, want)
+    assert got["nonfinite_states"] >= poisoned  # (every poisoned env is still non-finite one step later: counted in both steps)
+    env.close()
+
+
 def test_pipeline_form_follows_size_flags_and_marks(torch):
     """tb_pipeline_form: what TbOptions.ff_defer = 0 (auto) resolves to -- every episode end into the pool up to 16384 envs, the
     stragglers only above that with racket<->court contact, plain slots otherwise"""
