@@ -45,6 +45,14 @@ TB_DEV vec3 operator-(vec3 a, vec3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.
 TB_DEV vec3 operator*(float s, vec3 a) { return mk(s * a.x, s * a.y, s * a.z); }
 TB_DEV vec3 fma3(float s, vec3 x, vec3 y) { return mk(FMA(s, x.x, y.x), FMA(s, x.y, y.y), FMA(s, x.z, y.z)); }
 TB_DEV float dot(vec3 a, vec3 b) { return FMA(a.z, b.z, FMA(a.y, b.y, a.x * b.x)); }
+// any component non-zero (or NaN)? |x| + |y| + |z| is zero only if all three are (nothing cancels between magnitudes; a NaN or an
+// overflow to infinity compares unequal to zero too): two additions with free |.| modifiers and ONE comparison where three
+// comparisons and the scalar ors between them cost a lone wave three more issue slots
+#ifdef TB_AB_COMPARE_EACH
+TB_DEV bool nonzero3(vec3 v) { return (v.x != 0.0f) | (v.y != 0.0f) | (v.z != 0.0f); }
+#else
+TB_DEV bool nonzero3(vec3 v) { return (fabsf(v.x) + fabsf(v.y)) + fabsf(v.z) != 0.0f; }
+#endif
 TB_DEV vec3 cross(vec3 a, vec3 b) {
   return mk(FMA(a.y, b.z, -(a.z * b.y)), FMA(a.z, b.x, -(a.x * b.z)), FMA(a.x, b.y, -(a.y * b.x)));
 }
@@ -969,10 +977,10 @@ TB_DEV void integrate_velocities(const KParams& P, Racket& rk, Ball& b, vec3 Fr,
     // a racket that neither spins nor is torqued has zero angular acceleration: skip the
     // body-frame round trip (Tennisbot rackets until they are hit; every fast-forward substep
     // of a racket that was never torqued)
-    bool active = (rk.w.x != 0.0f) | (rk.w.y != 0.0f) | (rk.w.z != 0.0f) | (Tr.x != 0.0f) | (Tr.y != 0.0f) | (Tr.z != 0.0f);
+    const bool torqued = nonzero3(Tr);
+    bool active = nonzero3(rk.w) | torqued;
     TB_DIAG_ABLATE_ANGULAR(active);
     if (active) {
-      bool torqued = (Tr.x != 0.0f) | (Tr.y != 0.0f) | (Tr.z != 0.0f);
       vec3 wb = wb_pre, Tb = mk(0.0f, 0.0f, 0.0f);
       if (torqued) Tb = rotate_inv(rk.q, Tr);
       vec3 L = mk(P.racket_inertia[0] * wb.x, P.racket_inertia[1] * wb.y, P.racket_inertia[2] * wb.z);
@@ -989,7 +997,7 @@ TB_DEV void integrate_velocities(const KParams& P, Racket& rk, Ball& b, vec3 Fr,
     vec3 a = mk(FMA(Fb.x, P.ball_inv_mass, -(b.v.x * kd)), FMA(Fb.y, P.ball_inv_mass, -(b.v.y * kd)),
                 FMA(Fb.z, P.ball_inv_mass, -(b.v.z * kd)) - g);
     b.v = fma3(dt, a, b.v);
-    bool spinning = (b.w.x != 0.0f) | (b.w.y != 0.0f) | (b.w.z != 0.0f);
+    bool spinning = nonzero3(b.w);
     if (spinning) {
       if constexpr (LAZY) spin_b = sqrtf(dot(b.w, b.w));
       float ka = FMA(P.ang_damp_quad, spin_b, P.ang_damp);
