@@ -87,41 +87,65 @@ template <int KIND> struct Dims;
 template <> struct Dims<TB_ENV_SWING> { static constexpr int W = TB_SWING_WORDS, A = TB_SWING_ACT_DIM, O = TB_SWING_OBS_DIM, NAUX = 6; };
 template <> struct Dims<TB_ENV_TENNIS> { static constexpr int W = TB_TENNIS_WORDS, A = TB_TENNIS_ACT_DIM, O = TB_TENNIS_OBS_DIM, NAUX = 4; };
 
-TB_DEV float ld(const uint32_t* w, int row, int n, int i) { return __uint_as_float(w[(size_t)row * n + i]); }
-TB_DEV void st(uint32_t* w, int row, int n, int i, float v) { w[(size_t)row * n + i] = __float_as_uint(v); }
+// SwingRacket's state rows are addressed as ONE 64-bit base (scalar registers) + a 32-bit byte offset per row and lane: the
+// global_load / store form with a scalar base, one v_add_u32 per row -- instead of a 64-bit pointer bump per row (a 64-bit vector add
+// and two scalar adds: 108 scalar instructions per step launch for the 54 rows a step reads and writes, which a lone wave per SIMD
+// pays for one by one). 4096 envs 1005 -> 1033 M env steps/s, 1 M 11.3 -> 11.8 G; Tennisbot gains nothing at 4096 envs and loses 2.6 %
+// at 1 M: it keeps the 64-bit form. tb_create bounds n_envs so that the largest offset (30 rows x n x 4 bytes) fits 32 bits.
+template <bool OFF32>
+TB_DEV uint32_t row_word(const uint32_t* w, int row, int n, int i) {
+  if constexpr (OFF32) {
+    const uint32_t byte = ((uint32_t)row * (uint32_t)n + (uint32_t)i) * 4u;
+    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(w) + byte);
+  } else return w[(size_t)row * n + i];
+}
+template <bool OFF32>
+TB_DEV void row_store(uint32_t* w, int row, int n, int i, uint32_t v) {
+  if constexpr (OFF32) {
+    const uint32_t byte = ((uint32_t)row * (uint32_t)n + (uint32_t)i) * 4u;
+    *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(w) + byte) = v;
+  } else w[(size_t)row * n + i] = v;
+}
+#ifdef TB_AB_ROWS_64BIT
+template <int KIND> constexpr bool off32() { return false; }
+#else
+template <int KIND> constexpr bool off32() { return KIND == TB_ENV_SWING; }
+#endif
+template <int KIND> TB_DEV float ld(const uint32_t* w, int row, int n, int i) { return __uint_as_float(row_word<off32<KIND>()>(w, row, n, i)); }
+template <int KIND> TB_DEV void st(uint32_t* w, int row, int n, int i, float v) { row_store<off32<KIND>()>(w, row, n, i, __float_as_uint(v)); }
 
 template <int KIND>
 TB_DEV void load_env(const uint32_t* w, const uint8_t* done_state, int n, int i, EnvRegs& e) {
-  e.r.p = mk(ld(w, TB_W_RP, n, i), ld(w, TB_W_RP + 1, n, i), ld(w, TB_W_RP + 2, n, i));
-  e.r.q.x = ld(w, TB_W_RQ, n, i); e.r.q.y = ld(w, TB_W_RQ + 1, n, i); e.r.q.z = ld(w, TB_W_RQ + 2, n, i); e.r.q.w = ld(w, TB_W_RQ + 3, n, i);
-  e.r.v = mk(ld(w, TB_W_RV, n, i), ld(w, TB_W_RV + 1, n, i), ld(w, TB_W_RV + 2, n, i));
-  e.r.w = mk(ld(w, TB_W_RW, n, i), ld(w, TB_W_RW + 1, n, i), ld(w, TB_W_RW + 2, n, i));
-  e.b.p = mk(ld(w, TB_W_BP, n, i), ld(w, TB_W_BP + 1, n, i), ld(w, TB_W_BP + 2, n, i));
-  e.b.v = mk(ld(w, TB_W_BV, n, i), ld(w, TB_W_BV + 1, n, i), ld(w, TB_W_BV + 2, n, i));
-  e.b.w = mk(ld(w, TB_W_BW, n, i), ld(w, TB_W_BW + 1, n, i), ld(w, TB_W_BW + 2, n, i));
+  e.r.p = mk(ld<KIND>(w, TB_W_RP, n, i), ld<KIND>(w, TB_W_RP + 1, n, i), ld<KIND>(w, TB_W_RP + 2, n, i));
+  e.r.q.x = ld<KIND>(w, TB_W_RQ, n, i); e.r.q.y = ld<KIND>(w, TB_W_RQ + 1, n, i); e.r.q.z = ld<KIND>(w, TB_W_RQ + 2, n, i); e.r.q.w = ld<KIND>(w, TB_W_RQ + 3, n, i);
+  e.r.v = mk(ld<KIND>(w, TB_W_RV, n, i), ld<KIND>(w, TB_W_RV + 1, n, i), ld<KIND>(w, TB_W_RV + 2, n, i));
+  e.r.w = mk(ld<KIND>(w, TB_W_RW, n, i), ld<KIND>(w, TB_W_RW + 1, n, i), ld<KIND>(w, TB_W_RW + 2, n, i));
+  e.b.p = mk(ld<KIND>(w, TB_W_BP, n, i), ld<KIND>(w, TB_W_BP + 1, n, i), ld<KIND>(w, TB_W_BP + 2, n, i));
+  e.b.v = mk(ld<KIND>(w, TB_W_BV, n, i), ld<KIND>(w, TB_W_BV + 1, n, i), ld<KIND>(w, TB_W_BV + 2, n, i));
+  e.b.w = mk(ld<KIND>(w, TB_W_BW, n, i), ld<KIND>(w, TB_W_BW + 1, n, i), ld<KIND>(w, TB_W_BW + 2, n, i));
 #pragma unroll
-  for (int k = 0; k < 6; ++k) e.aux[k] = k < Dims<KIND>::NAUX ? ld(w, 22 + k, n, i) : 0.0f;
-  e.step_count = (int)w[(size_t)(Dims<KIND>::W - 2) * n + i];
-  e.episode = w[(size_t)(Dims<KIND>::W - 1) * n + i];
+  for (int k = 0; k < 6; ++k) e.aux[k] = k < Dims<KIND>::NAUX ? ld<KIND>(w, 22 + k, n, i) : 0.0f;
+  e.step_count = (int)row_word<off32<KIND>()>(w, Dims<KIND>::W - 2, n, i);
+  e.episode = row_word<off32<KIND>()>(w, Dims<KIND>::W - 1, n, i);
   e.done = done_state[i];
 }
 
 // `all`: also the rows that only change on reset (goal / spawn / d0 / shoot force / episode)
 template <int KIND>
 TB_DEV void store_env(uint32_t* w, uint8_t* done_state, int n, int i, const EnvRegs& e, bool all) {
-  st(w, TB_W_RP, n, i, e.r.p.x); st(w, TB_W_RP + 1, n, i, e.r.p.y); st(w, TB_W_RP + 2, n, i, e.r.p.z);
-  st(w, TB_W_RQ, n, i, e.r.q.x); st(w, TB_W_RQ + 1, n, i, e.r.q.y); st(w, TB_W_RQ + 2, n, i, e.r.q.z); st(w, TB_W_RQ + 3, n, i, e.r.q.w);
-  st(w, TB_W_RV, n, i, e.r.v.x); st(w, TB_W_RV + 1, n, i, e.r.v.y); st(w, TB_W_RV + 2, n, i, e.r.v.z);
-  st(w, TB_W_RW, n, i, e.r.w.x); st(w, TB_W_RW + 1, n, i, e.r.w.y); st(w, TB_W_RW + 2, n, i, e.r.w.z);
-  st(w, TB_W_BP, n, i, e.b.p.x); st(w, TB_W_BP + 1, n, i, e.b.p.y); st(w, TB_W_BP + 2, n, i, e.b.p.z);
-  st(w, TB_W_BV, n, i, e.b.v.x); st(w, TB_W_BV + 1, n, i, e.b.v.y); st(w, TB_W_BV + 2, n, i, e.b.v.z);
-  st(w, TB_W_BW, n, i, e.b.w.x); st(w, TB_W_BW + 1, n, i, e.b.w.y); st(w, TB_W_BW + 2, n, i, e.b.w.z);
+  st<KIND>(w, TB_W_RP, n, i, e.r.p.x); st<KIND>(w, TB_W_RP + 1, n, i, e.r.p.y); st<KIND>(w, TB_W_RP + 2, n, i, e.r.p.z);
+  st<KIND>(w, TB_W_RQ, n, i, e.r.q.x); st<KIND>(w, TB_W_RQ + 1, n, i, e.r.q.y); st<KIND>(w, TB_W_RQ + 2, n, i, e.r.q.z); st<KIND>(w, TB_W_RQ + 3, n, i, e.r.q.w);
+  st<KIND>(w, TB_W_RV, n, i, e.r.v.x); st<KIND>(w, TB_W_RV + 1, n, i, e.r.v.y); st<KIND>(w, TB_W_RV + 2, n, i, e.r.v.z);
+  st<KIND>(w, TB_W_RW, n, i, e.r.w.x); st<KIND>(w, TB_W_RW + 1, n, i, e.r.w.y); st<KIND>(w, TB_W_RW + 2, n, i, e.r.w.z);
+  st<KIND>(w, TB_W_BP, n, i, e.b.p.x); st<KIND>(w, TB_W_BP + 1, n, i, e.b.p.y); st<KIND>(w, TB_W_BP + 2, n, i, e.b.p.z);
+  st<KIND>(w, TB_W_BV, n, i, e.b.v.x); st<KIND>(w, TB_W_BV + 1, n, i, e.b.v.y); st<KIND>(w, TB_W_BV + 2, n, i, e.b.v.z);
+  st<KIND>(w, TB_W_BW, n, i, e.b.w.x); st<KIND>(w, TB_W_BW + 1, n, i, e.b.w.y); st<KIND>(w, TB_W_BW + 2, n, i, e.b.w.z);
   if (all) {
 #pragma unroll
-    for (int k = 0; k < Dims<KIND>::NAUX; ++k) st(w, 22 + k, n, i, e.aux[k]);
-    w[(size_t)(Dims<KIND>::W - 1) * n + i] = e.episode;
+    for (int k = 0; k < Dims<KIND>::NAUX; ++k) st<KIND>(w, 22 + k, n, i, e.aux[k]);
+    row_store<off32<KIND>()>(w, Dims<KIND>::W - 1, n, i, e.episode);
   }
-  w[(size_t)(Dims<KIND>::W - 2) * n + i] = (uint32_t)e.step_count;
+  row_store<off32<KIND>()>(w, Dims<KIND>::W - 2, n, i, (uint32_t)e.step_count);
   done_state[i] = (uint8_t)e.done;
 }
 
@@ -1553,7 +1577,7 @@ int tb_create(const TbParams* params, const TbOptions* options, int env_kind, in
   if (!params || !out) return fail(TB_E_INVAL, "tb_create: null argument");
   *out = nullptr;
   if (!kind_ok(env_kind)) return fail(TB_E_INVAL, "tb_create: unknown env kind");
-  if (n_envs <= 0 || n_envs > (1 << 26)) return fail(TB_E_INVAL, "tb_create: n_envs must be in [1, 2^26]");
+  if (n_envs <= 0 || n_envs > (1 << 25)) return fail(TB_E_INVAL, "tb_create: n_envs must be in [1, 2^25]");  // (32-bit row offsets: see row_word)
   if (int rc = validate_params(params)) return rc;
   TbOptions opt;
   memset(&opt, 0, sizeof opt);
