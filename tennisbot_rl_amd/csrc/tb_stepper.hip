@@ -1205,6 +1205,9 @@ int ensure_marks(TbHandle* h) {
 // i.e. 128 everywhere but for SwingRacket between 64 K and 128 K envs, where one wave per workgroup wins by 2-6 %.
 int pick_block(int kind, int n, const TbOptions& o) {
   if (o.block == 64 || o.block == 128 || o.block == 256) return o.block;
+  // (round 3, final build, no barrier left in the one-substep kernels: one-wave workgroups win up to 16384 envs -- SwingRacket 4096 envs
+  //  1052 against 1033 M env steps/s, 16384: 3.07 / 3.01 G, Tennisbot 4096: 738 / 733 M, 8192: 1.24 / 1.23 G; 32768: 5.65 / 5.68 and 3.78 / 3.82 G)
+  if (n <= 16384) return 64;
   return kind == TB_ENV_SWING && n >= 49152 && n <= 131072 ? 64 : 128;
 }
 

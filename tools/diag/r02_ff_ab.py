@@ -85,6 +85,20 @@ def main():
         for n in (65536, 131072, 262144):
             for o in (dict(ff_phases=1), dict(ff_phases=2), dict(ff_phases=3)):
                 out.append(measure(n, 104, o, reps=3, flags=flags)); print(json.dumps(out[-1]), flush=True)
+    if which == "blocks4096":  # workgroup size of the step kernels at the headline batch size (and Tennisbot's)
+        from tennisbot_rl_amd.params import ENV_TENNIS
+        for o in (dict(block=64), dict(block=128), dict(block=256), dict(block=64), dict(block=128)):
+            out.append(measure(4096, 1040, o, flags=flags)); print(json.dumps(out[-1]), flush=True)
+        for o in (dict(block=64), dict(block=128), dict(block=256), dict(block=64), dict(block=128)):
+            out.append(measure(4096, 1040, o, flags=flags, kind=ENV_TENNIS)); print(json.dumps(out[-1]), flush=True)
+    if which == "blocks_ladder":
+        from tennisbot_rl_amd.params import ENV_TENNIS
+        for n in (1024, 8192, 16384, 32768, 65536):
+            for o in (dict(block=64), dict(block=128), dict(block=64), dict(block=128)):
+                out.append(measure(n, 1040 if n <= 32768 else 104, o, reps=3, flags=flags)); print(json.dumps(out[-1]), flush=True)
+        for n in (8192, 32768):
+            for o in (dict(block=64), dict(block=128), dict(block=64), dict(block=128)):
+                out.append(measure(n, 1040, o, reps=3, flags=flags, kind=ENV_TENNIS)); print(json.dumps(out[-1]), flush=True)
     if which == "one":
         for o in ({}, {}, {}):
             out.append(measure(4096, 1040, o, flags=flags)); print(json.dumps(out[-1]), flush=True)
