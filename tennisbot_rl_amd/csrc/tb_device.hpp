@@ -235,6 +235,9 @@ TB_DEV bool racket_cull(const KParams& P, const float4* hull, vec3 dl, float s, 
 // TB_SWEEP_HELPERS-th edge each -- the very same arithmetic per edge -- and the asking lane combines their partial results by
 // the sequential loop's own rule (smallest distance / largest signed distance, lowest edge index on ties), read from the
 // helpers by cross-lane shuffles. Bit-identical to the one-lane loop; ~6 x shorter.
+#ifndef TB_SWEEP_COOP_BRANCHES
+#define TB_SWEEP_COOP_BRANCHES 0  // (1: A/B builds with the branching edge test in the helpers' loop)
+#endif
 constexpr int TB_SWEEP_HELPERS = TB_DIAG_SWEEP_HELPERS;  // 8 (tb_diag.hpp; 4 / 16 measured: 8.81 / 8.57 G vs 8.80 G env steps/s at 1 M envs)
 struct SweepOut { float best_d2, best_ry, best_rz, max_sd; int deep_edge; bool inside; };
 TB_DEV SweepOut outline_sweep(const float4* hull, int n_hull, bool need, float qy, float qz) {
@@ -256,6 +259,7 @@ TB_DEV SweepOut outline_sweep(const float4* hull, int n_hull, bool need, float q
         float wy = py - e0.x, wz = pz - e0.y;
         float cr = FMA(e0.z, wz, -(e0.w * wy));
         float sd = -(cr * e1.y);
+#if TB_SWEEP_COOP_BRANCHES
         if (sd > msd) { msd = sd; di = i; }
         // the closest boundary point of a convex outline lies on an edge that faces the point
         // (cr < 0); edges seen from behind cannot hold it and are skipped
@@ -267,6 +271,18 @@ TB_DEV SweepOut outline_sweep(const float4* hull, int n_hull, bool need, float q
           float d2 = FMA(ry, ry, rz * rz);
           if (d2 < bd2) { bd2 = d2; bry = ry; brz = rz; bi = i; }
         }
+#else  // without branches, like sweep_edge below: the helpers hold different edges, so some lane nearly always faces its edge anyway
+        const bool deeper = sd > msd;
+        msd = deeper ? sd : msd; di = deeper ? i : di;
+        const bool faces = cr < 0.0f;
+        float t = FMA(wy, e0.z, wz * e0.w) * e1.x;
+        t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+        float ry = FMA(-t, e0.z, wy), rz = FMA(-t, e0.w, wz);
+        float d2 = FMA(ry, ry, rz * rz);
+        const bool closer = faces & (d2 < bd2);
+        ins = faces ? 0 : ins;
+        bd2 = closer ? d2 : bd2; bry = closer ? ry : bry; brz = closer ? rz : brz; bi = closer ? i : bi;
+#endif
       }
     }
     // combine the helpers' partials (every lane runs the shuffles; only lane `src` keeps the result)
@@ -290,10 +306,46 @@ TB_DEV SweepOut outline_sweep(const float4* hull, int n_hull, bool need, float q
   return mine;
 }
 
-// the same sweep by one lane for itself (every instantiation but the large-batch fast-forward, see substep)
+// the same sweep by one lane for itself (every instantiation but the large-batch fast-forward, see substep).
+// One edge, WITHOUT branches: the closest-point arithmetic of an edge seen from behind (cr >= 0) is done and thrown away by the
+// selects -- the values kept, and every operation that produced them, are those of the branching form (the cooperative sweep
+// above and the oracle still have it): bit-identical.
+#ifndef TB_SWEEP_CHUNK
+#define TB_SWEEP_CHUNK 4  // (0: A/B builds with the one-edge-per-trip branching loop)
+#endif
+struct EdgeRec { float4 e0; float2 e1; };  // {a.y a.z e.y e.z}, {1/|e|^2 1/|e|}
+TB_DEV EdgeRec outline_edge(const float4* hull, int i) {
+  EdgeRec r;
+  r.e0 = hull[2 * i];
+  r.e1 = *reinterpret_cast<const float2*>(hull + 2 * i + 1);
+  return r;
+}
+TB_DEV void sweep_edge(SweepOut& o, int i, const EdgeRec& r, float py, float pz) {
+  const float4 e0 = r.e0;
+  float wy = py - e0.x, wz = pz - e0.y;
+  float cr = FMA(e0.z, wz, -(e0.w * wy));
+  float sd = -(cr * r.e1.y);
+  const bool deeper = sd > o.max_sd;
+  o.max_sd = deeper ? sd : o.max_sd; o.deep_edge = deeper ? i : o.deep_edge;
+  const bool faces = cr < 0.0f;
+  float t = FMA(wy, e0.z, wz * e0.w) * r.e1.x;
+  t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+  float ry = FMA(-t, e0.z, wy), rz = FMA(-t, e0.w, wz);
+  float d2 = FMA(ry, ry, rz * rz);
+  const bool closer = faces & (d2 < o.best_d2);
+  o.inside = o.inside & !faces;
+  o.best_d2 = closer ? d2 : o.best_d2; o.best_ry = closer ? ry : o.best_ry; o.best_rz = closer ? rz : o.best_rz;
+}
+// The branching loop was 38 DEPENDENT trips: read an edge, wait, test, branch, read the rest of it, wait (~12 k cycles for a lone
+// wave by in-kernel stamps, two thirds of it waiting for the table). Here the records of four edges are requested together and
+// evaluated side by side: a quarter of the waits, and four independent chains for the scheduler.
+// (Also tried: the NEXT four records requested before the present four are evaluated. Written plainly the compiler folds "this
+//  trip's records = the last trip's reads" back into reads at the top of the trip; pinned by a compiler barrier it measures +2 % at
+//  4096 envs and -15 % at 32768, where the barrier also keeps the fast-forward loop from hoisting its cull planes.)
 TB_DEV SweepOut outline_sweep_serial(const float4* hull, int n_hull, float py, float pz) {
   SweepOut o;
   o.best_d2 = 3.0e38f; o.best_ry = 0.0f; o.best_rz = 0.0f; o.max_sd = -3.0e38f; o.deep_edge = 0; o.inside = true;
+#if TB_SWEEP_CHUNK == 0
   for (int i = 0; i < n_hull; ++i) {
     const float4 e0 = hull[2 * i], e1 = hull[2 * i + 1];
     float wy = py - e0.x, wz = pz - e0.y;
@@ -309,6 +361,20 @@ TB_DEV SweepOut outline_sweep_serial(const float4* hull, int n_hull, float py, f
       if (d2 < o.best_d2) { o.best_d2 = d2; o.best_ry = ry; o.best_rz = rz; }
     }
   }
+#else
+  constexpr int C = TB_SWEEP_CHUNK;
+  const int whole = n_hull - n_hull % C;
+#pragma unroll 1
+  for (int i = 0; i < whole; i += C) {
+    EdgeRec r[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) r[k] = outline_edge(hull, i + k);
+#pragma unroll
+    for (int k = 0; k < C; ++k) sweep_edge(o, i + k, r[k], py, pz);
+  }
+#pragma unroll 1
+  for (int i = whole; i < n_hull; ++i) sweep_edge(o, i, outline_edge(hull, i), py, pz);
+#endif
   return o;
 }
 

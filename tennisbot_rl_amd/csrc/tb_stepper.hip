@@ -524,6 +524,9 @@ namespace {
 #ifndef TB_LAZY_TABLE
 #define TB_LAZY_TABLE 1  // (0: A/B builds that copy the table in every launch of the pipelined SwingRacket step kernel)
 #endif
+#ifndef TB_AB_SEP_SWING
+#define TB_AB_SEP_SWING 0  // (1: A/B builds in which SwingRacket's step kernels read the leading kernel arguments too)
+#endif
 #ifndef TB_TABLE_IN_MEMORY
 #define TB_TABLE_IN_MEMORY 1  // (0: A/B builds with the LDS copy in every kernel)
 #endif
@@ -550,7 +553,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
   const int i = POLICY ? blockIdx.x * 64 + (threadIdx.x & 63) : blockIdx.x * blockDim.x + threadIdx.x;
   // measured at 4096 envs: Tennisbot +5.6 % (687 -> 726 M env steps/s); SwingRacket -6 % if it uses them too
   // (its kernels sit at the SGPR limit), so SwingRacket keeps reading the struct
-  constexpr bool SEP = KIND == TB_ENV_TENNIS;
+  constexpr bool SEP = KIND == TB_ENV_TENNIS || TB_AB_SEP_SWING;
   const uint32_t* __restrict__ w_words = SEP ? k_words : A.words;
   const uint8_t* __restrict__ w_done = SEP ? k_done : A.done_state;
   const float* __restrict__ w_actions = SEP ? k_actions : A.actions;  // (SwingRacket: the compiler loads this pointer inside the `live` branch, a

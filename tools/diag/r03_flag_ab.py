@@ -17,6 +17,18 @@ if len(sys.argv) > 2 and sys.argv[1] == "--child":
     from tennisbot_rl_amd.rollout import RolloutBuffer
     from tennisbot_rl_amd.stepper import BatchedEnv
     dev = torch.device("cuda", 0)
+    if what.startswith("collect_"):  # a PPO collect of 1100 x 4096 (policy inside the rollout kernel): untrained, or the reference's trained policy
+        import numpy as np
+        from tennisbot_rl_amd.ppo import PPOTrainer
+        tr = PPOTrainer("SwingRacket-v0", num_envs=4096, n_steps=1100, seed=0)
+        if what == "collect_ref":
+            tr.policy.load_sb3_arrays(dict(np.load(os.path.join(ROOT, "tests", "golden", "ppo_swing_policy.npz"))))
+        for _ in range(20): tr.collect()
+        ts = []
+        for _ in range(15):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); tr.collect(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        ts.sort()
+        print(json.dumps({"rate_M": round(4096 * 1100 / ts[len(ts) // 2] / 1e6, 1)})); sys.exit(0)
     opts = {}
     if what.endswith("_ldsrows"):  # (the step kernel with its static rows in LDS: 103 instead of 154 VGPRs)
         what, opts = what[:-len("_ldsrows")], dict(swing_reg_rows=False)
