@@ -27,7 +27,9 @@ __global__ void __launch_bounds__(64) step_like(const float* __restrict__ src, f
 // the same launch with its arguments the way tb_step_kernel gets them: one 616-byte struct by value, the pointers in its middle, and
 // (STAGE) a 2.5 KB table copied to LDS behind a barrier before anything is computed
 struct Big { float pad0[70]; const float* src; float* dst; int n, lanes; float pad1[76]; const float4* table; };
-template <int R, int W, bool STAGE>
+// KW: how many of the struct's padding words the launch reads (scalar loads from the kernel-argument segment, all of them
+// needed before the first store): does a lone wave wait for its ARGUMENTS? (tb_step_kernel fetches 50-60 words of TbParams)
+template <int R, int W, bool STAGE, int KW = 2>
 __global__ void __launch_bounds__(64) step_like_big(Big A) {
   __shared__ float4 s_tab[160];
   const int lane = threadIdx.x;
@@ -39,6 +41,10 @@ __global__ void __launch_bounds__(64) step_like_big(Big A) {
     for (int r = 0; r < R; ++r) v[r] = A.src[(size_t)r * A.n + i];
   }
   float extra = A.pad0[3] + A.pad1[70];
+  if (KW > 2) {
+#pragma unroll
+    for (int k = 0; k < KW / 2; ++k) extra += A.pad0[k % 70] * 1e-30f + A.pad1[k % 76] * 1e-30f;
+  }
   if (STAGE) {
     for (int k = threadIdx.x; k < 160; k += 64) s_tab[k] = A.table[k];
     __syncthreads();
@@ -52,7 +58,7 @@ __global__ void __launch_bounds__(64) step_like_big(Big A) {
   for (int r = 0; r < W; ++r) A.dst[(size_t)r * A.n + i] = v[r] + acc * 1e-9f;
 }
 
-template <bool STAGE>
+template <bool STAGE, int KW = 2>
 void run_big(hipStream_t s, float* a, float* b, const float4* table, int N, int T, const char* label) {
   constexpr int R = 36, W = 30;
   hipGraph_t g; hipGraphExec_t ge;
@@ -60,7 +66,7 @@ void run_big(hipStream_t s, float* a, float* b, const float4* table, int N, int 
   for (int t = 0; t < T; ++t) {
     Big A = {};
     A.src = t % 2 ? b : a; A.dst = t % 2 ? a : b; A.n = N; A.lanes = 64; A.table = table;
-    hipLaunchKernelGGL((step_like_big<R, W, STAGE>), dim3(N / 64), dim3(64), 0, s, A);
+    hipLaunchKernelGGL((step_like_big<R, W, STAGE, KW>), dim3(N / 64), dim3(64), 0, s, A);
   }
   CHECK(hipStreamEndCapture(s, &g)); CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
   for (int k = 0; k < 50; ++k) CHECK(hipGraphLaunch(ge, s));
@@ -104,5 +110,9 @@ int main() {
   run_big<false>(s, a, b, table, N, T, "616-byte argument struct, 64 full waves");
   run_big<true>(s, a, b, table, N, T, "616-byte argument struct + 2.5 KB table staged into LDS behind a barrier");
   run_big<false>(s, a, b, table, N, T, "616-byte argument struct, 64 full waves");
+  run_big<false, 32>(s, a, b, table, N, T, "... 32 argument words read");
+  run_big<false, 64>(s, a, b, table, N, T, "... 64 argument words read");
+  run_big<false, 140>(s, a, b, table, N, T, "... 140 argument words read");
+  run_big<false, 2>(s, a, b, table, N, T, "... 2 argument words read");
   return 0;
 }
