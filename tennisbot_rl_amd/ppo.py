@@ -146,7 +146,7 @@ class PPOTrainer:
     """clipped-surrogate PPO over a BatchedEnv; one process per GPU when distributed"""
 
     def __init__(self, env_id="SwingRacket-v0", num_envs=4096, n_steps=104, device=None, seed=0, batch_size=None,
-                 pipeline=True, graph=True, fused=True, rollout_launch=True, params=None, ff_defer="all", **hp):
+                 pipeline=True, graph=True, fused=True, rollout_launch=True, params=None, ff_defer="all", options=None, **hp):
         import torch
         self.torch = torch
         kind = ENV_IDS[env_id]
@@ -159,12 +159,13 @@ class PPOTrainer:
         self.rank = dist.get_rank() if self.world > 1 else 0
         # params: a TbParams (default_params(flags=..., **overrides)), e.g. the reference's full contact set
         # (TB_F_RACKET_GROUND, rolling friction): the fused policy kernels are instantiated for it too
+        # options: further TbOptions fields for the env (make_options: e.g. policy_slices)
         # ff_defer: a trained policy's struck balls fly 300-775 substeps, and at most four fast-forward kernels run at once: the
         # collect was bound by them (229 M env steps/s with the reference's policy). "all": every episode end of a rollout is
         # parked into one pool that a single launch finishes at the join -- the rollout kernels run undisturbed, the long flights
         # side by side (TbOptions.ff_defer = 2; same results). Up to 64 episodes per join: beyond, the ordinary path takes over.
         self.env = BatchedEnv(kind, num_envs, device=device, seed=seed, env_id_base=self.rank * num_envs, params=params,
-                              track_terminal_obs=False, pipeline=pipeline and kind == ENV_SWING, options=dict(ff_defer=ff_defer))
+                              track_terminal_obs=False, pipeline=pipeline and kind == ENV_SWING, options=dict(options or {}, ff_defer=ff_defer))
         self.device = self.env.device
         self.n_steps, self.num_envs = int(n_steps), int(num_envs)
         self.buf = RolloutBuffer(kind, self.n_steps, num_envs, self.device).bind(self.env)

@@ -20,8 +20,8 @@ if len(sys.argv) > 2 and sys.argv[1] == "--child":
     if what.startswith("collect_"):  # a PPO collect of 1100 x 4096 (policy inside the rollout kernel): untrained, or the reference's trained policy
         import numpy as np
         from tennisbot_rl_amd.ppo import PPOTrainer
-        tr = PPOTrainer("SwingRacket-v0", num_envs=4096, n_steps=1100, seed=0)
-        if what == "collect_ref":
+        tr = PPOTrainer("SwingRacket-v0", num_envs=4096, n_steps=1100, seed=0, options=dict(policy_slices=3) if what.endswith("_s3") else None)
+        if what.startswith("collect_ref"):
             tr.policy.load_sb3_arrays(dict(np.load(os.path.join(ROOT, "tests", "golden", "ppo_swing_policy.npz"))))
         for _ in range(20): tr.collect()
         ts = []
