@@ -308,8 +308,8 @@ TB_DEV SweepOut outline_sweep(const float4* hull, int n_hull, bool need, float q
 
 // the same sweep by one lane for itself (every instantiation but the large-batch fast-forward, see substep).
 // One edge, WITHOUT branches: the closest-point arithmetic of an edge seen from behind (cr >= 0) is done and thrown away by the
-// selects -- the values kept, and every operation that produced them, are those of the branching form (the cooperative sweep
-// above and the oracle still have it): bit-identical.
+// selects -- the values kept, and every operation that produced them, are those of the branching form (the oracle still has
+// it, and the TB_SWEEP_CHUNK == 0 build below): bit-identical.
 #ifndef TB_SWEEP_CHUNK
 #define TB_SWEEP_CHUNK 4  // (0: A/B builds with the one-edge-per-trip branching loop)
 #endif
