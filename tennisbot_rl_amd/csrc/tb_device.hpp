@@ -235,9 +235,6 @@ TB_DEV bool racket_cull(const KParams& P, const float4* hull, vec3 dl, float s, 
 // TB_SWEEP_HELPERS-th edge each -- the very same arithmetic per edge -- and the asking lane combines their partial results by
 // the sequential loop's own rule (smallest distance / largest signed distance, lowest edge index on ties), read from the
 // helpers by cross-lane shuffles. Bit-identical to the one-lane loop; ~6 x shorter.
-#ifndef TB_SWEEP_COOP_BRANCHES
-#define TB_SWEEP_COOP_BRANCHES 0  // (1: A/B builds with the branching edge test in the helpers' loop)
-#endif
 constexpr int TB_SWEEP_HELPERS = TB_DIAG_SWEEP_HELPERS;  // 8 (tb_diag.hpp; 4 / 16 measured: 8.81 / 8.57 G vs 8.80 G env steps/s at 1 M envs)
 struct SweepOut { float best_d2, best_ry, best_rz, max_sd; int deep_edge; bool inside; };
 TB_DEV SweepOut outline_sweep(const float4* hull, int n_hull, bool need, float qy, float qz) {
@@ -259,7 +256,6 @@ TB_DEV SweepOut outline_sweep(const float4* hull, int n_hull, bool need, float q
         float wy = py - e0.x, wz = pz - e0.y;
         float cr = FMA(e0.z, wz, -(e0.w * wy));
         float sd = -(cr * e1.y);
-#if TB_SWEEP_COOP_BRANCHES
         if (sd > msd) { msd = sd; di = i; }
         // the closest boundary point of a convex outline lies on an edge that faces the point
         // (cr < 0); edges seen from behind cannot hold it and are skipped
@@ -271,18 +267,6 @@ TB_DEV SweepOut outline_sweep(const float4* hull, int n_hull, bool need, float q
           float d2 = FMA(ry, ry, rz * rz);
           if (d2 < bd2) { bd2 = d2; bry = ry; brz = rz; bi = i; }
         }
-#else  // without branches, like sweep_edge below: the helpers hold different edges, so some lane nearly always faces its edge anyway
-        const bool deeper = sd > msd;
-        msd = deeper ? sd : msd; di = deeper ? i : di;
-        const bool faces = cr < 0.0f;
-        float t = FMA(wy, e0.z, wz * e0.w) * e1.x;
-        t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
-        float ry = FMA(-t, e0.z, wy), rz = FMA(-t, e0.w, wz);
-        float d2 = FMA(ry, ry, rz * rz);
-        const bool closer = faces & (d2 < bd2);
-        ins = faces ? 0 : ins;
-        bd2 = closer ? d2 : bd2; bry = closer ? ry : bry; brz = closer ? rz : brz; bi = closer ? i : bi;
-#endif
       }
     }
     // combine the helpers' partials (every lane runs the shuffles; only lane `src` keeps the result)
@@ -309,7 +293,8 @@ TB_DEV SweepOut outline_sweep(const float4* hull, int n_hull, bool need, float q
 // the same sweep by one lane for itself (every instantiation but the large-batch fast-forward, see substep).
 // One edge, WITHOUT branches: the closest-point arithmetic of an edge seen from behind (cr >= 0) is done and thrown away by the
 // selects -- the values kept, and every operation that produced them, are those of the branching form (the oracle still has
-// it, and the TB_SWEEP_CHUNK == 0 build below): bit-identical.
+// it, and the TB_SWEEP_CHUNK == 0 build below): bit-identical. (The helpers' loop of the cooperative sweep above keeps its branch:
+// without it the survivor kernels of a 1 M-env fast-forward issue 7 % more vector instructions and nothing gets faster.)
 #ifndef TB_SWEEP_CHUNK
 #define TB_SWEEP_CHUNK 4  // (0: A/B builds with the one-edge-per-trip branching loop)
 #endif
