@@ -1173,10 +1173,13 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
       if (near_racket) past_slab = racket_slab<KIND == TB_ENV_TENNIS>(P, lp, scale, ql, qax);
       if (__any(past_slab)) {  // the first reader of the table in this launch: this wave copies it (another wave of the workgroup may be
                                // writing the same values to the same places)
+        // (shared among the lanes that are HERE: the last wave of a batch that is no multiple of 64 has fewer than 64, and a copy
+        //  strided by 64 left the entries of its missing lanes unwritten -- found by test_outline_sweep_with_other_outlines)
         float4* dst = const_cast<float4*>(hull);
-        const int lane = (int)(threadIdx.x & 63);
-        for (int k = lane; k < 2 * P.n_hull; k += 64) dst[k] = table_mem[k];
-        for (int k = TB_HULL_PLANES + lane; k < TB_HULL_LDS; k += 64) dst[k] = table_mem[k];
+        const unsigned long long here = __ballot(1);
+        const int lane = (int)(threadIdx.x & 63), na = __popcll(here), rank = __popcll(here & ((1ull << lane) - 1ull));
+        for (int k = rank; k < 2 * P.n_hull; k += na) dst[k] = table_mem[k];
+        for (int k = TB_HULL_PLANES + rank; k < TB_HULL_LDS; k += na) dst[k] = table_mem[k];
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // every lane's writes are in LDS before any lane reads another's
         if (past_slab) {
           TB_LANES_ADD1(12);

@@ -1186,6 +1186,72 @@ def test_fast_forward_with_balls_thrown_at_a_spinning_racket(torch, n, options):
     env.close()
 
 
+def with_outline(p, n_edges, radius_y=0.13, radius_z=0.33):
+    """`p` with another racket outline: a convex n-gon (an ellipse sampled at uneven angles), CCW in (y, z) about the COM, with the
+    fields params.default_params derives from the outline set the same way"""
+    from tennisbot_rl_amd.params import hull_edge_table
+    rng = np.random.default_rng(100 + n_edges)
+    ang = np.sort((np.arange(n_edges) + rng.uniform(-0.3, 0.3, n_edges)) * (2.0 * np.pi / n_edges))
+    verts = np.stack([radius_y * np.cos(ang), radius_z * np.sin(ang)], 1)
+    rec = hull_edge_table(verts, (0.0, 0.0), 1.0)
+    q = p.copy()
+    q.n_hull = n_edges
+    e = np.ctypeslib.as_array(q.hull_edges)
+    e[:] = 0.0
+    e[:n_edges] = rec
+    vmax = float(np.sqrt((rec[:, :2].astype(np.float64) ** 2).sum(1).max() + float(q.racket_half_thick) ** 2))
+    q.hull_bound_radius = vmax * 1.0001
+    q.racket_ground_threshold = 0.02 * vmax
+    return q
+
+
+@pytest.mark.parametrize("n_edges", [3, 4, 5, 8, 11, 38, 40, 48, 56, 60, 62, 63, 64])
+def test_outline_sweep_with_other_outlines(torch, n_edges):
+    """the outline sweep takes four edges per trip and the rest one by one: outlines of 3 (no whole trip), 4 and 8 (no rest), 5 and
+    11 edges and the largest the table holds, 64 -- balls thrown at spinning rackets as above, through the step kernels (a ball
+    next to the racket during the 25 short steps) and both forms of the fast-forward, bit for bit against the oracle"""
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    n = 3000
+    for options in (dict(ff_defer="all"), dict(ff_defer=False)):
+        rng = np.random.default_rng(77 + n_edges)
+        p = with_outline(default_params(), n_edges)
+        env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=5, params=p, pipeline=True, track_terminal_obs=False, options=options)
+        pf = p.copy(); pf.flags |= F_AUTO_RESET
+        ref = OracleBatch(pf, ENV_SWING, n, seed=5, precision="f32")
+        ref.L.tbo_set_threads(ref.h, 16)
+        q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+        rp = np.stack([rng.uniform(8, 10, n), rng.uniform(-2, 2, n), rng.uniform(1.5, 4.0, n)], 1)
+        rv = rng.uniform(-1.5, 1.5, (n, 3))
+        u = rng.normal(size=(n, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+        dist = rng.uniform(0.1, 0.9, n)  # from inside the bounding sphere to well outside it
+        bp = rp + u * dist[:, None]
+        bp[:, 2] = np.maximum(bp[:, 2], 0.3)
+        tof = rng.uniform(0.02, 0.3, n)
+        target = rp + rv * tof[:, None] + np.array([0.0, 0.0, -0.5 * 9.81])[None, :] * (tof ** 2)[:, None]
+        bv = (target - bp) / tof[:, None] + np.array([0.0, 0.0, 0.5 * 9.81])[None, :] * tof[:, None] + rng.normal(scale=0.3, size=(n, 3))
+        step0 = 12  # half of the envs' balls arrive during the short steps 13..25, the others in the fast-forward
+        fields = dict(racket_pos=rp, racket_quat=q, racket_vel=rv, racket_angvel=rng.uniform(-9, 9, (n, 3)), ball_pos=bp, ball_vel=bv,
+                      ball_angvel=rng.uniform(-30, 30, (n, 3)), goal=np.stack([rng.uniform(-11, -4, n), rng.uniform(-4, 4, n)], 1), spawn_pos=(9, 0, 0.6),
+                      init_dist=rng.uniform(8, 20, n), step_count=step0)
+        w, d = make_words(ENV_SWING, n, **fields)
+        env.set_state_words(torch.from_numpy(w.view(np.int32)).cuda(), torch.from_numpy(d).cuda()); ref.set_state_words(w, d)
+        assert env.phase() == step0
+        outs = []
+        for t in range(26 - step0 + 26):
+            a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
+            obs, rew, done = env.step(torch.from_numpy(a).cuda())
+            o2, r2, d2, s2 = ref.step(a)
+            same(done.cpu().numpy(), d2, "done %d" % t); same(obs.cpu().numpy(), o2, "obs %d" % t)
+            outs.append((rew, r2))
+        env.flush()
+        for t, (rew, r2) in enumerate(outs):
+            same(rew.cpu().numpy(), r2, "reward %d" % t)
+        got, want = env.counters(), ref.counters()
+        assert list(got.values()) == [int(x) for x in want], (got, want)
+        assert got["racket_ball_contact_substeps"] > n // 20 and got["nonfinite_states"] == 0 and got["lockstep_violations"] == 0
+        env.close()
+
+
 @pytest.mark.parametrize("kind", [ENV_SWING, ENV_TENNIS])
 def test_nonfinite_states_are_counted_like_the_oracle_counts_them(torch, kind):
     """the nonfinite_states counter with something to count: an infinity or a NaN injected into one of the 22 state values of every
