@@ -1252,6 +1252,43 @@ def test_outline_sweep_with_other_outlines(torch, n_edges):
         env.close()
 
 
+@pytest.mark.parametrize("n_edges", [3, 4, 6, 38, 63])
+def test_tennisbot_rackets_with_other_outlines(torch, n_edges):
+    """the same for Tennisbot, whose step kernel reads the outline table from memory instead of an LDS copy: rackets of random scale and
+    attitude with another outline, balls thrown at them, a batch that ends in a partial wave -- 40 steps bit for bit"""
+    n = 3000
+    rng = np.random.default_rng(177 + n_edges)
+    p = with_outline(default_params(), n_edges)
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    env = BatchedEnv(ENV_TENNIS, n, device="cuda:0", seed=11, params=p, auto_reset=True)
+    pf = p.copy(); pf.flags |= F_AUTO_RESET
+    ref = OracleBatch(pf, ENV_TENNIS, n, seed=11, precision="f32")
+    ref.L.tbo_set_threads(ref.h, 16)
+    scale = rng.uniform(1.0, 3.0, n)
+    q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    rp = np.stack([rng.uniform(8, 12, n), rng.uniform(-4, 4, n), rng.uniform(1.0, 2.5, n)], 1)
+    rv = rng.uniform(-1.0, 1.0, (n, 3))
+    u = rng.normal(size=(n, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    bp = rp + u * (rng.uniform(0.1, 0.9, n) * scale)[:, None]
+    bp[:, 2] = np.maximum(bp[:, 2], 0.3)
+    tof = rng.uniform(0.02, 0.15, n)
+    bv = (rp + rv * tof[:, None] - bp) / tof[:, None] + np.array([0.0, 0.0, 0.5 * 9.81])[None, :] * tof[:, None] + rng.normal(scale=0.3, size=(n, 3))
+    w, d = make_words(ENV_TENNIS, n, racket_pos=rp, racket_quat=q, racket_vel=rv, racket_angvel=rng.uniform(-6, 6, (n, 3)), ball_pos=bp, ball_vel=bv,
+                      ball_angvel=rng.uniform(-30, 30, (n, 3)), shoot_force=(30, 0, 20), step_count=50, racket_scale=scale)
+    env.set_state_words(w.view(np.int32), d); ref.set_state_words(w, d)
+    for t in range(40):
+        a = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+        obs, rew, done = env.step(torch.from_numpy(a).cuda())
+        o2, r2, d2, s2 = ref.step(a)
+        same(done.cpu().numpy(), d2, "done %d" % t); same(obs.cpu().numpy(), o2, "obs %d" % t); same(rew.cpu().numpy(), r2, "reward %d" % t)
+        if t % 8 == 7:
+            compare_state(env, ref, "state %d" % t)
+    got, want = env.counters(), ref.counters()
+    assert list(got.values()) == [int(x) for x in want], (got, want)
+    assert got["racket_ball_contact_substeps"] > n // 20 and got["nonfinite_states"] == 0
+    env.close()
+
+
 @pytest.mark.parametrize("kind", [ENV_SWING, ENV_TENNIS])
 def test_nonfinite_states_are_counted_like_the_oracle_counts_them(torch, kind):
     """the nonfinite_states counter with something to count: an infinity or a NaN injected into one of the 22 state values of every
