@@ -327,3 +327,40 @@ def test_trainer_collect_by_rollout_launch_equals_per_step_launches(torch):
         assert torch.equal(a.buf.raw, b.buf.raw), "rollout buffers differ in round %d" % it
         assert torch.equal(a.values, b.values) and torch.equal(a.logps, b.logps) and torch.equal(a._raw_actions, b._raw_actions)
         assert torch.equal(a.obs_seq, b.obs_seq) and torch.equal(a.last_value, b.last_value)
+
+
+@pytest.mark.parametrize("n,slices", [(1000, 0), (4096, 0), (5000, 0), (1000, 3)])
+def test_fused_rollout_under_the_trained_policy_matches_the_oracle(torch, n, slices):
+    """the env wave of tb_policy_rollout against the ORACLE, directly, where it works hardest: under the reference's trained policy the
+    racket goes for the ball, and a fifth of an env wave's substeps run the outline sweep and the contact solver (random weights
+    hardly ever get there). Three episodes in one call; the oracle is stepped with the actions the kernel reports; every
+    observation, reward, done flag and counter bit for bit, with batch sizes that end in partial waves and slices"""
+    import os
+    from tennisbot_rl_amd.params import F_AUTO_RESET, default_params
+    from tennisbot_rl_amd.ppo import SWING_DEFAULTS, build_actor_critic, pack_policy
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    from oracle import OracleBatch
+    policy = build_actor_critic(OBS_DIM[ENV_SWING], ACT_DIM[ENV_SWING], tuple(SWING_DEFAULTS["net_arch"])).to("cuda:0")
+    policy.load_sb3_arrays(dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "ppo_swing_policy.npz"))))
+    blob = pack_policy(policy)
+    p = default_params()
+    env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=8, pipeline=True, track_terminal_obs=False, params=p, options=dict(policy_slices=slices))
+    pf = p.copy(); pf.flags |= F_AUTO_RESET
+    ref = OracleBatch(pf, ENV_SWING, n, seed=8, precision="f32")
+    ref.L.tbo_set_threads(ref.h, 16)
+    o = env.reset()
+    assert np.array_equal(o.cpu().numpy(), ref.reset())
+    T = 78
+    (obs, rew, done), (act, raw, logp, value) = env.policy_rollout(blob, o, T, seed=5)
+    env.flush()
+    torch.cuda.synchronize()
+    act_h, obs_h, rew_h, done_h = act.cpu().numpy(), obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+    for t in range(T):
+        o2, r2, d2, s2 = ref.step(np.ascontiguousarray(act_h[t]))
+        assert np.array_equal(obs_h[t].view(np.uint32), o2.view(np.uint32)), "obs differs at step %d" % t
+        assert np.array_equal(rew_h[t].view(np.uint32), r2.view(np.uint32)), "reward differs at step %d" % t
+        assert np.array_equal(done_h[t] != 0, d2 != 0), "done differs at step %d" % t
+    got, want = env.counters(), ref.counters()
+    assert list(got.values()) == [int(x) for x in want], (got, want)
+    assert got["racket_ball_contact_substeps"] > n and got["nonfinite_states"] == 0 and got["lockstep_violations"] == 0
+    env.close()
