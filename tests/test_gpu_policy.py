@@ -364,3 +364,18 @@ def test_fused_rollout_under_the_trained_policy_matches_the_oracle(torch, n, sli
     assert list(got.values()) == [int(x) for x in want], (got, want)
     assert got["racket_ball_contact_substeps"] > n and got["nonfinite_states"] == 0 and got["lockstep_violations"] == 0
     env.close()
+    # ... and the same actions through the ordinary pipelined step kernel (tb_step: one launch per step, the outline table copied
+    # lazily by the first wave whose ball gets past the racket's slab -- here most waves' do, the partial last one included)
+    twin = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=8, pipeline=True, track_terminal_obs=False, params=p)
+    twin.reset()
+    outs = []
+    for t in range(T):
+        o3, r3, d3 = twin.step(act[t])
+        assert torch.equal(o3, obs[t]) and torch.equal(d3 != 0, done[t] != 0), "tb_step differs at step %d" % t
+        outs.append(r3)  # (a parking step's reward is written by its fast-forward: compared after the join)
+    twin.flush()
+    torch.cuda.synchronize()
+    for t in range(T):
+        assert torch.equal(outs[t], rew[t]), "tb_step reward differs at step %d" % t
+    assert twin.counters() == got
+    twin.close()
