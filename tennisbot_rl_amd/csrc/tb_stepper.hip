@@ -584,6 +584,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
     // steps/s, larger batches unchanged; the same in the SwingRacket step kernel costs it 3 %, so it is not done there.
     asm volatile("" :: "s"(A.P.dt), "s"(A.P.gravity), "s"(A.P.lin_damp), "s"(A.P.lin_damp_quad), "s"(A.P.racket_inv_mass), "s"(A.P.ball_inv_mass),
                  "s"(A.P.hull_bound_radius), "s"(A.P.hull_margin), "s"(A.P.ball_radius), "s"(A.P.contact_threshold), "s"(A.P.static_top), "s"(A.P.max_ang_step));
+    asm volatile("" :: "s"(A.obs), "s"(A.reward), "s"(A.done_out), "s"(A.substeps));  // ... and where the outputs go: 769 -> 783 M (SwingRacket: 1125 -> 1119 M, not done there either)
   }
 #endif
   Manifold M;
