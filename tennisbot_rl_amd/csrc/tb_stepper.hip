@@ -524,6 +524,9 @@ namespace {
 #ifndef TB_LAZY_TABLE
 #define TB_LAZY_TABLE 1  // (0: A/B builds that copy the table in every launch of the pipelined SwingRacket step kernel)
 #endif
+#ifndef TB_POLICY_VGPR_PARAMS
+#define TB_POLICY_VGPR_PARAMS 1
+#endif
 #ifndef TB_EARLY_PARAMS
 #define TB_EARLY_PARAMS 1  // (0: A/B builds that leave the placement of the Tennisbot step kernel's argument loads to the compiler)
 #endif
@@ -745,6 +748,19 @@ __global__ void __launch_bounds__((2 * S + 1) * 64) tb_policy_rollout_kernel(KAr
   float stdv[NA];
 #pragma unroll
   for (int k = 0; k < NA; ++k) stdv[k] = expf(A.pol_weights[2 * tower_floats<KIND>() + k]);
+  // The free-flight constants of the substep as VECTOR registers for the whole launch. As kernel arguments they are scalar loads
+  // that the compiler, at its SGPR limit in this kernel, re-issues inside the per-step loop (two dozen of them, each behind a wait
+  // the lone env wave cannot hide); the env wave has ~300 vector registers to spare, and a value that went through an empty asm
+  // cannot be fetched again. (TB_POLICY_VGPR_PARAMS 0: A/B builds that pass the argument block itself.)
+  KParams Pl = A.P;
+#if TB_POLICY_VGPR_PARAMS
+#define TB_PIN(f) asm volatile("" : "+v"(Pl.f))
+  TB_PIN(dt); TB_PIN(gravity); TB_PIN(lin_damp); TB_PIN(ang_damp); TB_PIN(lin_damp_quad); TB_PIN(ang_damp_quad); TB_PIN(max_ang_step); TB_PIN(contact_threshold);
+  TB_PIN(racket_inv_mass); TB_PIN(racket_inertia[0]); TB_PIN(racket_inertia[1]); TB_PIN(racket_inertia[2]);
+  TB_PIN(racket_inv_inertia[0]); TB_PIN(racket_inv_inertia[1]); TB_PIN(racket_inv_inertia[2]);
+  TB_PIN(racket_half_thick); TB_PIN(hull_margin); TB_PIN(hull_bound_radius); TB_PIN(ball_inv_mass); TB_PIN(ball_radius); TB_PIN(magnus_k); TB_PIN(static_top);
+#undef TB_PIN
+#endif
   for (int t = 0; t < A.T; ++t) {
     float eps[NA];
     if (live) policy_draw<KIND>(A, i, e, eps);  // while the towers run
@@ -756,7 +772,7 @@ __global__ void __launch_bounds__((2 * S + 1) * 64) tb_policy_rollout_kernel(KAr
       bool d, parked = false;
       float rew;
       if (KIND == TB_ENV_SWING) {
-        rew = swing_step<RG, false, true>(A.P, s_hull, e, M, a, ns, cnt, true, parked TB_STAMP_PASS);  // never loops in here: see tb_step_kernel<LEAN>; COLD
+        rew = swing_step<RG, false, true>(Pl, s_hull, e, M, a, ns, cnt, true, parked TB_STAMP_PASS);  // never loops in here: see tb_step_kernel<LEAN>; COLD
         make_obs<TB_ENV_SWING>(e, o);
         d = e.done != TB_DONE_NO;
         if (parked) {
@@ -770,7 +786,7 @@ __global__ void __launch_bounds__((2 * S + 1) * 64) tb_policy_rollout_kernel(KAr
           d = true;
         }
       } else {
-        rew = tennis_step<RG, true, true>(A.P, s_hull, e, M, a, o, d, cnt TB_STAMP_PASS);
+        rew = tennis_step<RG, true, true>(Pl, s_hull, e, M, a, o, d, cnt TB_STAMP_PASS);
       }
       cnt[6] += (uint32_t)(ns - 1);
       if (!state_is_finite(e))
