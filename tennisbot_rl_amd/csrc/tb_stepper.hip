@@ -590,6 +590,15 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
     asm volatile("" :: "s"(A.obs), "s"(A.reward), "s"(A.done_out), "s"(A.substeps));  // ... and where the outputs go: 769 -> 783 M (SwingRacket: 1125 -> 1119 M, not done there either)
   }
 #endif
+#if TB_EARLY_PARAMS
+  if constexpr (KIND == TB_ENV_SWING && !POLICY && !MULTI && LEAN) {
+    // The pipelined SwingRacket step kernel keeps its own placement of the constants (naming them as above costs it 3 %), but the four
+    // arguments of its rare branches -- the reset's RNG key, the parking record's pointers -- which the compiler hoists out of those
+    // branches to the top of the substep, behind a wait of their own, are better fetched here too: 1110-1118 -> 1129-1134 M (also
+    // measured: the substeps / pool pointers with them: the same; counters and terminal observations as well: 1060 M).
+    asm volatile("" :: "s"(A.seed), "s"(A.env_id_base), "s"(A.ff_rec), "s"(A.ff_flag));
+  }
+#endif
   Manifold M;
   init_manifold(M, POLICY ? (int)(threadIdx.x & 63) : (int)threadIdx.x, POLICY ? 64 : (int)blockDim.x, !REGROWS);
   bool had_contacts = false;
