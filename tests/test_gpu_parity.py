@@ -11,6 +11,7 @@ import pytest
 
 from helpers import make_words
 from oracle import OracleBatch
+from outlines import with_outline
 from tennisbot_rl_amd.params import (ENV_SWING, ENV_TENNIS, F_AUTO_RESET, F_DEFAULT, F_NET, F_RACKET_GROUND, STATE_WORDS, default_params,
                                      reference_rolling_friction)
 
@@ -1184,25 +1185,6 @@ def test_fast_forward_with_balls_thrown_at_a_spinning_racket(torch, n, options):
     assert list(got.values()) == [int(x) for x in want], (got, want)
     assert got["racket_ball_contact_substeps"] > n // 20 and got["nonfinite_states"] == 0 and got["lockstep_violations"] == 0
     env.close()
-
-
-def with_outline(p, n_edges, radius_y=0.13, radius_z=0.33):
-    """`p` with another racket outline: a convex n-gon (an ellipse sampled at uneven angles), CCW in (y, z) about the COM, with the
-    fields params.default_params derives from the outline set the same way"""
-    from tennisbot_rl_amd.params import hull_edge_table
-    rng = np.random.default_rng(100 + n_edges)
-    ang = np.sort((np.arange(n_edges) + rng.uniform(-0.3, 0.3, n_edges)) * (2.0 * np.pi / n_edges))
-    verts = np.stack([radius_y * np.cos(ang), radius_z * np.sin(ang)], 1)
-    rec = hull_edge_table(verts, (0.0, 0.0), 1.0)
-    q = p.copy()
-    q.n_hull = n_edges
-    e = np.ctypeslib.as_array(q.hull_edges)
-    e[:] = 0.0
-    e[:n_edges] = rec
-    vmax = float(np.sqrt((rec[:, :2].astype(np.float64) ** 2).sum(1).max() + float(q.racket_half_thick) ** 2))
-    q.hull_bound_radius = vmax * 1.0001
-    q.racket_ground_threshold = 0.02 * vmax
-    return q
 
 
 @pytest.mark.parametrize("n_edges", [3, 4, 5, 8, 11, 38, 40, 48, 56, 60, 62, 63, 64])

@@ -112,9 +112,14 @@ def test_sphere_vs_racket_face_edge_and_deep():
     assert query_racket(p, (0, 0, 0), q, (3.0, 0, 0))[0] is False
 
 
-def test_sphere_vs_racket_matches_bruteforce():
-    """distance to the prism == brute-force minimum over a dense sampling of its surface"""
+@pytest.mark.parametrize("n_edges", [None, 3, 5, 8, 64])
+def test_sphere_vs_racket_matches_bruteforce(n_edges):
+    """distance to the prism == brute-force minimum over a dense sampling of its surface; the racket's own outline (38 edges from
+    racket.stl) and the synthetic convex ones the GPU parity tests use (tests/outlines.py)"""
     p = default_params()
+    if n_edges is not None:
+        from outlines import with_outline
+        p = with_outline(p, n_edges)
     v = p.hull_vertices()
     hx = p.racket_half_thick
     t = np.linspace(0, 1, 400)[:, None]
