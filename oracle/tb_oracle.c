@@ -231,6 +231,9 @@ typedef struct {
   uint32_t episode;
   uint8_t done;
   Manifold m;
+#ifdef TBO_TRACE_STATIONARY
+  struct { int timed_out, first[5], bits_at_end, n_rg_at_end, substeps, first_racket, ball_below_court; } trace;
+#endif
 } Env;
 
 struct TboBatch {
@@ -612,8 +615,17 @@ static void setup_ground_row(const Prm *P, RowG *c, const Hit *h, const Sym3 *W,
 }
 
 #ifdef TBO_TRACE_STATIONARY
-int g_stat_first[4096]; int g_stat_n;
-int tbo_debug_stationary(int *out) { memcpy(out, g_stat_first, sizeof(int) * g_stat_n); int n = g_stat_n; g_stat_n = 0; return n; }
+/* Stationarity tracer (-DTBO_TRACE_STATIONARY builds only; tools/stationary_trace.py -> profiles/r04_stationary.md):
+ * for every fast-forward that ends by the 800-substep limit, the first loop substep k from which the WHOLE simulation
+ * state -- racket (13 reals), ball (9), the racket<->court cache (count, vertex ids, three impulses per point, support
+ * vertex) -- repeats with period p = 1 .. 4 through to the limit (the pending restoring force is a function of the
+ * racket position, so it repeats with the state). Kept per env (Env.trace), so the OpenMP env loop may run. */
+#define TRACE_MAXP 4
+typedef struct { Racket r; Ball b; Manifold m; } Snap;
+static inline void snap_take(Snap *s, const Env *e) {
+  memset(s, 0, sizeof *s); s->r = e->r; s->b = e->b; s->m.n = e->m.n; s->m.deep = e->m.deep;
+  for (int j = 0; j < e->m.n; ++j) { s->m.id[j] = e->m.id[j]; s->m.jn[j] = e->m.jn[j]; s->m.jt1[j] = e->m.jt1[j]; s->m.jt2[j] = e->m.jt2[j]; }
+}
 #endif
 /* diagnostics (-DTBO_DIAG builds only): solver sweeps and solves so far. Plain globals: single-threaded use -- they are
  * not in the default builds, whose env loop runs under `#pragma omp parallel` (a data race, and a cache line every thread's
@@ -931,22 +943,40 @@ static real swing_step(const Prm *P, Env *e, const float *a, int *substeps, uint
   if (e->step_count < 25 && (bits & CT_RACKET)) reward += R(2); /* :98-101 */
   if (e->step_count > 25) {                                     /* :105 */
     v3 Fp = zero; /* forces were cleared by the substep above */
-    while (!e->done) { /* :106 */
 #ifdef TBO_TRACE_STATIONARY
-      Racket r0 = e->r; Ball b0 = e->b; Manifold m0 = e->m;
+    Snap ring[TRACE_MAXP + 1]; int first[TRACE_MAXP + 1] = {-1, -1, -1, -1, -1}, nloop = 0, first_racket = -1;
+    snap_take(&ring[0], e); nloop = 1; /* ring[0]: the state the loop starts from (no force pending: not comparable, kept for indexing) */
 #endif
+    while (!e->done) { /* :106 */
       bits = substep(P, TB_ENV_SWING, &e->r, &e->b, &e->m, Fp, zero, zero, e->aux[0], e->aux[1], R(1)); /* :107 */
 #ifdef TBO_TRACE_STATIONARY
-      { extern int g_stat_first[4096]; extern int g_stat_n;
-        static __thread int first; if (e->step_count == 26) first = -1;
-        int same = !memcmp(&r0, &e->r, sizeof r0) && !memcmp(&b0, &e->b, sizeof b0) && m0.n == e->m.n && !memcmp(m0.jn, e->m.jn, sizeof m0.jn) && !memcmp(m0.jt1, e->m.jt1, sizeof m0.jt1) && !memcmp(m0.jt2, e->m.jt2, sizeof m0.jt2);
-        if (same && first < 0) first = e->step_count; if (!same) first = -1;
-        if (e->step_count + 1 > 800 && g_stat_n < 4096) g_stat_first[g_stat_n++] = first; }
+      { /* ring[k % 5] = state after loop substep k; first[p] = the k from which state_k == state_(k-p) has held without a break */
+        Snap *cur = &ring[nloop % (TRACE_MAXP + 1)];
+        snap_take(cur, e);
+        for (int p = 1; p <= TRACE_MAXP; ++p) {
+          int same = nloop >= p && !memcmp(cur, &ring[(nloop - p) % (TRACE_MAXP + 1)], sizeof *cur);
+          if (!same) first[p] = -1; else if (first[p] < 0) first[p] = nloop;
+        }
+        { /* the racket and its contact cache alone (the ball left out) */
+          const Snap *prev = &ring[(nloop - 1) % (TRACE_MAXP + 1)];
+          int same = !memcmp(&cur->r, &prev->r, sizeof cur->r) && !memcmp(&cur->m, &prev->m, sizeof cur->m);
+          if (!same) first_racket = -1; else if (first_racket < 0) first_racket = nloop;
+        }
+        ++nloop;
+      }
 #endif
       e->step_count += 1; ns++;
       if (bits & CT_RACKET) cnt[0]++;
       if (bits & (CT_GROUND | CT_NET)) { e->done = TB_DONE_PENDING_FORCE; reward += moved_dist_to_goal(e); cnt[1]++; } /* :111-114 */
       if (bits & CT_GOAL) { reward += moved_dist_to_goal(e); reward += R(50); e->done = TB_DONE_PENDING_FORCE; cnt[2]++; } /* :119-123 */
+#ifdef TBO_TRACE_STATIONARY
+      if (e->step_count > 800) {
+        e->trace.timed_out = !e->done; e->trace.bits_at_end = bits; e->trace.n_rg_at_end = e->m.n; e->trace.substeps = nloop - 1;
+        for (int p = 0; p <= TRACE_MAXP; ++p) e->trace.first[p] = first[p];
+        e->trace.first_racket = first_racket;
+        e->trace.ball_below_court = e->b.p.z < -(P->ground_half[2] + P->ball_radius);
+      }
+#endif
       if (e->step_count > 800) { if (!e->done) cnt[3]++; e->done = TB_DONE_PENDING_FORCE; } /* :127-128 */
       Fp = V3(R(-50) * (e->r.p.x - e->aux[2]), R(-2) * (e->r.p.y - e->aux[3]), R(-2) * ((e->r.p.z - e->aux[4]) - R(4))); /* :135-141 */
     }
@@ -1113,6 +1143,21 @@ void tbo_set_state(TboBatch *B, const uint32_t *words, const uint8_t *done) {
     memset(&e->m, 0, sizeof e->m); /* the contact cache is not part of the state words */
   }
 }
+
+#ifdef TBO_TRACE_STATIONARY
+/* out[i] = {timed_out, first[1..4], contact bits of the last substep, cached racket<->court points, loop substeps,
+ * first substep of the racket-and-cache-only fixed point, ball below the court at the end}; clears the records */
+void tbo_trace_stationary(TboBatch *B, int32_t *out) {
+  for (int i = 0; i < B->n; ++i) {
+    Env *e = &B->e[i];
+    int32_t *o = out + 10 * (size_t)i;
+    o[8] = e->trace.first_racket; o[9] = e->trace.ball_below_court;
+    o[0] = e->trace.timed_out; for (int p = 1; p <= TRACE_MAXP; ++p) o[p] = e->trace.first[p];
+    o[5] = e->trace.bits_at_end; o[6] = e->trace.n_rg_at_end; o[7] = e->trace.substeps;
+    memset(&e->trace, 0, sizeof e->trace);
+  }
+}
+#endif
 
 /* unit-level hooks for the known-answer tests */
 int tbo_get_manifold(TboBatch *B, int env, int32_t ids[MAX_RG], double imp[3 * MAX_RG]) {
