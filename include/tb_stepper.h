@@ -169,7 +169,7 @@ typedef struct TbHandle TbHandle;
  */
 typedef struct TbOptions {
   uint32_t struct_size;     /* sizeof(TbOptions): lets a newer library read an older caller's struct */
-  int32_t block;            /* threads per workgroup of the step kernels: 64, 128 or 256 (auto: 128; 64 for SwingRacket-v0 between 49152 and 131072 envs) */
+  int32_t block;            /* threads per workgroup of the step kernels: 64, 128 or 256 (auto: 64 up to 16384 envs, above that 128; 64 for SwingRacket-v0 between 49152 and 131072 envs) */
   int32_t tennis_reg_rows;  /* Tennisbot static contact rows in registers: 1 on, -1 off (auto: on) */
   int32_t swing_reg_rows;   /* the same for the pipelined SwingRacket step kernel: 1 on, -1 off (auto: on) */
   int32_t ff_lanes_per_wave; /* parked envs per wave in the first fast-forward phase, 1..64 (auto: 64 from 4096 envs on, fewer below) */
@@ -332,7 +332,10 @@ int tb_policy_rollout(TbHandle *h, int n_steps, const float *weights_dev, const 
  * Replays of captured graphs are launched by the caller, not by this library: a caller that mixes eager
  * pipelined steps with graph replays calls tb_flush on the replaying stream first (the graph's launches bake in
  * slot indices and cannot wait for an eager fast-forward still reading its slot; stepper.StepGraph.replay does).
- * At most 2^24 envs per handle with the pipeline on (8 slots of parked records + survivor lists: 4.6 KB per env).
+ * At most 2^24 envs per handle with the pipeline on. Device memory per env: 8 slots of parked records (192 B) and flags, with
+ * ff_phases > 1 also up to two survivor lists per slot: 1.5-4.6 KB; handles that use the pool (TbOptions.ff_defer: on request, by
+ * default up to 16384 envs, above that -- to 131072 -- only with TB_F_RACKET_GROUND, then allocated by the tb_set_params call that
+ * turns it on) another 72 records + destination pointers: 14 KB.
  */
 int tb_set_pipeline(TbHandle *h, int enable);
 int tb_flush(TbHandle *h, void *stream);
@@ -412,7 +415,12 @@ int tb_set_state(TbHandle *h, const uint32_t *words, const uint8_t *done, int on
  * finished, [6] substeps, [7] non-finite state detections, [8] lockstep violations: lanes that reached
  * an episode end in a launch the host had not given a fast-forward slot (only possible when a captured
  * graph is replayed at another phase than it was captured at; their terminal reward is lost). Synchronises
- * the stream. */
+ * the stream.
+ * CONTRACT for callers that replay captured graphs themselves: out[6] counts the first substep of every agent step on the HOST,
+ * when tb_step / tb_rollout / tb_policy_* ENQUEUE work that runs (n_envs x steps per call; nothing during stream capture, where
+ * nothing runs). Each replay of a graph holding K captured steps must therefore be reported with tb_phase_advance(h, K) -- the
+ * call the episode phase needs anyway -- or out[6] under-reports by n_envs x K per replay (every other counter is device-side
+ * and needs nothing). */
 #define TB_N_COUNTERS 9
 int tb_counters(TbHandle *h, uint64_t *out, void *stream);
 int tb_counters_reset(TbHandle *h, void *stream);

@@ -1004,6 +1004,10 @@ __global__ void __launch_bounds__(64, (ESC && !RG) ? TB_ESC_WAVES : 1) tb_ff_ker
         if (A.substeps) A.substeps[i] = ns;
       }
       if (A.ff_flag) A.ff_flag[src] = 0;  // the record is free again (lists and sorted copies are rewritten whole before their next use)
+      // the pool run: a consumed record says so itself. A region's records are expected to be rewritten whole by the next launch that
+      // parks into it -- but an env that does NOT park there (the lockstep invariant broken: counters[8]) would leave this record, with
+      // its destination pointer, to be run once more by the next pool run. One 4-byte store per episode end.
+      if (POOL && A.pool_dst_in) reinterpret_cast<uint32_t*>(A.ff_rec + (size_t)src * TB_FF_REC + 7)[2] = 0u;
     }
     if (A.ff_next) {  // survivors: one atomic per wave reserves their places in the next phase's list
       const unsigned long long m = __ballot(unfinished);
@@ -1683,6 +1687,7 @@ int tb_create(const TbParams* params, const TbOptions* options, int env_kind, in
 }
 
 static void release_pipeline(TbHandle* h);
+static void release_pool(TbHandle* h);
 
 int tb_destroy(TbHandle* h) {
   if (!h) return TB_OK;
@@ -1717,13 +1722,7 @@ static void release_pipeline(TbHandle* h) {
     h->d_ff_rec[k] = nullptr; h->d_ff_flag[k] = nullptr; h->d_ff_sorted[k] = nullptr; h->d_ff_list[k][0] = nullptr; h->d_ff_list[k][1] = nullptr;
     h->d_ff_count[k] = nullptr; h->ev_step[k] = nullptr; h->ev_ff[k] = nullptr; h->side[k] = nullptr; h->ff_busy[k] = 0;
   }
-  if (h->d_pool) (void)hipFree(h->d_pool);
-  if (h->d_pool_dst) (void)hipFree(h->d_pool_dst);
-  if (h->d_pool_count) (void)hipFree(h->d_pool_count);
-  if (h->ev_pool) (void)hipEventDestroy(h->ev_pool);
-  if (h->ev_direct) (void)hipEventDestroy(h->ev_direct);
-  h->ev_pool = nullptr; h->ev_direct = nullptr; h->pool_ev_valid = 0; h->direct_ev_valid = 0; h->pool_episodes = 0; h->pool_run_upto = 0;
-  h->d_pool = nullptr; h->d_pool_dst = nullptr; h->d_pool_count = nullptr; h->pool_cap = 0; h->pool_slack = 0; h->pool_pending = 0;
+  release_pool(h);
   h->pipeline = 0;
 }
 
@@ -1732,6 +1731,53 @@ static int g_fail_alloc_countdown = 0;
 static hipError_t pipeline_malloc(void** p, size_t bytes) {
   if (g_fail_alloc_countdown > 0 && --g_fail_alloc_countdown == 0) { *p = nullptr; return hipErrorOutOfMemory; }
   return hipMalloc(p, bytes);
+}
+
+// The pool (TbOptions.ff_defer): 64 n records (two reference-sized rollouts of 1100 steps with EVERY episode end in it) + the slack
+// all resident fast-forward waves could overshoot it by (slots x n), 192 B each + an 8-byte destination pointer: 14 KB per env.
+// Allocated only for handles whose defer_mode can be non-zero: on request, up to 16384 envs, or above that (to 131072) once the
+// parameter block turns racket<->court contact on -- tb_set_params calls this again. (Until round 4 every pipelined handle up
+// to 131072 envs got one: 1.9 GB at that size that the default kernels never touched.) Zeroed: a record's tag word says whether
+// it holds a parked env, and no launch may ever find a tag it did not write.
+static bool pool_wanted(const TbHandle* h) {
+  if (h->n > TB_DEFER_MAX_ENVS || h->opt.ff_defer < 0) return false;
+  return h->opt.ff_defer > 0 || h->n <= 16384 || (h->kp.flags & TB_F_RACKET_GROUND);
+}
+static void release_pool(TbHandle* h) {
+  if (h->d_pool) (void)hipFree(h->d_pool);
+  if (h->d_pool_dst) (void)hipFree(h->d_pool_dst);
+  if (h->d_pool_count) (void)hipFree(h->d_pool_count);
+  if (h->ev_pool) (void)hipEventDestroy(h->ev_pool);
+  if (h->ev_direct) (void)hipEventDestroy(h->ev_direct);
+  h->ev_pool = nullptr; h->ev_direct = nullptr; h->pool_ev_valid = 0; h->direct_ev_valid = 0; h->pool_episodes = 0; h->pool_run_upto = 0;
+  h->d_pool = nullptr; h->d_pool_dst = nullptr; h->d_pool_count = nullptr; h->pool_cap = 0; h->pool_slack = 0; h->pool_pending = 0;
+}
+static int alloc_pool_parts(TbHandle* h, float4** pool, float*** dst, int** count, hipEvent_t* ev_pool, hipEvent_t* ev_direct, size_t recs) {
+  HIP_TRY(pipeline_malloc((void**)pool, sizeof(float4) * (size_t)TB_FF_REC_MAX * recs));
+  HIP_TRY(hipMemset(*pool, 0, sizeof(float4) * (size_t)TB_FF_REC_MAX * recs));
+  HIP_TRY(pipeline_malloc((void**)dst, sizeof(float*) * recs));
+  HIP_TRY(hipMemset(*dst, 0, sizeof(float*) * recs));
+  HIP_TRY(pipeline_malloc((void**)count, sizeof(int)));
+  HIP_TRY(hipMemset(*count, 0, sizeof(int)));
+  HIP_TRY(hipEventCreateWithFlags(ev_pool, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(ev_direct, hipEventDisableTiming));
+  return TB_OK;
+}
+static int alloc_pool(TbHandle* h) {  // all of it or none: defer_mode takes a non-null d_pool for a usable pool
+  if (h->d_pool || !pool_wanted(h)) return TB_OK;
+  const size_t recs = (size_t)64 * h->n + (size_t)TB_FF_SLOTS * h->n;
+  float4* pool = nullptr; float** dst = nullptr; int* count = nullptr; hipEvent_t e1 = nullptr, e2 = nullptr;
+  if (int rc = alloc_pool_parts(h, &pool, &dst, &count, &e1, &e2, recs)) {
+    if (pool) (void)hipFree(pool);
+    if (dst) (void)hipFree(dst);
+    if (count) (void)hipFree(count);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e2) (void)hipEventDestroy(e2);
+    return rc;
+  }
+  h->pool_cap = 64 * h->n; h->pool_slack = TB_FF_SLOTS * h->n;
+  h->d_pool = pool; h->d_pool_dst = dst; h->d_pool_count = count; h->ev_pool = e1; h->ev_direct = e2;
+  return TB_OK;
 }
 
 static int alloc_pipeline(TbHandle* h) {
@@ -1753,18 +1799,7 @@ static int alloc_pipeline(TbHandle* h) {
     HIP_TRY(hipEventCreateWithFlags(&h->ev_step[k], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_ff[k], hipEventDisableTiming));
   }
-  if (h->n <= TB_DEFER_MAX_ENVS && h->opt.ff_defer >= 0) {
-    // the stragglers' pool: 64 n records (two reference-sized rollouts of 1100 steps with EVERY env deferred) + the slack all
-    // resident fast-forward waves could overshoot it by (slots x n): 14 KB per env
-    h->pool_cap = 64 * h->n; h->pool_slack = TB_FF_SLOTS * h->n;
-    const size_t recs = (size_t)h->pool_cap + (size_t)h->pool_slack;
-    HIP_TRY(pipeline_malloc((void**)&h->d_pool, sizeof(float4) * (size_t)TB_FF_REC_MAX * recs));
-    HIP_TRY(pipeline_malloc((void**)&h->d_pool_dst, sizeof(float*) * recs));
-    HIP_TRY(pipeline_malloc((void**)&h->d_pool_count, sizeof(int)));
-    HIP_TRY(hipMemset(h->d_pool_count, 0, sizeof(int)));
-    HIP_TRY(hipEventCreateWithFlags(&h->ev_pool, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&h->ev_direct, hipEventDisableTiming));
-  }
+  if (int rc = alloc_pool(h)) return rc;
   HIP_TRY(hipDeviceSynchronize());
   return TB_OK;
 }
@@ -1933,6 +1968,10 @@ int tb_set_params(TbHandle* h, const TbParams* params, void* stream) {
   to_kparams(params, &h->kp, &h->cull_planes[0][0]);
   if (int rc = upload_hull(h, s)) return rc;
   HIP_TRY(hipStreamSynchronize(s));
+  if (h->side[0]) {  // a pipelined handle whose new parameter block asks for the pool (racket<->court contact above 16384 envs)
+    if (int rc = alloc_pool(h)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+  }
   h->params_generation++;
   return TB_OK;
 }

@@ -165,7 +165,7 @@ class PPOTrainer:
         # parked into one pool that a single launch finishes at the join -- the rollout kernels run undisturbed, the long flights
         # side by side (TbOptions.ff_defer = 2; same results). Up to 64 episodes per join: beyond, the ordinary path takes over.
         self.env = BatchedEnv(kind, num_envs, device=device, seed=seed, env_id_base=self.rank * num_envs, params=params,
-                              track_terminal_obs=False, pipeline=pipeline and kind == ENV_SWING, options=dict(options or {}, ff_defer=ff_defer))
+                              track_terminal_obs=False, pipeline=pipeline and kind == ENV_SWING, options=dict({"ff_defer": ff_defer}, **(options or {})))  # (an explicit options['ff_defer'] wins over the keyword's default)
         self.device = self.env.device
         self.n_steps, self.num_envs = int(n_steps), int(num_envs)
         self.buf = RolloutBuffer(kind, self.n_steps, num_envs, self.device).bind(self.env)

@@ -1187,51 +1187,113 @@ def test_fast_forward_with_balls_thrown_at_a_spinning_racket(torch, n, options):
     env.close()
 
 
+def thrown_at_racket_through_the_short_steps(torch, n, n_edges, options, step0=12, threads=16):
+    """balls thrown at spinning rackets from inside the bounding sphere to well outside it, starting at agent step `step0`: half of
+    them arrive during the short steps step0+1 .. 25 (the step kernels' racket narrowphase), the others in the fast-forward; the rest
+    of that episode and a whole ordinary one behind it, bit for bit against the oracle"""
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    rng = np.random.default_rng(77 + n_edges)
+    p = with_outline(default_params(), n_edges) if n_edges else default_params()
+    env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=5, params=p, pipeline=True, track_terminal_obs=False, options=options)
+    pf = p.copy(); pf.flags |= F_AUTO_RESET
+    ref = OracleBatch(pf, ENV_SWING, n, seed=5, precision="f32")
+    ref.L.tbo_set_threads(ref.h, threads)
+    q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    rp = np.stack([rng.uniform(8, 10, n), rng.uniform(-2, 2, n), rng.uniform(1.5, 4.0, n)], 1)
+    rv = rng.uniform(-1.5, 1.5, (n, 3))
+    u = rng.normal(size=(n, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    dist = rng.uniform(0.1, 0.9, n)  # from inside the bounding sphere to well outside it
+    bp = rp + u * dist[:, None]
+    bp[:, 2] = np.maximum(bp[:, 2], 0.3)
+    tof = rng.uniform(0.02, 0.3, n)
+    target = rp + rv * tof[:, None] + np.array([0.0, 0.0, -0.5 * 9.81])[None, :] * (tof ** 2)[:, None]
+    bv = (target - bp) / tof[:, None] + np.array([0.0, 0.0, 0.5 * 9.81])[None, :] * tof[:, None] + rng.normal(scale=0.3, size=(n, 3))
+    fields = dict(racket_pos=rp, racket_quat=q, racket_vel=rv, racket_angvel=rng.uniform(-9, 9, (n, 3)), ball_pos=bp, ball_vel=bv,
+                  ball_angvel=rng.uniform(-30, 30, (n, 3)), goal=np.stack([rng.uniform(-11, -4, n), rng.uniform(-4, 4, n)], 1), spawn_pos=(9, 0, 0.6),
+                  init_dist=rng.uniform(8, 20, n), step_count=step0)
+    w, d = make_words(ENV_SWING, n, **fields)
+    env.set_state_words(torch.from_numpy(w.view(np.int32)).cuda(), torch.from_numpy(d).cuda()); ref.set_state_words(w, d)
+    assert env.phase() == step0
+    outs = []
+    short_step_contacts = 0
+    for t in range(26 - step0 + 26):
+        a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
+        obs, rew, done = env.step(torch.from_numpy(a).cuda())
+        o2, r2, d2, s2 = ref.step(a)
+        same(done.cpu().numpy(), d2, "done %d" % t); same(obs.cpu().numpy(), o2, "obs %d" % t)
+        outs.append((rew, r2))
+        if t < 24 - step0:
+            short_step_contacts += int((r2 == 2.0).sum())  # the contact bonus of swingracket_env.py:98-101: only a short step's racket row pays it
+    env.flush()
+    for t, (rew, r2) in enumerate(outs):
+        same(rew.cpu().numpy(), r2, "reward %d" % t)
+    got, want = env.counters(), ref.counters()
+    assert list(got.values()) == [int(x) for x in want], (got, want)
+    assert got["racket_ball_contact_substeps"] > n // 20 and got["nonfinite_states"] == 0 and got["lockstep_violations"] == 0
+    assert short_step_contacts > n // 50, short_step_contacts  # the step kernels' own outline sweeps were exercised, not only the fast-forward's
+    env.close()
+
+
 @pytest.mark.parametrize("n_edges", [3, 4, 5, 8, 11, 38, 40, 48, 56, 60, 62, 63, 64])
 def test_outline_sweep_with_other_outlines(torch, n_edges):
     """the outline sweep takes four edges per trip and the rest one by one: outlines of 3 (no whole trip), 4 and 8 (no rest), 5 and
     11 edges and the largest the table holds, 64 -- balls thrown at spinning rackets as above, through the step kernels (a ball
     next to the racket during the 25 short steps) and both forms of the fast-forward, bit for bit against the oracle"""
-    from tennisbot_rl_amd.stepper import BatchedEnv
-    n = 3000
     for options in (dict(ff_defer="all"), dict(ff_defer=False)):
-        rng = np.random.default_rng(77 + n_edges)
-        p = with_outline(default_params(), n_edges)
-        env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=5, params=p, pipeline=True, track_terminal_obs=False, options=options)
-        pf = p.copy(); pf.flags |= F_AUTO_RESET
-        ref = OracleBatch(pf, ENV_SWING, n, seed=5, precision="f32")
-        ref.L.tbo_set_threads(ref.h, 16)
-        q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
-        rp = np.stack([rng.uniform(8, 10, n), rng.uniform(-2, 2, n), rng.uniform(1.5, 4.0, n)], 1)
-        rv = rng.uniform(-1.5, 1.5, (n, 3))
-        u = rng.normal(size=(n, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
-        dist = rng.uniform(0.1, 0.9, n)  # from inside the bounding sphere to well outside it
-        bp = rp + u * dist[:, None]
-        bp[:, 2] = np.maximum(bp[:, 2], 0.3)
-        tof = rng.uniform(0.02, 0.3, n)
-        target = rp + rv * tof[:, None] + np.array([0.0, 0.0, -0.5 * 9.81])[None, :] * (tof ** 2)[:, None]
-        bv = (target - bp) / tof[:, None] + np.array([0.0, 0.0, 0.5 * 9.81])[None, :] * tof[:, None] + rng.normal(scale=0.3, size=(n, 3))
-        step0 = 12  # half of the envs' balls arrive during the short steps 13..25, the others in the fast-forward
-        fields = dict(racket_pos=rp, racket_quat=q, racket_vel=rv, racket_angvel=rng.uniform(-9, 9, (n, 3)), ball_pos=bp, ball_vel=bv,
-                      ball_angvel=rng.uniform(-30, 30, (n, 3)), goal=np.stack([rng.uniform(-11, -4, n), rng.uniform(-4, 4, n)], 1), spawn_pos=(9, 0, 0.6),
-                      init_dist=rng.uniform(8, 20, n), step_count=step0)
-        w, d = make_words(ENV_SWING, n, **fields)
-        env.set_state_words(torch.from_numpy(w.view(np.int32)).cuda(), torch.from_numpy(d).cuda()); ref.set_state_words(w, d)
-        assert env.phase() == step0
-        outs = []
-        for t in range(26 - step0 + 26):
-            a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
-            obs, rew, done = env.step(torch.from_numpy(a).cuda())
-            o2, r2, d2, s2 = ref.step(a)
-            same(done.cpu().numpy(), d2, "done %d" % t); same(obs.cpu().numpy(), o2, "obs %d" % t)
-            outs.append((rew, r2))
-        env.flush()
-        for t, (rew, r2) in enumerate(outs):
-            same(rew.cpu().numpy(), r2, "reward %d" % t)
-        got, want = env.counters(), ref.counters()
-        assert list(got.values()) == [int(x) for x in want], (got, want)
-        assert got["racket_ball_contact_substeps"] > n // 20 and got["nonfinite_states"] == 0 and got["lockstep_violations"] == 0
-        env.close()
+        thrown_at_racket_through_the_short_steps(torch, 3000, n_edges, options)
+
+
+def test_pool_run_never_reruns_a_consumed_record(torch):
+    """with every episode end parked straight into the pool (ff_defer = 2) a region's records are rewritten by
+    the next launch that parks into it -- unless an env does not park there. The library keeps episodes in lockstep, so only a
+    caller that replays a captured graph at another episode phase (raw hipGraphLaunch through the C ABI; stepper.StepGraph refuses)
+    gets there: the captured parking launch then parks nobody, and the pool run of that replay finds the LAST replay's records in
+    its region, each with a destination pointer. They must not run again: a consumed record says so itself (its tag is cleared by
+    the pool run). Before round 4 the stale episodes were re-run and their rewards written through the stale pointers."""
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    n, K = 1000, 26
+    rng = np.random.default_rng(3)
+    env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=2, pipeline=True, track_terminal_obs=False, options=dict(ff_defer="all"))
+    assert env.pipeline_form() == "pool"
+    env.reset()
+    acts = torch.from_numpy(rng.uniform(-1, 1, (K, n, 6)).astype(np.float32)).cuda()
+    obs = torch.zeros((K, n, 6), device="cuda"); rew = torch.zeros((K, n), device="cuda"); done = torch.zeros((K, n), dtype=torch.uint8, device="cuda")
+    g = env.capture(lambda: [env.step(acts[t], out=(obs[t], rew[t], done[t])) for t in range(K)])
+    g.replay()
+    torch.cuda.synchronize()
+    first = rew[K - 1].clone()
+    assert (first != 0).float().mean() > 0.05 and bool(done[K - 1].all())  # the pool run paid the terminal rewards (a ball that drops straight down earns exactly 0)
+    for t in range(10):  # move the envs to phase 10 outside the graph
+        env.step(acts[t])
+    env.flush(); torch.cuda.synchronize()
+    assert env.phase() == 10 and not g.valid()
+    with pytest.raises(Exception):
+        g.replay()  # the Python surface refuses ...
+    rew.fill_(-777.0)
+    g.graph.replay()  # ... a C-ABI caller's own hipGraphLaunch does not ask
+    torch.cuda.synchronize()
+    c = env.counters()
+    assert c["lockstep_violations"] == n, c  # every env ended its episode in a launch captured without a parking slot: reported
+    # the captured parking launch (graph step 25, envs at step 9 of their episode) parked nobody and wrote plain step rewards;
+    # the pool run behind it found only consumed records in its region: nothing of the first replay's episodes ran again
+    last = rew[K - 1].cpu().numpy()
+    assert np.array_equal(last, np.zeros(n, np.float32)) or set(np.unique(last)) <= {0.0, 2.0}, np.unique(last)[:8]
+    nz = first.cpu().numpy() != 0
+    assert not (last[nz] == first.cpu().numpy()[nz]).any()  # none of the first replay's terminal rewards came back
+    env.close()
+
+
+@pytest.mark.parametrize("n,options,n_edges", [(3000, dict(block=128), 38), (3000, dict(block=256), 38), (3000, dict(block=256, ff_defer=False), 11),
+                                               (1061, dict(block=128), 63), (3000, dict(block=128, swing_reg_rows=False), 38), (20011, None, 38),
+                                               (20011, dict(block=256), 5)],
+                         ids=["block128", "block256", "block256-slots-11gon", "block128-63gon", "block128-lds-rows", "auto-block-20011", "block256-20011-5gon"])
+def test_lazily_copied_outline_table_in_multi_wave_workgroups(torch, n, options, n_edges):
+    """The pipelined SwingRacket step kernel copies the outline table into LDS lazily: the first WAVE whose ball gets past the racket's
+    slab test copies it for itself, without a workgroup barrier (substep<LAZYTAB>, tb_device.hpp). Up to 16384 envs workgroups are one
+    wave; here they are two and four waves (TbOptions.block = 128 / 256, and the automatic 128 above 16384 envs) that copy into and
+    read from the SAME LDS table, with balls past the slab during the short steps in most workgroups and batch sizes that end in a
+    partial wave and a partial workgroup -- the variant no test reached before round 4."""
+    thrown_at_racket_through_the_short_steps(torch, n, n_edges, options)
 
 
 @pytest.mark.parametrize("n_edges", [3, 4, 6, 38, 63])
