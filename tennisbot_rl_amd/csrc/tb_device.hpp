@@ -363,6 +363,58 @@ TB_DEV SweepOut outline_sweep_serial(const float4* hull, int n_hull, float py, f
   return o;
 }
 
+// The sweep with ONE EDGE PER LANE (the env wave of the policy rollout kernels, which brings all 64 lanes into substep: 16 or 48 of
+// them hold envs, the others a far-away dummy and nothing to do). Lane j evaluates edge j -- the arithmetic of sweep_edge -- for the
+// query point of each asking lane in turn, and a six-step butterfly combines the 64 partial results by the sequential loop's own
+// rule: the lexicographic minimum of (squared distance, edge index) over the facing edges, the lexicographic (largest signed
+// distance, smallest edge index), the conjunction of "seen from inside". Both orders are total on what takes part (a NaN never
+// replaced the running value in the loop and is left out here), so the order of combination does not matter: bit-identical to
+// outline_sweep_serial, in ~150 instructions per query instead of ten dependent trips through LDS.
+// MUST be reached by all 64 lanes of the wave (n_hull <= 64 = TB_MAX_HULL edges, one lane each).
+TB_DEV SweepOut outline_sweep_wide(const float4* hull, int n_hull, bool need, float qy, float qz) {
+  const int lane = (int)(threadIdx.x & 63);
+  SweepOut mine;
+  mine.best_d2 = 3.0e38f; mine.best_ry = 0.0f; mine.best_rz = 0.0f; mine.max_sd = -3.0e38f; mine.deep_edge = 0; mine.inside = true;
+  const bool has = lane < n_hull;
+  EdgeRec r;
+  r.e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f); r.e1 = make_float2(0.0f, 0.0f);
+  if (has) r = outline_edge(hull, lane);
+  for (unsigned long long todo = __ballot(need); todo; todo &= todo - 1ull) {
+    const int src = __ffsll((long long)todo) - 1;
+    const float py = __shfl(qy, src, 64), pz = __shfl(qz, src, 64);
+    float d2 = 3.0e38f, ry = 0.0f, rz = 0.0f, sd = -3.0e38f;
+    int bi = 0x7fffffff, di = 0x7fffffff, ins = 1;
+    if (has) {
+      const float4 e0 = r.e0;
+      float wy = py - e0.x, wz = pz - e0.y;
+      float cr = FMA(e0.z, wz, -(e0.w * wy));
+      float s1 = -(cr * r.e1.y);
+      if (s1 > -3.0e38f) { sd = s1; di = lane; }
+      const bool faces = cr < 0.0f;
+      float t = FMA(wy, e0.z, wz * e0.w) * r.e1.x;
+      t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+      float y1 = FMA(-t, e0.z, wy), z1 = FMA(-t, e0.w, wz);
+      float q1 = FMA(y1, y1, z1 * z1);
+      if (faces & (q1 < 3.0e38f)) { d2 = q1; ry = y1; rz = z1; bi = lane; }
+      ins = faces ? 0 : 1;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float od2 = __shfl_xor(d2, off, 64), ory = __shfl_xor(ry, off, 64), orz = __shfl_xor(rz, off, 64), osd = __shfl_xor(sd, off, 64);
+      const int obi = __shfl_xor(bi, off, 64), odi = __shfl_xor(di, off, 64), oins = __shfl_xor(ins, off, 64);
+      const bool closer = od2 < d2 || (od2 == d2 && obi < bi);
+      d2 = closer ? od2 : d2; ry = closer ? ory : ry; rz = closer ? orz : rz; bi = closer ? obi : bi;
+      const bool deeper = osd > sd || (osd == sd && odi < di);
+      sd = deeper ? osd : sd; di = deeper ? odi : di;
+      ins &= oins;
+    }
+    if (lane == src) {
+      mine.best_d2 = d2; mine.best_ry = ry; mine.best_rz = rz; mine.max_sd = sd; mine.deep_edge = di == 0x7fffffff ? 0 : di; mine.inside = ins != 0;
+    }
+  }
+  return mine;
+}
+
 template <bool SCALED>
 TB_DEV Hit racket_finish(const KParams& P, const float4* hull, const Racket& rk, vec3 d, float s, vec3 l, float ax, const SweepOut& so) {
   Hit h;
@@ -506,15 +558,23 @@ TB_DEV vec3 racket_invI(const KParams& P, quat q, vec3 x, float inv_s2) {
   if (SCALED) b = mk(b.x * inv_s2, b.y * inv_s2, b.z * inv_s2);
   return rotate(q, b);
 }
+// 1 / sqrt(a) for the tangent basis. a == 1 exactly for every axis-aligned normal -- the court's and the net's faces, i.e. nearly every
+// static contact -- and 1 / sqrtf(1) is exactly 1 under IEEE rounding: the same value without the ~30 dependent instructions of
+// a correctly rounded square root and division, which a lone wave in the contact path pays one by one.
+TB_DEV float inv_sqrt_unit(float a) {
+  float k = 1.0f;
+  if (a != 1.0f) k = 1.0f / sqrtf(a);
+  return k;
+}
 TB_DEV void plane_space(vec3 n, vec3& p, vec3& q) {
   if (fabsf(n.z) > 0.7071067811865475244f) {
     float a = FMA(n.y, n.y, n.z * n.z);
-    float k = 1.0f / sqrtf(a);
+    float k = inv_sqrt_unit(a);
     p = mk(0.0f, -(n.z * k), n.y * k);
     q = mk(a * k, -(n.x * p.z), n.x * p.y);
   } else {
     float a = FMA(n.x, n.x, n.y * n.y);
-    float k = 1.0f / sqrtf(a);
+    float k = inv_sqrt_unit(a);
     p = mk(-(n.y * k), n.x * k, 0.0f);
     q = mk(-(n.z * p.y), n.z * p.x, a * k);
   }
@@ -1113,10 +1173,24 @@ template <int KIND> TB_DEV bool near_goal(const KParams& P, float zlow) { return
 // entry. Nothing reads it before a ball gets past the racket's slab test -- in the 25 short steps of a random-action episode none
 // does -- so the copy (2.5 KB from `table_mem`, by the wave that needs it, no barrier: a wave's LDS operations complete in order)
 // is made right there, behind a wave vote, instead of by every launch up front (0.4 us of a ~4 us launch, tools/diag/lanes_per_wave.hip).
-template <int KIND, bool RG, bool REGROWS = false, bool COLD = false, bool RELOAD = false, bool ESC = false, bool REGGROUND = false, bool LAZYTAB = false>
+// The forms are chosen by ONE template argument, a mask of SF_* bits (named at every call site; each form is explained above):
+enum : unsigned {
+  SF_RG = 1u,          // the extended contact set compiled in: racket<->court manifold, rolling-friction rows
+  SF_REGROWS = 2u,     // the three static contact rows in registers instead of the lane's LDS column
+  SF_COLD = 4u,        // contact-path constants from the LDS copy of the parameter block (the policy rollout kernels' env wave)
+  SF_RELOAD = 8u,      // large-batch fast-forward: cull planes re-read per call, outline sweep shared by 8 helper lanes, lazy spin rate
+  SF_ESC = 16u,        // first phase of the large-batch fast-forward: hand over instead of sweeping (CT_ESCAPE)
+  SF_REGGROUND = 32u,  // the racket<->court rows of a solve in registers (small-batch kernels that loop)
+  SF_LAZYTAB = 64u,    // the LDS outline table is copied by the first wave that reads it (pipelined SwingRacket step kernel)
+  SF_WIDE = 128u,      // all 64 lanes of the wave are in the substep: the outline sweep takes one edge per lane (outline_sweep_wide)
+};
+template <int KIND, unsigned FORM>
 TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Manifold& M, vec3 Fr, vec3 Tr, vec3 Fb, float goal_x, float goal_y, float scale TB_STAMP_ARG,
                    const float4* table_mem = nullptr) {
+  constexpr bool RG = (FORM & SF_RG) != 0, REGROWS = (FORM & SF_REGROWS) != 0, COLD = (FORM & SF_COLD) != 0, RELOAD = (FORM & SF_RELOAD) != 0,
+                 ESC = (FORM & SF_ESC) != 0, REGGROUND = (FORM & SF_REGGROUND) != 0, LAZYTAB = (FORM & SF_LAZYTAB) != 0, WIDE = (FORM & SF_WIDE) != 0;
   static_assert(!LAZYTAB || (!ESC && !RELOAD && !COLD && !RG), "the lazily copied table serves the plain one-substep kernel only");
+  static_assert(!WIDE || !RELOAD, "one form of shared sweep at a time");
   int bits = 0;
   TB_STAMP(st, 0);  // everything between two substeps (loop control, env logic)
   constexpr bool TWO = ESC && !RG && !REGROWS;  // the static rows in two LDS slots, see load_row
@@ -1193,7 +1267,12 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
     // step kernels beside them than that gives back (702 -> 655 M env steps/s), and in the loop-free step kernels its ballot masks
     // cost SGPR spills at kernel start (-10 %)
     TB_LANES(4, need);        // [4] lanes that need the outline sweep, [5] wave-substeps with one
-    if constexpr (!RELOAD) {  // each lane for itself
+    if constexpr (WIDE) {  // all 64 lanes are here, one edge each (the narrow policy rollout kernels: 16 envs and 48 dummies per env wave)
+      if (__any(need)) {
+        const SweepOut so = outline_sweep_wide(hull, P.n_hull, need, ql.y, ql.z);
+        if (need) hr = racket_finish<KIND == TB_ENV_TENNIS>(P, hull, rk, d, scale, ql, qax, so);
+      }
+    } else if constexpr (!RELOAD) {  // each lane for itself
       if (need) hr = racket_finish<KIND == TB_ENV_TENNIS>(P, hull, rk, d, scale, ql, qax, outline_sweep_serial(hull, P.n_hull, ql.y, ql.z));
     } else if (__any(need)) {  // the sweep is shared by the wave: every active lane goes in
       const SweepOut so = outline_sweep(hull, P.n_hull, need, ql.y, ql.z);
@@ -1225,7 +1304,33 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
 
   TB_LANES(8, bits != 0);     // [8] lanes with a contact, [9] wave-substeps with one
   TB_LANES(10, hr.hit);       // [10] lanes with a racket contact, [11] wave-substeps with one
-  if (__any(bits != 0)) {
+  // A ball on the court and nothing else -- what nearly every solve of a Tennisbot batch is (the ball bounces on its way to the
+  // racket): when no lane of the wave touches anything BUT the ground, its one row is set up and solved in registers by a loop of
+  // its own, without the row slots, the per-row votes and the racket's bookkeeping of the general solver below. The operations on
+  // the env, and their order, are those of solve_contacts with row 1 alone: bit-identical. Tennisbot only (4096 envs, same box:
+  // 786-788 -> 810 M env steps/s, with inv_sqrt_unit 813-814): in SwingRacket's kernels a ground contact is the one substep that
+  // ends an episode, and the second copy of the row code costs them more than it saves (32768 envs 6.01 -> 5.91 G, PPO collect under
+  // the trained policy 581 -> 569 M; the pipelined step kernel 1125 -> 1105 M).
+  bool solved = false;
+  constexpr bool SOLO = !RG && KIND == TB_ENV_TENNIS;
+  if constexpr (SOLO) {
+    if (__any(bits != 0) && !__any((bits & ~CT_GROUND) != 0)) {
+      solved = true;
+      TB_DIAG_ADD_LEADER(6, 1);
+      if (bits) {
+        const KParams& PC = COLD ? *reinterpret_cast<const KParams*>(hull + TB_HULL_KP) : P;
+        RowS c;
+        setup_static(PC, c, hg, PC.rest_court, PC.fric_court, b);
+        float jref = 0.0f;
+        for (int it = 0; it < PC.solver_iters; ++it) {
+          bool moved = normal_static(PC, c, b, jref);
+          moved |= friction_static(PC, c, b, jref);
+          if (!moved) break;
+        }
+      }
+    }
+  }
+  if (!solved && __any(bits != 0)) {
     TB_DIAG_ADD_LEADER(6, 1);  // wave-substeps that enter the solver
     if (bits) {  // only lanes that touch something enter the solver
       const KParams& PC = COLD ? *reinterpret_cast<const KParams*>(hull + TB_HULL_KP) : P;

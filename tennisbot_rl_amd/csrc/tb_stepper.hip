@@ -377,20 +377,22 @@ TB_DEV vec3 restoring_force(const EnvRegs& e) {  // swingracket_env.py:135-141
 //                    the goal or step_count > 800; no agent input enters it. The first of them runs
 //                    with no force at all (the previous substep cleared the accumulators), the
 //                    later ones with the restoring force of :135-141.
+// FORM   = the substep's form, a mask of SF_* bits (tb_device.hpp). The ones that show here:
 // `in_ff` = start inside the fast-forward (tb_ff_kernel resuming a parked env).
 // `defer`  = leave the fast-forward to tb_ff_kernel: sets `parked` instead of looping.
 // BUDGET  = tb_ff_kernel only: leave the loop after `budget` substeps with the env still running (`parked` again): the
 //           next phase kernel resumes it from the saved state, with the restoring force recomputed from that state.
-// ESC     = first phase of the large-batch tb_ff_kernel: a lane that needs the racket's exact narrowphase leaves the loop BEFORE
-//           that substep (`parked` again, nothing of the substep applied); see substep<ESC>.
-// LAZYTAB   = see substep (the pipelined step kernel: `hull` is filled from `table_mem` by the first wave that reads it)
-template <bool RG, bool REGROWS = false, bool COLD = false, bool BUDGET = false, bool RELOAD = false, bool ESC = false, bool REGGROUND = false, bool LAZYTAB = false>
+// SF_ESC  = first phase of the large-batch tb_ff_kernel: a lane that needs the racket's exact narrowphase leaves the loop BEFORE
+//           that substep (`parked` again, nothing of the substep applied); see substep.
+// SF_LAZYTAB = see substep (the pipelined step kernel: `hull` is filled from `table_mem` by the first wave that reads it)
+template <unsigned FORM, bool BUDGET = false>
 TB_DEV float swing_loop(const KParams& P, const float4* hull, EnvRegs& e, Manifold& M, vec3 F, vec3 T, bool in_ff, bool defer, bool& parked,
                         int& ns, uint32_t* cnt TB_STAMP_ARG, int budget = 0, const float4* table_mem = nullptr) {
   const vec3 zero = mk(0.0f, 0.0f, 0.0f);
   float reward = 0.0f;
   for (;;) {
-    int bits = substep<TB_ENV_SWING, RG, REGROWS, COLD, RELOAD, ESC, REGGROUND, LAZYTAB>(P, hull, e.r, e.b, M, F, T, zero, e.aux[0], e.aux[1], 1.0f TB_STAMP_PASS, table_mem);  // :82 / :107
+    constexpr bool ESC = (FORM & SF_ESC) != 0;
+    int bits = substep<TB_ENV_SWING, FORM>(P, hull, e.r, e.b, M, F, T, zero, e.aux[0], e.aux[1], 1.0f TB_STAMP_PASS, table_mem);  // :82 / :107
     if (ESC && (bits & CT_ESCAPE)) { parked = true; break; }
     e.step_count += 1; ns++;                                                                                   // :83 / :108
     if (bits & CT_RACKET) cnt[0]++;
@@ -411,7 +413,7 @@ TB_DEV float swing_loop(const KParams& P, const float4* hull, EnvRegs& e, Manifo
   return reward;
 }
 
-template <bool RG, bool REGROWS = false, bool COLD = false, bool LAZYTAB = false>
+template <unsigned FORM>
 TB_DEV float swing_step(const KParams& P, const float4* hull, EnvRegs& e, Manifold& M, const float* a, int& ns, uint32_t* cnt, bool defer, bool& parked TB_STAMP_ARG,
                         const float4* table_mem = nullptr) {
   vec3 F = mk(a[0] * 400.0f, a[1] * 400.0f, FMA(a[2], 400.0f, 4.0f * 9.81f));  // :76-77
@@ -421,7 +423,7 @@ TB_DEV float swing_step(const KParams& P, const float4* hull, EnvRegs& e, Manifo
     e.done = TB_DONE_YES;
   }
   ns = 0;
-  const float rew = swing_loop<RG, REGROWS, COLD, false, false, false, false, LAZYTAB>(P, hull, e, M, F, T, false, defer, parked, ns, cnt TB_STAMP_PASS, 0, table_mem);
+  const float rew = swing_loop<FORM>(P, hull, e, M, F, T, false, defer, parked, ns, cnt TB_STAMP_PASS, 0, table_mem);
   if (!parked && M.n == 0) M.deep = 0;  // an empty cache is not kept between env.step() calls (a parked env's call is not over: its record keeps it)
   return rew;
 }
@@ -432,13 +434,13 @@ TB_DEV float dist_to_reward(float d) {
 }
 
 // tennisbot_env.py:104-207 (the DELAY_MODE sleep at :124-126 is dropped on purpose)
-template <bool RG, bool REGROWS = false, bool COLD = false>
+template <unsigned FORM>
 TB_DEV float tennis_step(const KParams& P, const float4* hull, EnvRegs& e, Manifold& M, const float* a, float* obs, bool& ret_done, uint32_t* cnt TB_STAMP_ARG) {
   const vec3 zero = mk(0.0f, 0.0f, 0.0f);
   vec3 F = mk(a[0] * 10.0f, a[1] * 10.0f, 4.0f * 9.81f);  // :112-115
   vec3 Fb = zero;
   if (e.step_count < 5) Fb = mk(e.aux[0], e.aux[1], e.aux[2]);  // :118-119
-  int bits = substep<TB_ENV_TENNIS, RG, REGROWS, COLD>(P, hull, e.r, e.b, M, F, zero, Fb, 0.0f, 0.0f, e.aux[3] TB_STAMP_PASS);  // :121
+  int bits = substep<TB_ENV_TENNIS, FORM>(P, hull, e.r, e.b, M, F, zero, Fb, 0.0f, 0.0f, e.aux[3] TB_STAMP_PASS);  // :121
   if (M.n == 0) M.deep = 0;  // an empty cache is not kept between env.step() calls
   e.step_count += 1;                                                                // :122
   if (bits & CT_RACKET) cnt[0]++;
@@ -553,6 +555,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
   constexpr bool TABLE_IN_MEMORY = !POLICY && !MULTI && KIND == TB_ENV_TENNIS && TB_TABLE_IN_MEMORY;
   // LAZYTAB (tb_step on pipelined SwingRacket without the extended contact set): the LDS copy is made by the first wave that reads it (substep<LAZYTAB>)
   constexpr bool LAZYTAB = !POLICY && !MULTI && KIND == TB_ENV_SWING && LEAN && !RG && TB_LAZY_TABLE;
+  constexpr unsigned FORM = (RG ? SF_RG : 0u) | (REGROWS ? SF_REGROWS : 0u) | (LAZYTAB ? SF_LAZYTAB : 0u);
   __shared__ float4 s_lds_hull[TABLE_IN_MEMORY ? 1 : TB_HULL_LDS];
   __shared__ __attribute__((aligned(16))) float s_mean[POLICY ? 64 * 8 : 4];
   // POLICY: 256-thread workgroups, four waves per 64 envs, each running both towers of a 16-env slice (see policy_towers); wave 0 steps the envs
@@ -587,7 +590,9 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
     // steps/s, larger batches unchanged; the same in the SwingRacket step kernel costs it 3 %, so it is not done there.
     asm volatile("" :: "s"(A.P.dt), "s"(A.P.gravity), "s"(A.P.lin_damp), "s"(A.P.lin_damp_quad), "s"(A.P.racket_inv_mass), "s"(A.P.ball_inv_mass),
                  "s"(A.P.hull_bound_radius), "s"(A.P.hull_margin), "s"(A.P.ball_radius), "s"(A.P.contact_threshold), "s"(A.P.static_top), "s"(A.P.max_ang_step));
+#if TB_EARLY_PARAMS != 2
     asm volatile("" :: "s"(A.obs), "s"(A.reward), "s"(A.done_out), "s"(A.substeps));  // ... and where the outputs go: 769 -> 783 M (SwingRacket: 1125 -> 1119 M, not done there either)
+#endif
   }
 #endif
 #if TB_EARLY_PARAMS
@@ -644,7 +649,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
       bool d, parked = false;
       float rew;
       if (KIND == TB_ENV_SWING) {
-        rew = swing_step<RG, REGROWS, false, LAZYTAB>(A.P, s_hull, e, M, a, ns, cnt, LEAN || A.defer != 0, parked TB_STAMP_PASS, w_hull);
+        rew = swing_step<FORM>(A.P, s_hull, e, M, a, ns, cnt, LEAN || A.defer != 0, parked TB_STAMP_PASS, w_hull);
         make_obs<TB_ENV_SWING>(e, o);
         d = e.done != TB_DONE_NO;  // swingracket_env.py:145 returns self.done
         if (parked) {
@@ -662,7 +667,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
           d = true;
         }
       } else {
-        rew = tennis_step<RG, REGROWS>(A.P, s_hull, e, M, a, o, d, cnt TB_STAMP_PASS);
+        rew = tennis_step<FORM>(A.P, s_hull, e, M, a, o, d, cnt TB_STAMP_PASS);
       }
       cnt[6] += (uint32_t)(ns - 1);  // substeps beyond the first of each agent step
       ns_total += ns;
@@ -740,7 +745,20 @@ __global__ void __launch_bounds__((2 * S + 1) * 64) tb_policy_rollout_kernel(KAr
   }
   const int i = blockIdx.x * E + lane;
   const bool live = lane < E && i < A.n;
+  // Lanes without an env (48 of the 64 at S = 1) step a DUMMY: a racket hovering at rest, a ball a kilometre up, a step counter that
+  // never reaches an episode end. It touches nothing, asks for nothing and is never stored -- but its lane is IN the substep, so the
+  // racket narrowphase can hand every lane one edge of an asking env's outline sweep (outline_sweep_wide).
   EnvRegs e;
+  {
+    const vec3 z3 = mk(0.0f, 0.0f, 0.0f);
+    e.r.p = mk(0.0f, 0.0f, 10.0f); e.r.q.x = 0.0f; e.r.q.y = 0.0f; e.r.q.z = 0.0f; e.r.q.w = 1.0f; e.r.v = z3; e.r.w = z3;
+    e.b.p = mk(100.0f, 100.0f, 1000.0f); e.b.v = z3; e.b.w = z3;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) e.aux[k] = 0.0f;
+    e.aux[3] = 1.0f;  // (Tennisbot: the racket scale; SwingRacket: spawn y)
+    e.aux[5] = 1.0f;  // (SwingRacket: d0)
+    e.step_count = -(1 << 30); e.episode = 0u; e.done = TB_DONE_NO;
+  }
   if (live) load_env<KIND>(A.words, A.done_state, A.n, i, e);
   Manifold M;
   init_manifold(M, lane, 64, KIND == TB_ENV_SWING);  // SwingRacket: static rows in LDS; Tennisbot keeps them in registers (REGROWS below)
@@ -774,46 +792,53 @@ __global__ void __launch_bounds__((2 * S + 1) * 64) tb_policy_rollout_kernel(KAr
     float eps[NA];
     if (live) policy_draw<KIND>(A, i, e, eps);  // while the towers run
     __syncthreads();  // the action means of step t are in LDS
-    if (live) {
+    {
       float a[NA], o[NO];
-      policy_sample<KIND>(A, s_mean, i, e, a, (size_t)t, eps, stdv);
-      int ns = 1;
-      bool d, parked = false;
-      float rew;
-      if (KIND == TB_ENV_SWING) {
-        rew = swing_step<RG, false, true>(Pl, s_hull, e, M, a, ns, cnt, true, parked TB_STAMP_PASS);  // never loops in here: see tb_step_kernel<LEAN>; COLD
-        make_obs<TB_ENV_SWING>(e, o);
-        d = e.done != TB_DONE_NO;
-        if (parked) {
-          if (A.ff_rec) {
-            park_env<RG>(A.ff_rec, i, e, M);
-            if (A.ff_flag) A.ff_flag[i] = 1;
-            if (A.pool_dst_out) A.pool_dst_out[i] = A.reward + (size_t)t * A.st_rew + i;
-          } else {
-            cnt[8]++;  // lockstep invariant broken (see launch_policy_rollout): reported, never silent
-          }
-          d = true;
-        }
-      } else {
-        rew = tennis_step<RG, true, true>(Pl, s_hull, e, M, a, o, d, cnt TB_STAMP_PASS);
-      }
-      cnt[6] += (uint32_t)(ns - 1);
-      if (!state_is_finite(e))
-        cnt[7]++;
-      if (d) {  // (rollouts require TB_F_AUTO_RESET)
-        cnt[5]++;
-        e.episode += 1u;
-        reset_env<KIND>(A, s_hull + TB_HULL_KP, i, e);
-        M.n = 0; M.deep = 0;
-        make_obs<KIND>(e, o);
-        any_reset = true;
-      }
-      // the towers wait for the observations only: they go to LDS before the step's outputs go to memory
 #pragma unroll
-      for (int k = 0; k < NO; ++k) s_obs[lane * NO + k] = o[k];
-      write_obs<KIND>(A.obs + (size_t)t * A.st_obs, (size_t)i, o);
-      A.reward[(size_t)t * A.st_rew + i] = rew;
-      A.done_out[(size_t)t * A.st_done + i] = d ? 1 : 0;
+      for (int k = 0; k < NA; ++k) a[k] = 0.0f;
+      if (live) policy_sample<KIND>(A, s_mean, i, e, a, (size_t)t, eps, stdv);
+      int ns = 1;
+      bool d = false, parked = false;
+      float rew;
+      // (every lane of the wave, dummies included: see above)
+      // (the wide sweep where 48 of the 64 lanes are dummies; with 48 envs per wave -- S = 3 -- its one-query-at-a-time loop loses to every
+      //  lane sweeping for itself: PPO collect under the trained policy, same box, S = 1: 570-574 -> 592-595 M env steps/s, S = 3: 461 -> 426 M)
+      constexpr unsigned FORM = (RG ? SF_RG : 0u) | SF_COLD | (S == 1 ? SF_WIDE : 0u);
+      if (KIND == TB_ENV_SWING) rew = swing_step<FORM>(Pl, s_hull, e, M, a, ns, cnt, true, parked TB_STAMP_PASS);  // never loops in here: see tb_step_kernel<LEAN>
+      else rew = tennis_step<FORM | SF_REGROWS>(Pl, s_hull, e, M, a, o, d, cnt TB_STAMP_PASS);
+      if (live) {
+        if (KIND == TB_ENV_SWING) {
+          make_obs<TB_ENV_SWING>(e, o);
+          d = e.done != TB_DONE_NO;
+          if (parked) {
+            if (A.ff_rec) {
+              park_env<RG>(A.ff_rec, i, e, M);
+              if (A.ff_flag) A.ff_flag[i] = 1;
+              if (A.pool_dst_out) A.pool_dst_out[i] = A.reward + (size_t)t * A.st_rew + i;
+            } else {
+              cnt[8]++;  // lockstep invariant broken (see launch_policy_rollout): reported, never silent
+            }
+            d = true;
+          }
+        }
+        cnt[6] += (uint32_t)(ns - 1);
+        if (!state_is_finite(e))
+          cnt[7]++;
+        if (d) {  // (rollouts require TB_F_AUTO_RESET)
+          cnt[5]++;
+          e.episode += 1u;
+          reset_env<KIND>(A, s_hull + TB_HULL_KP, i, e);
+          M.n = 0; M.deep = 0;
+          make_obs<KIND>(e, o);
+          any_reset = true;
+        }
+        // the towers wait for the observations only: they go to LDS before the step's outputs go to memory
+#pragma unroll
+        for (int k = 0; k < NO; ++k) s_obs[lane * NO + k] = o[k];
+        write_obs<KIND>(A.obs + (size_t)t * A.st_obs, (size_t)i, o);
+        A.reward[(size_t)t * A.st_rew + i] = rew;
+        A.done_out[(size_t)t * A.st_done + i] = d ? 1 : 0;
+      }
     }
     __syncthreads();  // the observations after step t are in LDS
   }
@@ -983,12 +1008,13 @@ __global__ void __launch_bounds__(64, (ESC && !RG) ? TB_ESC_WAVES : 1) tb_ff_ker
       }
       const int ns0 = ns;
       // (small batches: the racket<->court rows of a solve in registers -- one wave per SIMD anyway, and a grounded racket's lane is alone in its wave)
-      float rew = swing_loop<RG, false, false, true, BIG, ESC, RG && !BIG>(A.P, s_hull, e, M, F0, zero, true, false, unfinished, ns, cnt TB_STAMP_PASS, budget);
+      constexpr unsigned FORM = (RG ? SF_RG : 0u) | (BIG ? SF_RELOAD : 0u) | (ESC ? SF_ESC : 0u) | (RG && !BIG ? SF_REGGROUND : 0u);
+      float rew = swing_loop<FORM, true>(A.P, s_hull, e, M, F0, zero, true, false, unfinished, ns, cnt TB_STAMP_PASS, budget);
       if constexpr (POOL) {
         // a full pool: finish here after all (the counter is read, not reserved: see the slack above)
         if (unfinished && A.ff_next && *reinterpret_cast<volatile int*>(A.ff_next_count) >= A.ff_cap) {
           unfinished = false;
-          rew = swing_loop<RG, false, false, true, BIG, ESC, RG && !BIG>(A.P, s_hull, e, M, restoring_force(e), zero, true, false, unfinished, ns, cnt TB_STAMP_PASS, 0x7fffffff);
+          rew = swing_loop<FORM, true>(A.P, s_hull, e, M, restoring_force(e), zero, true, false, unfinished, ns, cnt TB_STAMP_PASS, 0x7fffffff);
         }
       }
       cnt[6] += (uint32_t)(ns - ns0);
