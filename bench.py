@@ -238,11 +238,58 @@ class Rollouts:
 
 
 def pick_exchange_form(chunked_wall, chunked_ok, single_wall, single_ok):
-    """which of the two timed exchange forms `value` reports: the faster one whose gathered shards checked out (both were run over the
-    same K steps between the same barriers; the max-over-ranks times are identical on every rank, so every rank answers alike)"""
-    if single_ok and (not chunked_ok or single_wall < chunked_wall):
+    """which of the two timed exchange forms `value` reports: ALWAYS the default form (the chunked, overlapped exchange) -- the metric
+    is one fixed workload on every node, not the faster of two noisy measurements; the single all-gather's figures stay
+    beside it under exchange.single_all_gather. Only a chunked run whose gathered shards FAILED their check gives way to a single
+    all-gather whose shards checked out (a question of validity, not of speed)."""
+    if single_ok and not chunked_ok:
         return "single_all_gather"
     return "chunked"
+
+
+# What the exchange should cost on a node, before any node has been measured (VERDICT r03, item 7). xGMI: 8 GPUs fully connected,
+# 7 links x ~153 GB/s per GPU and direction (MI355X_MICROARCH.md / SURVEY.md 8e); an all-gather of B bytes per rank moves
+# (world - 1) x B into every GPU. "direct": every rank writes its shard to all peers at once, one link each; "ring": world - 1 hops
+# over one link. RCCL's choice is not ours to make; both are given.
+XGMI_LINK_GBS = 153.0
+
+
+def predict_exchange(world, bytes_per_rank, rollout_ms, chunks, exposed_chunk_fraction=None):
+    """predicted rollout + exchange time per rank and the scaling efficiency it implies (value(N) / (N x value(1))), for the single
+    all-gather after the rollout (nothing overlapped) and for the chunked form (all but the last chunk's exchange hidden behind
+    later chunks' steps, when a chunk's exchange is shorter than a chunk's steps)"""
+    if world < 2:
+        return None
+    out = {"assumed": {"xgmi_link_GBs": XGMI_LINK_GBS, "links_per_gpu": 7, "world": world, "bytes_per_rank": int(bytes_per_rank), "rollout_ms": rollout_ms,
+                       "note": "peak link rate, no protocol overhead: an upper bound on the efficiency; the first SCALE record is to be read against it"}}
+    for name, hops in (("direct", 1), ("ring", world - 1)):
+        ag_ms = hops * bytes_per_rank / (XGMI_LINK_GBS * 1e9) * 1e3
+        single = rollout_ms + ag_ms
+        per_chunk = ag_ms / chunks
+        steps_chunk = rollout_ms / chunks
+        chunked = rollout_ms + per_chunk + max(0.0, per_chunk - steps_chunk) * (chunks - 1)
+        out[name] = {"all_gather_ms": ag_ms, "single_all_gather": {"ms_per_rollout": single, "efficiency": rollout_ms / single},
+                     "chunked": {"chunks": chunks, "ms_per_rollout": chunked, "efficiency": rollout_ms / chunked}}
+    return out
+
+
+def cadence_profile(env_name, n_envs):
+    """kernel_us / gap_us of the step launches inside the replayed rollout graph, from the committed un-profiled probe
+    (profiles/*cadence.json, tools/diag/r04_cadence.py: a build that runs at the product's rate logs the real-time counter at the entry
+    and exit of every launch) -- the two committed numbers `roofline.frac` can be recomputed from. (rocprofv3's per-dispatch average is
+    NOT such a number: the profiler serialises every dispatch and counts its start-up, 4.5 us against a 3.6 us cadence.)"""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*cadence.json"))):
+        try:
+            with open(f) as fh:
+                d = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        w = d.get(env_name)
+        if isinstance(w, dict) and w.get("envs") == n_envs and "kernel_us" in w and "gap_us" in w and "cadence_build_rate_M" in w:
+            best = (w, os.path.basename(f))
+    return best
 
 
 def timed_pipeline_form(env, marked):
@@ -642,8 +689,8 @@ def main():
     if dist_on:
         torch.distributed.all_reduce(wall_t, op=torch.distributed.ReduceOp.MAX)
     # Two complete forms of the same job were timed the same way (K steps each, barrier + synchronize on both sides, max over ranks):
-    # `value` is the FASTER one on this node, named in config.workload and in exchange.timed_form; the other stays beside it.
-    # (All ranks hold the same two max-over-ranks times, so all of them pick the same form.)
+    # `value` is ALWAYS the default (chunked) form's, named in config.workload and in exchange.timed_form; the single all-gather's
+    # figures stay beside it (pick_exchange_form: only a chunked run whose shards failed their check gives way).
     picked_single = single is not None and pick_exchange_form(float(wall_t.item()), gather_ok, float(w1_t[0].item()), bool(ok1.item() > 0.5)) == "single_all_gather"
     if picked_single:
         chunked = {"form": exch["form"], "value": world * N * steps_timed / float(wall_t.item()), "ms_per_rollout": float(wall_t.item()) / rollouts * 1e3,
@@ -663,6 +710,7 @@ def main():
         launch_s = ev_s / steps_timed
         achieved = per_launch_bytes / launch_s / 1e9
         traffic = None if args.contact_off else pmc_traffic(args.env, N)
+        cadence = None if (args.contact_off or args.racket_ground or args.rolling_friction) else cadence_profile(args.env, N)
         sps = timed_substeps / (world * N * steps_timed)
         if exch is not None:
             exch["exposed_exchange_ms"] = max(0.0, wall_max / rollouts * 1e3 - exch["rollout_ms"])
@@ -679,7 +727,7 @@ def main():
             exch = {"ranks_seen": world, "bytes_per_rank": 0, "form": "none: REPLICAS ONLY, the sum of the ranks' own rollouts (RCCL unusable: %s)" % replicas_only}
         gather_note = ("" if not R.collective else ", rollouts all-gathered (RCCL) in %d step-chunks overlapped with the steps (one hipGraph, progress marks watched by the host)" % R.chunks
                        if R.chunks > 1 and not picked_single else ", 1 RCCL all-gather of the rollout at the collect boundary"
-                       + (" (faster on this node than the %d-chunk overlapped form timed beside it: exchange.chunked)" % R.chunks if picked_single else ""))
+                       + (" (the %d-chunk overlapped form timed beside it FAILED its gather check: exchange.chunked)" % R.chunks if picked_single else ""))
         result = {
             "metric": "env steps/sec (whole node), SwingRacket-v0 @4096 envs/GPU" if args.env == "swing" and N == 4096
                       else "env steps/sec (whole node), %s @%d envs/GPU" % ("SwingRacket-v0" if args.env == "swing" else "Tennisbot-v0", N),
@@ -714,7 +762,21 @@ def main():
                          "note": "latency-bound at this batch size, not bandwidth-bound (see sweep / DESIGN.md)"},
             "parity": parity_text(),
         }
+        if cadence is not None:
+            cw, csrc = cadence
+            # launch_us (HIP events over the whole rollouts / their steps) = kernel_us + gap_us (one step launch and the gap to the next
+            # one in the chain) + join_share_us (the rollout's ONE fast-forward launch at the join, per step)
+            result["roofline"].update({
+                "kernel_us": cw["kernel_us"], "gap_us": cw["gap_us"], "join_share_us": cw.get("join_share_us"),
+                "cadence_source": csrc, "cadence_build_rate_M": cw["cadence_build_rate_M"], "cadence_product_rate_same_box_M": cw.get("product_rate_same_box_M"),
+                "cadence_note": "committed un-profiled probe (tools/diag/r04_cadence.py): real-time counter at entry / exit of every step launch of one "
+                                "replayed rollout, on a build that replays at the product's rate; frac = algorithmic_bytes_per_launch / "
+                                "((kernel_us + gap_us + join_share_us) us) / peak. rocprofv3's per-dispatch average (profiles/*kernel_stats.csv) is "
+                                "longer than the un-profiled cadence and is not what frac rests on (profiles/README.md)"})
         if exch is not None:
+            if R.collective and exch.get("rollout_ms"):
+                exch["predicted"] = predict_exchange(max(world, exch.get("ranks_seen", world)), exch["bytes_per_rank"], exch["rollout_ms"], max(R.chunks, 1))
+                exch["predicted_for_8_gpus"] = predict_exchange(8, exch["bytes_per_rank"], exch["rollout_ms"], max(R.chunks, 1))
             result["exchange"] = exch
         if replicas_only is not None:  # never to be mistaken for the metric: the rollouts were NOT exchanged
             result["replicas_only"] = True

@@ -8,6 +8,8 @@
 //   -DTB_DIAG_STAMPS         s_memtime stamps: cycles per substep segment and per kernel phase, summed per
 //                            wave into g_diag_cycles[16] (tools/diag/diag_stamps*.py, diag_ff_sort.py)
 //   -DTB_DIAG_TRACE          entry / exit real-time of every step-kernel launch into g_diag_trace (tools/diag/r03_cadence_probe.py)
+//   -DTB_DIAG_CADENCE        the lean launch trace: entry / exit real-time of every step-kernel launch without any atomic
+//                            (tools/diag/r04_cadence.py: the kernel_us / gap_us of bench.py's roofline)
 //   -DTB_DIAG_LANES          lane census of the substep's wave votes into g_diag_lanes[16]
 //                            (tools/diag/diag_lanes.py)
 //   -DTB_DIAG_NO_ANGULAR / _NO_ORIENT / _NO_NARROW (/ _NO_RACKET / _NO_STATICS: its halves)
@@ -113,6 +115,24 @@ __device__ unsigned int g_diag_trace_n;
 #define TB_DIAG_TRACE_EXIT(tr) do { } while (0)
 #endif
 
+// ---- launch cadence (-DTB_DIAG_CADENCE) ------------------------------------------------------
+// The lean form of the launch trace, for the figures bench.py quotes (tools/diag/r04_cadence.py -> profiles/r04_cadence.json): the
+// first thread of a step-kernel launch reads the 100 MHz real-time counter on entry and on exit and stores both at the end -- no
+// atomic, nothing any other thread does, one extra load (the launch's running number, requested beside the state loads) and three
+// stores by one lane. A build with it replays the headline graph at the product's rate (the -DTB_DIAG_TRACE build above, with its
+// returning atomic at entry and one atomic per workgroup at exit, runs 20 % slower: its gaps are not the product's).
+#ifdef TB_DIAG_CADENCE
+__device__ unsigned long long g_diag_cadence[2 * 8192];
+__device__ unsigned int g_diag_cadence_n;
+#define TB_DIAG_CADENCE_ENTRY(t0, nn) const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(); unsigned int nn = 0u; \
+  do { if (blockIdx.x == 0 && threadIdx.x == 0) nn = *reinterpret_cast<volatile unsigned int*>(&g_diag_cadence_n); } while (0)
+#define TB_DIAG_CADENCE_EXIT(t0, nn) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t1_ = __builtin_amdgcn_s_memrealtime(); \
+  g_diag_cadence[2 * (nn & 8191u)] = t0; g_diag_cadence[2 * (nn & 8191u) + 1] = t1_; g_diag_cadence_n = nn + 1u; } } while (0)
+#else
+#define TB_DIAG_CADENCE_ENTRY(t0, nn) do { } while (0)
+#define TB_DIAG_CADENCE_EXIT(t0, nn) do { } while (0)
+#endif
+
 // ---- timing-only ablations (results are wrong) ---------------------------------------------
 #ifdef TB_DIAG_NO_ANGULAR
 #define TB_DIAG_ABLATE_ANGULAR(flag) flag = false
@@ -163,6 +183,17 @@ int tb_diag_read_trace_all_out(unsigned long long* out, int max_entries) {
   const int k = max_entries < 8192 ? max_entries : 8192;
   if (k > 0) HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_trace_prev_all_out), sizeof(unsigned long long) * (size_t)k));
   return k;
+}
+#endif
+#ifdef TB_DIAG_CADENCE
+// the ring of entry / exit pairs (100 MHz ticks; launch k of the count since the last reset sits at pair k % 8192); returns that count
+int tb_diag_read_cadence(unsigned long long* out_8192_pairs, int reset) {
+  HIP_TRY(hipDeviceSynchronize());
+  unsigned int n = 0;
+  HIP_TRY(hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_diag_cadence_n), sizeof n));
+  HIP_TRY(hipMemcpyFromSymbol(out_8192_pairs, HIP_SYMBOL(g_diag_cadence), sizeof(unsigned long long) * 2 * 8192));
+  if (reset) { unsigned int z = 0; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_diag_cadence_n), &z, sizeof z)); }
+  return (int)n;
 }
 #endif
 #ifdef TB_DIAG_LDS_PAD

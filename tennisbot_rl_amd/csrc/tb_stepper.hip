@@ -575,6 +575,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
   EnvRegs e;
   TB_DIAG_NOW(t_entry);
   TB_DIAG_TRACE_ENTRY(trace_slot);
+  TB_DIAG_CADENCE_ENTRY(cad_t0, cad_n);
   // issue every load this launch depends on back to back -- state rows, the first step's actions,
   // the outline table -- so that their latencies overlap instead of queueing behind the barrier
   float a[NA];
@@ -700,6 +701,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
   TB_DIAG_ADD_LANE0(9, 1);
   TB_DIAG_ADD_LANE0(14, __builtin_amdgcn_s_memrealtime() - rt_kernel0);
   TB_DIAG_TRACE_EXIT(trace_slot);
+  TB_DIAG_CADENCE_EXIT(cad_t0, cad_n);
 }
 
 // T agent steps with the policy inside, ONE launch: no launch boundary, no state round trip between the

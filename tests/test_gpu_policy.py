@@ -329,12 +329,15 @@ def test_trainer_collect_by_rollout_launch_equals_per_step_launches(torch):
         assert torch.equal(a.obs_seq, b.obs_seq) and torch.equal(a.last_value, b.last_value)
 
 
-@pytest.mark.parametrize("n,slices", [(1000, 0), (4096, 0), (5000, 0), (1000, 3)])
-def test_fused_rollout_under_the_trained_policy_matches_the_oracle(torch, n, slices):
+@pytest.mark.parametrize("n,slices,n_edges", [(1000, 0, 0), (4096, 0, 0), (5000, 0, 0), (1000, 3, 0), (1000, 1, 64), (777, 1, 63), (900, 1, 5), (900, 1, 3),
+                                              (600, 3, 11)])
+def test_fused_rollout_under_the_trained_policy_matches_the_oracle(torch, n, slices, n_edges):
     """the env wave of tb_policy_rollout against the ORACLE, directly, where it works hardest: under the reference's trained policy the
     racket goes for the ball, and a fifth of an env wave's substeps run the outline sweep and the contact solver (random weights
     hardly ever get there). Three episodes in one call; the oracle is stepped with the actions the kernel reports; every
-    observation, reward, done flag and counter bit for bit, with batch sizes that end in partial waves and slices"""
+    observation, reward, done flag and counter bit for bit, with batch sizes that end in partial waves and slices.
+    n_edges: other racket outlines (tests/outlines.py) -- the 16-env form sweeps an outline with ONE EDGE PER LANE of the env wave
+    (outline_sweep_wide: 64 edges = every lane, 63 = one lane without, 3 and 5 = most lanes without), the 48-env form lane by lane"""
     import os
     from tennisbot_rl_amd.params import F_AUTO_RESET, default_params
     from tennisbot_rl_amd.ppo import SWING_DEFAULTS, build_actor_critic, pack_policy
@@ -344,6 +347,9 @@ def test_fused_rollout_under_the_trained_policy_matches_the_oracle(torch, n, sli
     policy.load_sb3_arrays(dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "ppo_swing_policy.npz"))))
     blob = pack_policy(policy)
     p = default_params()
+    if n_edges:
+        from outlines import with_outline
+        p = with_outline(p, n_edges)
     env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=8, pipeline=True, track_terminal_obs=False, params=p, options=dict(policy_slices=slices))
     pf = p.copy(); pf.flags |= F_AUTO_RESET
     ref = OracleBatch(pf, ENV_SWING, n, seed=8, precision="f32")
@@ -362,7 +368,7 @@ def test_fused_rollout_under_the_trained_policy_matches_the_oracle(torch, n, sli
         assert np.array_equal(done_h[t] != 0, d2 != 0), "done differs at step %d" % t
     got, want = env.counters(), ref.counters()
     assert list(got.values()) == [int(x) for x in want], (got, want)
-    assert got["racket_ball_contact_substeps"] > n and got["nonfinite_states"] == 0 and got["lockstep_violations"] == 0
+    assert got["racket_ball_contact_substeps"] > (n // 4 if n_edges else n) and got["nonfinite_states"] == 0 and got["lockstep_violations"] == 0
     env.close()
     # ... and the same actions through the ordinary pipelined step kernel (tb_step: one launch per step, the outline table copied
     # lazily by the first wave whose ball gets past the racket's slab -- here most waves' do, the partial last one included)

@@ -3,9 +3,10 @@
 #   bash tools/refresh_profiles.sh <tag> a     bench lines, sweeps, rocprofv3 kernel stats of the same commands
 #   bash tools/refresh_profiles.sh <tag> b     PMC traffic passes, SQ counters at 1 M envs
 #   bash tools/refresh_profiles.sh <tag> c     PPO probes (collect rate, learning curve), pin analysis, racket<->court rates
-# (writes under gpurun_out/<tag>/; copy what is judged into profiles/). Steps are joined so that a failing GPU step stops the pass.
+# (writes under gpurun_out/<tag>/; copy what is judged into profiles/). EVERY GPU step ends in `|| exit 1`: a step that fails or
+# faults stops the pass -- it is looked into from its log, never run past.
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 PART=${2:-a}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
@@ -34,9 +35,10 @@ elif [ "$PART" = "b" ]; then
   B="--envs-per-gpu 1048576 --rollout-steps 104 --steps 104 --warmup 26 --no-cpu-baseline --no-sweep"
   for C in "VALUBusy" "VALUUtilization" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
     N=$(echo $C | tr ' ' '_')
-    rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_sq -o sq_$N -- python3 $R/bench.py $B > $OUT/sq_$N.log 2>&1 || echo "pass $N failed"
+    rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_sq -o sq_$N -- python3 $R/bench.py $B > $OUT/sq_$N.log 2>&1 || { echo "pass $N failed"; tail -20 $OUT/sq_$N.log; exit 1; }
   done
-  python3 $R/tools/summarize_pmc_sq.py $OUT/pmc_sq > $OUT/sq_counters_1m.txt 2>&1; cat $OUT/sq_counters_1m.txt
+  python3 $R/tools/summarize_pmc_sq.py $OUT/pmc_sq > $OUT/sq_counters_1m.txt 2>&1 || exit 1
+  cat $OUT/sq_counters_1m.txt
 else
   python3 tools/diag/r03_ppo_probe.py curve > $OUT/ppo_probe.log 2>&1 || { tail -20 $OUT/ppo_probe.log; exit 1; }
   cp $R/gpurun_out/r03_ppo_probe.json $OUT/ppo_probe.json
@@ -44,8 +46,8 @@ else
   cp $R/gpurun_out/r03_collect_breakdown.json $OUT/collect_breakdown.json
   python3 tools/pin_sensitivity.py > $OUT/pin_sensitivity.log 2>&1 || { tail -20 $OUT/pin_sensitivity.log; exit 1; }
   cp $R/gpurun_out/r03_pin_sensitivity.json $R/gpurun_out/r03_pin_sensitivity.md $OUT/
-  python3 tools/diag/r02_ff_ab.py lanes rg > $OUT/racket_ground_lanes.log 2>&1
-  python3 tools/diag/r03_cadence_probe.py > $OUT/cadence_probe.log 2>&1
-  cp $R/gpurun_out/r03_cadence_probe.json $OUT/cadence_probe.json
+  python3 tools/diag/r02_ff_ab.py lanes rg > $OUT/racket_ground_lanes.log 2>&1 || { tail -20 $OUT/racket_ground_lanes.log; exit 1; }
+  python3 tools/diag/r04_cadence.py > $OUT/cadence.log 2>&1 || { tail -20 $OUT/cadence.log; exit 1; }
+  cp $R/gpurun_out/r04_cadence.json $OUT/cadence.json
   grep -v amdgpu.ids $OUT/ppo_probe.log $OUT/collect_breakdown.log | cut -c1-600
 fi
