@@ -48,11 +48,7 @@ TB_DEV float dot(vec3 a, vec3 b) { return FMA(a.z, b.z, FMA(a.y, b.y, a.x * b.x)
 // any component non-zero (or NaN)? |x| + |y| + |z| is zero only if all three are (nothing cancels between magnitudes; a NaN or an
 // overflow to infinity compares unequal to zero too): two additions with free |.| modifiers and ONE comparison where three
 // comparisons and the scalar ors between them cost a lone wave three more issue slots
-#ifdef TB_AB_COMPARE_EACH
-TB_DEV bool nonzero3(vec3 v) { return (v.x != 0.0f) | (v.y != 0.0f) | (v.z != 0.0f); }
-#else
 TB_DEV bool nonzero3(vec3 v) { return (fabsf(v.x) + fabsf(v.y)) + fabsf(v.z) != 0.0f; }
-#endif
 TB_DEV vec3 cross(vec3 a, vec3 b) {
   return mk(FMA(a.y, b.z, -(a.z * b.y)), FMA(a.z, b.x, -(a.x * b.z)), FMA(a.x, b.y, -(a.y * b.x)));
 }
@@ -205,7 +201,10 @@ TB_DEV bool racket_planes(const KParams& P, const float4* hull, vec3 l, float s)
   const float r = P.ball_radius, thr = P.contact_threshold;
   float sep = -3.0e38f;
   int first = TB_HULL_PLANES;
-  if (RELOAD) asm volatile("" : "+v"(first));  // a row index the compiler cannot see through: the reads stay here (the index, not the
+#ifndef TB_HINT_RELOAD_PLANES
+#define TB_HINT_RELOAD_PLANES 1  // (a scheduling hint like those listed in tb_stepper.hip; tools/diag/r04_hint_recheck.py)
+#endif
+  if (RELOAD && TB_HINT_RELOAD_PLANES) asm volatile("" : "+v"(first));  // a row index the compiler cannot see through: the reads stay here (the index, not the
                                               // pointer: laundering the pointer loses its address space and the reads become flat loads)
   const float4* cpl = hull + first;
   float cp[3 * TB_N_CULL];
@@ -293,11 +292,9 @@ TB_DEV SweepOut outline_sweep(const float4* hull, int n_hull, bool need, float q
 // the same sweep by one lane for itself (every instantiation but the large-batch fast-forward, see substep).
 // One edge, WITHOUT branches: the closest-point arithmetic of an edge seen from behind (cr >= 0) is done and thrown away by the
 // selects -- the values kept, and every operation that produced them, are those of the branching form (the oracle still has
-// it, and the TB_SWEEP_CHUNK == 0 build below): bit-identical. (The helpers' loop of the cooperative sweep above keeps its branch:
+// it): bit-identical. (The helpers' loop of the cooperative sweep above keeps its branch:
 // without it the survivor kernels of a 1 M-env fast-forward issue 7 % more vector instructions and nothing gets faster.)
-#ifndef TB_SWEEP_CHUNK
-#define TB_SWEEP_CHUNK 4  // (0: A/B builds with the one-edge-per-trip branching loop)
-#endif
+constexpr int TB_SWEEP_CHUNK = 4;  // edges requested together per trip (2: no gain; the branching one-edge-per-trip loop: EXPERIMENTS.md)
 struct EdgeRec { float4 e0; float2 e1; };  // {a.y a.z e.y e.z}, {1/|e|^2 1/|e|}
 TB_DEV EdgeRec outline_edge(const float4* hull, int i) {
   EdgeRec r;
@@ -330,23 +327,6 @@ TB_DEV void sweep_edge(SweepOut& o, int i, const EdgeRec& r, float py, float pz)
 TB_DEV SweepOut outline_sweep_serial(const float4* hull, int n_hull, float py, float pz) {
   SweepOut o;
   o.best_d2 = 3.0e38f; o.best_ry = 0.0f; o.best_rz = 0.0f; o.max_sd = -3.0e38f; o.deep_edge = 0; o.inside = true;
-#if TB_SWEEP_CHUNK == 0
-  for (int i = 0; i < n_hull; ++i) {
-    const float4 e0 = hull[2 * i], e1 = hull[2 * i + 1];
-    float wy = py - e0.x, wz = pz - e0.y;
-    float cr = FMA(e0.z, wz, -(e0.w * wy));
-    float sd = -(cr * e1.y);
-    if (sd > o.max_sd) { o.max_sd = sd; o.deep_edge = i; }
-    if (cr < 0.0f) {
-      o.inside = false;
-      float t = FMA(wy, e0.z, wz * e0.w) * e1.x;
-      t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
-      float ry = FMA(-t, e0.z, wy), rz = FMA(-t, e0.w, wz);
-      float d2 = FMA(ry, ry, rz * rz);
-      if (d2 < o.best_d2) { o.best_d2 = d2; o.best_ry = ry; o.best_rz = rz; }
-    }
-  }
-#else
   constexpr int C = TB_SWEEP_CHUNK;
   const int whole = n_hull - n_hull % C;
 #pragma unroll 1
@@ -359,7 +339,6 @@ TB_DEV SweepOut outline_sweep_serial(const float4* hull, int n_hull, float py, f
   }
 #pragma unroll 1
   for (int i = whole; i < n_hull; ++i) sweep_edge(o, i, outline_edge(hull, i), py, pz);
-#endif
   return o;
 }
 

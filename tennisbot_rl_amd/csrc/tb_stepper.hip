@@ -106,11 +106,7 @@ TB_DEV void row_store(uint32_t* w, int row, int n, int i, uint32_t v) {
     *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(w) + byte) = v;
   } else w[(size_t)row * n + i] = v;
 }
-#ifdef TB_AB_ROWS_64BIT
-template <int KIND> constexpr bool off32() { return false; }
-#else
 template <int KIND> constexpr bool off32() { return KIND == TB_ENV_SWING; }
-#endif
 template <int KIND> TB_DEV float ld(const uint32_t* w, int row, int n, int i) { return __uint_as_float(row_word<off32<KIND>()>(w, row, n, i)); }
 template <int KIND> TB_DEV void st(uint32_t* w, int row, int n, int i, float v) { row_store<off32<KIND>()>(w, row, n, i, __float_as_uint(v)); }
 
@@ -466,10 +462,6 @@ TB_DEV bool finite3(vec3 v) { return isfinite(v.x) && isfinite(v.y) && isfinite(
 // all 22 state values finite? x * 0 is (+-)0 for a finite x and NaN for an infinity or a NaN, and NaN survives every sum: four
 // short fma chains and ONE comparison instead of 22 class tests and the scalar ands between them (the same verdict for every input)
 TB_DEV bool state_is_finite(const EnvRegs& e) {
-#ifdef TB_AB_CLASS_FINITE
-  return finite3(e.r.p) && finite3(e.r.v) && finite3(e.r.w) && finite3(e.b.p) && finite3(e.b.v) && finite3(e.b.w) &&
-         isfinite(e.r.q.x) && isfinite(e.r.q.y) && isfinite(e.r.q.z) && isfinite(e.r.q.w);
-#else
   float a0 = e.r.p.x * 0.0f, a1 = e.r.p.y * 0.0f, a2 = e.r.p.z * 0.0f, a3 = e.r.q.x * 0.0f;
   a0 = FMA(e.r.q.y, 0.0f, a0); a1 = FMA(e.r.q.z, 0.0f, a1); a2 = FMA(e.r.q.w, 0.0f, a2); a3 = FMA(e.r.v.x, 0.0f, a3);
   a0 = FMA(e.r.v.y, 0.0f, a0); a1 = FMA(e.r.v.z, 0.0f, a1); a2 = FMA(e.r.w.x, 0.0f, a2); a3 = FMA(e.r.w.y, 0.0f, a3);
@@ -478,7 +470,6 @@ TB_DEV bool state_is_finite(const EnvRegs& e) {
   a0 = FMA(e.b.w.y, 0.0f, a0); a1 = FMA(e.b.w.z, 0.0f, a1);
   const float t = (a0 + a1) + (a2 + a3);
   return t == t;
-#endif
 }
 
 // wave-level sum of per-lane event counts; one atomic per wave and counter that is non-zero, into
@@ -523,20 +514,20 @@ namespace {
 // one to two more waves per SIMD for the kernel every RL step launches.
 // POLICY: the actions are not read from memory but inferred in-kernel (tb_policy_step).
 // REGROWS (Tennisbot, small batches): the static contact rows in registers, see solve_contacts.
-#ifndef TB_LAZY_TABLE
-#define TB_LAZY_TABLE 1  // (0: A/B builds that copy the table in every launch of the pipelined SwingRacket step kernel)
+// SCHEDULING HINTS. Three places below (and one in tb_device.hpp) steer where the compiler puts scalar argument loads, with empty
+// `asm volatile` statements that only NAME values. They change no result; each was chosen by a same-box A/B on AMD clang 22 / ROCm 7.2
+// (profiles/EXPERIMENTS.md) and is worth 1-4 % to a launch-bound kernel -- on THIS compiler. They are the only compile-time switches
+// left in the product sources, kept so that tools/diag/r04_hint_recheck.py can re-measure every one of them (-DTB_HINT_x=0 against
+// the default) after a toolchain change; a hint that no longer pays is deleted, not tuned. (Round 4's re-check deleted one: the
+// pipelined SwingRacket step kernel's rare-branch arguments named early gave 4096 envs +1 % and cost 32768 envs 5 %.)
+#ifndef TB_HINT_TENNIS_CONSTANTS
+#define TB_HINT_TENNIS_CONSTANTS 1   // Tennisbot step kernel: the free-flight constants fetched beside the state loads
 #endif
-#ifndef TB_POLICY_VGPR_PARAMS
-#define TB_POLICY_VGPR_PARAMS 1
+#ifndef TB_HINT_TENNIS_OUTPUTS
+#define TB_HINT_TENNIS_OUTPUTS 1     // ... and its output pointers
 #endif
-#ifndef TB_EARLY_PARAMS
-#define TB_EARLY_PARAMS 1  // (0: A/B builds that leave the placement of the Tennisbot step kernel's argument loads to the compiler)
-#endif
-#ifndef TB_AB_SEP_SWING
-#define TB_AB_SEP_SWING 0  // (1: A/B builds in which SwingRacket's step kernels read the leading kernel arguments too)
-#endif
-#ifndef TB_TABLE_IN_MEMORY
-#define TB_TABLE_IN_MEMORY 1  // (0: A/B builds with the LDS copy in every kernel)
+#ifndef TB_HINT_POLICY_VGPR_PARAMS
+#define TB_HINT_POLICY_VGPR_PARAMS 1 // policy rollout kernels: the substep's constants pinned in vector registers for the whole launch
 #endif
 template <int KIND, bool LEAN, bool MULTI, bool RG, bool POLICY = false, bool REGROWS = false>
 __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict__ k_words, const uint8_t* __restrict__ k_done, const float* __restrict__ k_actions,
@@ -552,9 +543,9 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
   // Tennisbot 4096 envs: 689 -> 727 M env steps/s, 1 M: 19.2 -> 19.5 G. The pipelined SwingRacket step kernel, at its SGPR limit,
   // pays more for the table's addresses than the copy costs it (918 -> 899 M, 32768 envs 5.17 -> 4.80 G): it keeps the LDS copy,
   // like every kernel that loops (fast-forward, tb_rollout, the fused policy).
-  constexpr bool TABLE_IN_MEMORY = !POLICY && !MULTI && KIND == TB_ENV_TENNIS && TB_TABLE_IN_MEMORY;
+  constexpr bool TABLE_IN_MEMORY = !POLICY && !MULTI && KIND == TB_ENV_TENNIS;
   // LAZYTAB (tb_step on pipelined SwingRacket without the extended contact set): the LDS copy is made by the first wave that reads it (substep<LAZYTAB>)
-  constexpr bool LAZYTAB = !POLICY && !MULTI && KIND == TB_ENV_SWING && LEAN && !RG && TB_LAZY_TABLE;
+  constexpr bool LAZYTAB = !POLICY && !MULTI && KIND == TB_ENV_SWING && LEAN && !RG;
   constexpr unsigned FORM = (RG ? SF_RG : 0u) | (REGROWS ? SF_REGROWS : 0u) | (LAZYTAB ? SF_LAZYTAB : 0u);
   __shared__ float4 s_lds_hull[TABLE_IN_MEMORY ? 1 : TB_HULL_LDS];
   __shared__ __attribute__((aligned(16))) float s_mean[POLICY ? 64 * 8 : 4];
@@ -562,7 +553,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
   const int i = POLICY ? blockIdx.x * 64 + (threadIdx.x & 63) : blockIdx.x * blockDim.x + threadIdx.x;
   // measured at 4096 envs: Tennisbot +5.6 % (687 -> 726 M env steps/s); SwingRacket -6 % if it uses them too
   // (its kernels sit at the SGPR limit), so SwingRacket keeps reading the struct
-  constexpr bool SEP = KIND == TB_ENV_TENNIS || TB_AB_SEP_SWING;
+  constexpr bool SEP = KIND == TB_ENV_TENNIS;
   const uint32_t* __restrict__ w_words = SEP ? k_words : A.words;
   const uint8_t* __restrict__ w_done = SEP ? k_done : A.done_state;
   const float* __restrict__ w_actions = SEP ? k_actions : A.actions;  // (SwingRacket: the compiler loads this pointer inside the `live` branch, a
@@ -583,7 +574,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
     load_env<KIND>(w_words, w_done, w_n, i, e);
     if (!POLICY) load_actions<KIND>(w_actions, (size_t)i, a);
   }
-#if TB_EARLY_PARAMS
+#if TB_HINT_TENNIS_CONSTANTS
   if constexpr (KIND == TB_ENV_TENNIS && !POLICY && !MULTI) {
     // The constants of a free-flight substep are wanted HERE, i.e. fetched beside the state loads in flight: left alone the compiler
     // sinks some of their scalar loads to where they are used, each behind a wait that a lone wave cannot hide (~0.12 us: what a
@@ -591,19 +582,11 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
     // steps/s, larger batches unchanged; the same in the SwingRacket step kernel costs it 3 %, so it is not done there.
     asm volatile("" :: "s"(A.P.dt), "s"(A.P.gravity), "s"(A.P.lin_damp), "s"(A.P.lin_damp_quad), "s"(A.P.racket_inv_mass), "s"(A.P.ball_inv_mass),
                  "s"(A.P.hull_bound_radius), "s"(A.P.hull_margin), "s"(A.P.ball_radius), "s"(A.P.contact_threshold), "s"(A.P.static_top), "s"(A.P.max_ang_step));
-#if TB_EARLY_PARAMS != 2
+  }
+#endif
+#if TB_HINT_TENNIS_OUTPUTS
+  if constexpr (KIND == TB_ENV_TENNIS && !POLICY && !MULTI)
     asm volatile("" :: "s"(A.obs), "s"(A.reward), "s"(A.done_out), "s"(A.substeps));  // ... and where the outputs go: 769 -> 783 M (SwingRacket: 1125 -> 1119 M, not done there either)
-#endif
-  }
-#endif
-#if TB_EARLY_PARAMS
-  if constexpr (KIND == TB_ENV_SWING && !POLICY && !MULTI && LEAN) {
-    // The pipelined SwingRacket step kernel keeps its own placement of the constants (naming them as above costs it 3 %), but the four
-    // arguments of its rare branches -- the reset's RNG key, the parking record's pointers -- which the compiler hoists out of those
-    // branches to the top of the substep, behind a wait of their own, are better fetched here too: 1110-1118 -> 1129-1134 M (also
-    // measured: the substeps / pool pointers with them: the same; counters and terminal observations as well: 1060 M).
-    asm volatile("" :: "s"(A.seed), "s"(A.env_id_base), "s"(A.ff_rec), "s"(A.ff_flag));
-  }
 #endif
   Manifold M;
   init_manifold(M, POLICY ? (int)(threadIdx.x & 63) : (int)threadIdx.x, POLICY ? 64 : (int)blockDim.x, !REGROWS);
@@ -780,9 +763,9 @@ __global__ void __launch_bounds__((2 * S + 1) * 64) tb_policy_rollout_kernel(KAr
   // The free-flight constants of the substep as VECTOR registers for the whole launch. As kernel arguments they are scalar loads
   // that the compiler, at its SGPR limit in this kernel, re-issues inside the per-step loop (two dozen of them, each behind a wait
   // the lone env wave cannot hide); the env wave has ~300 vector registers to spare, and a value that went through an empty asm
-  // cannot be fetched again. (TB_POLICY_VGPR_PARAMS 0: A/B builds that pass the argument block itself.)
+  // cannot be fetched again.
   KParams Pl = A.P;
-#if TB_POLICY_VGPR_PARAMS
+#if TB_HINT_POLICY_VGPR_PARAMS
 #define TB_PIN(f) asm volatile("" : "+v"(Pl.f))
   TB_PIN(dt); TB_PIN(gravity); TB_PIN(lin_damp); TB_PIN(ang_damp); TB_PIN(lin_damp_quad); TB_PIN(ang_damp_quad); TB_PIN(max_ang_step); TB_PIN(contact_threshold);
   TB_PIN(racket_inv_mass); TB_PIN(racket_inertia[0]); TB_PIN(racket_inertia[1]); TB_PIN(racket_inertia[2]);
@@ -945,20 +928,11 @@ __global__ void __launch_bounds__(TB_FF_SORT_BLOCK) tb_ff_sort_kernel(KArgs A, f
 // one or two per kernel. Same arithmetic per env, same results, complete after the flush as before. A lane that finds the pool
 // full (ff_cap records) finishes its loop here instead; lanes that pass that check together may overshoot the capacity by what
 // all resident waves can hold, and the pool is allocated with that much slack.
+constexpr int TB_PHASE_LANES = 64;    // survivors per wave in the phase kernels behind the first (32 measured: EXPERIMENTS.md)
+constexpr int TB_PHASE_GRID_DIV = 256; // their grid: n / 256 one-wave workgroups (measured / 128 ... / 1024)
+constexpr int TB_BUDGET_MARGIN = 8;
 template <bool RG, bool BIG, bool ESC = false, bool POOL = false>
-#ifndef TB_PHASE_LANES
-#define TB_PHASE_LANES 64  // survivors per wave in the phase kernels behind the first (32 measured: see EXPERIMENTS.md)
-#endif
-#ifndef TB_PHASE_GRID_DIV
-#define TB_PHASE_GRID_DIV 256
-#endif
-#ifndef TB_BUDGET_MARGIN
-#define TB_BUDGET_MARGIN 8  // substeps beyond the ballistic estimate before a lane is handed to the next phase
-#endif
-#ifndef TB_ESC_WAVES
-#define TB_ESC_WAVES 4
-#endif
-__global__ void __launch_bounds__(64, (ESC && !RG) ? TB_ESC_WAVES : 1) tb_ff_kernel(KArgs A) {
+__global__ void __launch_bounds__(64, (ESC && !RG) ? 4 : 1) tb_ff_kernel(KArgs A) {
   static_assert(!POOL || !ESC, "the pool has no hand-over phase behind it");
   constexpr int TB_FF_REC = ff_rec<RG>();
   __shared__ float4 s_hull[TB_HULL_LDS];
@@ -1005,7 +979,7 @@ __global__ void __launch_bounds__(64, (ESC && !RG) ? TB_ESC_WAVES : 1) tb_ff_ker
       // most balls -- is finished with everybody else's long flights at the join, not four kernels at a time
       int budget = 0x7fffffff;
       if (A.ff_next) {
-        budget = 4 * predict_flight(A.P, e.b.p, e.b.v) + TB_BUDGET_MARGIN;
+        budget = 4 * predict_flight(A.P, e.b.p, e.b.v) + TB_BUDGET_MARGIN;  // substeps beyond the ballistic estimate before a lane is handed to the next phase
         if (POOL) budget = (budget < 112 ? budget : 112) + A.ff_extra;
       }
       const int ns0 = ns;
@@ -1374,9 +1348,6 @@ int launch_ff(TbHandle* h, int slot, const KArgs& a_in, const void* term, const 
     }
     const bool big = h->n >= 131072;
     const bool esc = big && ph == 0 && phases > 1;
-#ifdef TB_ESC_GRID_CAP  // (A/B builds: the first phase as at most this many resident waves, see EXPERIMENTS.md)
-    if (esc && (int)grid.x > TB_ESC_GRID_CAP) grid = dim3((unsigned)TB_ESC_GRID_CAP);
-#endif
     const size_t lds = esc && !rg ? sizeof(float) * 64 * TB_ROWS_LDS_TWO : dyn_lds(false, rg, 64);
     if (esc) { if (rg) hipLaunchKernelGGL((tb_ff_kernel<true, true, true>), grid, block, lds, side, k); else hipLaunchKernelGGL((tb_ff_kernel<false, true, true>), grid, block, lds, side, k); }
     else if (rg) { if (big) hipLaunchKernelGGL((tb_ff_kernel<true, true>), grid, block, lds, side, k); else hipLaunchKernelGGL((tb_ff_kernel<true, false>), grid, block, lds, side, k); }
