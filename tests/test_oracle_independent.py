@@ -1,0 +1,216 @@
+"""An independently STRUCTURED restatement of one substep, against the oracle's float64 build.
+
+oracle/tb_oracle.c and the HIP kernels are deliberate twins (same operations in the same order, one author), so their bit-for-bit
+agreement says nothing about a formula both got wrong. Here the same published model is
+written a third time in another shape -- dense 12 x 12 inverse mass matrix, explicit 1 x 12 Jacobian rows, projected Gauss-Seidel on
+J M^-1 J^T -- with none of the hand-derived shortcuts of the C / HIP code (no pre-multiplied angular responses, no separate static /
+racket row types, no world-inertia special cases, rotation matrices instead of quaternion sandwiches). Only the narrowphase result
+(distance, normal, contact point) is taken from the oracle's own query functions, whose geometry has its own brute-force tests
+(test_oracle_kat.py). Agreement: exact in free flight (drag, gyroscopic term), 2e-9 for bounces on the court, the goal and the net, 3e-6
+for random oblique hits on a tumbling racket -- there the state's quaternion is a float32 one, unit to 6e-8 only, the racket-frame
+normal rotated by it is as long as that, and the oracle (like Bullet) takes a contact normal for a unit vector where the dense
+form computes n . M^-1 n: 2e-7 of a 10 m/s impulse. A wrong effective mass, Jacobian sign or friction frame would show as 1e-2.
+"""
+import numpy as np
+import pytest
+
+from helpers import make_words
+from oracle import OracleBatch, query_box, query_goal, query_racket
+from tennisbot_rl_amd.params import ENV_SWING, default_params
+
+DT = 1.0 / 240.0
+
+
+def f64(x):
+    """a float32 parameter as the float64 build reads it: the shortest decimal that round-trips"""
+    return float(np.format_float_positional(np.float32(x), unique=True))
+
+
+def rotmat(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def plane_space(n):
+    """Bullet's btPlaneSpace1 (published in LinearMath/btVector3.h)"""
+    if abs(n[2]) > np.sqrt(0.5):
+        a = n[1] * n[1] + n[2] * n[2]
+        k = 1.0 / np.sqrt(a)
+        p = np.array([0.0, -n[2] * k, n[1] * k])
+        q = np.array([a * k, -n[0] * p[2], n[0] * p[1]])
+    else:
+        a = n[0] * n[0] + n[1] * n[1]
+        k = 1.0 / np.sqrt(a)
+        p = np.array([-n[1] * k, n[0] * k, 0.0])
+        q = np.array([-n[2] * p[1], n[2] * p[0], a * k])
+    return p, q
+
+
+def substep_dense(P, rk, bl, F_racket, T_racket, contacts, sweeps):
+    """rk = (p, q, v, w), bl = (p, v, w); contacts: list of dicts(n, dist, rr or None, e, mu) in the solver's row order.
+    Returns the state after one substep."""
+    mr, mb, r = 1.0 / f64(P.racket_inv_mass), 1.0 / f64(P.ball_inv_mass), f64(P.ball_radius)
+    Ib = 1.0 / f64(P.ball_inv_inertia)
+    I = np.diag([f64(x) for x in P.racket_inertia])
+    k1, k2, a1, a2, g = f64(P.lin_damp), f64(P.lin_damp_quad), f64(P.ang_damp), f64(P.ang_damp_quad), f64(P.gravity)
+    erp, vthr = f64(P.erp), f64(P.rest_vel_threshold)
+    rp, rq, rv, rw = (np.array(x, float) for x in rk)
+    bp, bv, bw = (np.array(x, float) for x in bl)
+    R = rotmat(rq)
+    # (2) velocity update: v += dt (F/m + g - v (k1 + k2 |v|)); body-frame Euler equation with the same drag on the angular momentum
+    rv = rv + DT * (np.array(F_racket) / mr - np.array([0, 0, g]) - rv * (k1 + k2 * np.linalg.norm(rv)))
+    wb = R.T @ rw
+    if np.any(rw != 0) or np.any(np.array(T_racket) != 0):
+        L = I @ wb
+        wb_dot = np.linalg.solve(I, R.T @ np.array(T_racket) - np.cross(wb, L) - L * (a1 + a2 * np.linalg.norm(wb)))
+        rw = rw + DT * (R @ wb_dot)
+    bv = bv + DT * (-np.array([0, 0, g]) - bv * (k1 + k2 * np.linalg.norm(bv)))
+    if np.any(bw != 0):
+        bw = bw + DT * (-bw * (a1 + a2 * np.linalg.norm(bw)))
+    # (3) projected Gauss-Seidel on generalised velocities u = [racket v, racket w, ball v, ball w]
+    Minv = np.zeros((12, 12))
+    Minv[0:3, 0:3] = np.eye(3) / mr
+    Minv[3:6, 3:6] = R @ np.linalg.inv(I) @ R.T
+    Minv[6:9, 6:9] = np.eye(3) / mb
+    Minv[9:12, 9:12] = np.eye(3) / Ib
+    u = np.concatenate([rv, rw, bv, bw])
+    rows = []
+    for c in contacts:
+        n = np.array(c["n"], float)
+        t1, t2 = plane_space(n)
+        rb = -r * n
+
+        def jac(d, c=c, rb=rb):
+            J = np.zeros(12)
+            J[6:9] = d; J[9:12] = np.cross(rb, d)        # ball point velocity: v_b + w_b x rb
+            if c["rr"] is not None:                      # minus the racket point velocity: v_r + w_r x rr
+                J[0:3] = -d; J[3:6] = -np.cross(np.array(c["rr"]), d)
+            return J
+        Jn, J1, J2 = jac(n), jac(t1), jac(t2)
+        vn = Jn @ u
+        rest = 0.0 if abs(vn) < vthr else max(0.0, c["e"] * (-vn))
+        pos = -c["dist"] / DT if c["dist"] > 0 else -c["dist"] * erp / DT
+        rows.append(dict(Jn=Jn, J1=J1, J2=J2, target=rest + pos, mu=c["mu"], jn=0.0, j1=0.0, j2=0.0))
+    for _ in range(sweeps):
+        for c in rows:  # all normal rows first ...
+            k = 1.0 / (c["Jn"] @ Minv @ c["Jn"])
+            jn = max(0.0, c["jn"] + (c["target"] - c["Jn"] @ u) * k)
+            u = u + Minv @ c["Jn"] * (jn - c["jn"]); c["jn"] = jn
+        for c in rows:  # ... then the friction rows, boxed by mu x the row's current normal impulse
+            lim = c["mu"] * c["jn"]
+            if not lim > 0:
+                continue
+            for J, key in ((c["J1"], "j1"), (c["J2"], "j2")):
+                k = 1.0 / (J @ Minv @ J)
+                j = min(lim, max(-lim, c[key] - (J @ u) * k))
+                u = u + Minv @ J * (j - c[key]); c[key] = j
+    rv, rw, bv, bw = u[0:3], u[3:6], u[6:9], u[9:12]
+    # (4) pose update: exponential map of w dt
+    rp, bp = rp + DT * rv, bp + DT * bv
+    ang = np.linalg.norm(rw) * DT
+    if ang > 0:
+        assert ang < 0.25 * np.pi  # (the clamp quirk has its own test; not exercised here)
+        ax = rw / np.linalg.norm(rw)
+        dq = np.concatenate([ax * np.sin(0.5 * ang), [np.cos(0.5 * ang)]])
+        x1, y1, z1, w1 = dq; x2, y2, z2, w2 = rq
+        rq = np.array([w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2,
+                       w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2])
+        rq = rq / np.linalg.norm(rq)
+    return (rp, rq, rv, rw), (bp, bv, bw)
+
+
+def _compare(P, n, fields, goal, sweeps, want_hits, tol=2e-9):
+    w, d = make_words(ENV_SWING, n, goal=goal, spawn_pos=(9, 0, 0.6), init_dist=10.0, step_count=5, **fields)
+    b = OracleBatch(P, ENV_SWING, n, precision="f64")
+    b.set_state_words(w, d)
+    s0 = b.get_state()
+    a = np.zeros((n, 6), np.float32)
+    b.step(a)
+    s1 = b.get_state()
+    hits = 0
+    worst = 0.0
+    for i in range(n):
+        rk = (s0["racket_pos"][i], s0["racket_quat"][i], s0["racket_vel"][i], s0["racket_angvel"][i])
+        bl = (s0["ball_pos"][i], s0["ball_vel"][i], s0["ball_angvel"][i])
+        contacts = []  # the solver's row order: racket, ground, net, goal
+        h, dist, nrm, rr = query_racket(P, rk[0], rk[1], bl[0])
+        if h:
+            contacts.append(dict(n=nrm, dist=dist, rr=rr, e=f64(P.rest_racket), mu=f64(P.fric_racket)))
+        h, dist, nrm = query_box(P, np.array(P.ground_half), bl[0])
+        if h:
+            contacts.append(dict(n=nrm, dist=dist, rr=None, e=f64(P.rest_court), mu=f64(P.fric_court)))
+        h, dist, nrm = query_box(P, np.array(P.net_half), bl[0])
+        if h:
+            contacts.append(dict(n=nrm, dist=dist, rr=None, e=f64(P.rest_court), mu=f64(P.fric_court)))
+        h, dist, nrm = query_goal(P, float(goal[0]), float(goal[1]), bl[0])
+        if h:
+            contacts.append(dict(n=nrm, dist=dist, rr=None, e=f64(P.rest_goal), mu=f64(P.fric_goal)))
+        hits += bool(contacts)
+        # agent action 0: F = (0, 0, 4 * 9.81) (swingracket_env.py:76-77), no torque
+        (rp, rq, rv, rw), (bp, bv, bw) = substep_dense(P, rk, bl, (0.0, 0.0, 4 * 9.81), (0.0, 0.0, 0.0), contacts, sweeps)
+        for name, mine in (("racket_pos", rp), ("racket_vel", rv), ("racket_angvel", rw), ("ball_pos", bp), ("ball_vel", bv), ("ball_angvel", bw)):
+            err = np.abs(mine - s1[name][i]).max()
+            worst = max(worst, err)
+            # (spins: the ball's tiny inertia turns a friction impulse into tens of rad/s, so the same relative error is 10 x larger)
+            assert err < (10 * tol if name.endswith("angvel") else tol), (i, name, mine, s1[name][i], len(contacts))
+        qa = s1["racket_quat"][i]
+        assert min(np.abs(rq - qa).max(), np.abs(rq + qa).max()) < tol, (i, rq, qa)
+    assert hits >= want_hits, hits
+    return worst
+
+
+def rot(q, v):
+    u, w = q[:, :3], q[:, 3:4]
+    t = 2 * np.cross(u, v)
+    return v + w * t + np.cross(u, t)
+
+
+@pytest.mark.parametrize("sweeps", [1, 4])
+def test_oblique_hits_on_a_tumbling_racket_match_a_dense_pgs(sweeps):
+    """the racket row with friction, restitution, ERP / speculative margin, drag and the gyroscopic term: 96 random hits, the oracle
+    held to exactly `sweeps` solver sweeps (tolerance 0) so that both run the same iteration"""
+    n = 96
+    rng = np.random.default_rng(5 + sweeps)
+    P = default_params(solver_iters=sweeps, solver_tol=0.0)
+    r = float(P.ball_radius)
+    q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    rp = np.tile(np.array((10.0, 0.0, 3.0)), (n, 1))
+    side = np.where(rng.random(n) < 0.5, -1.0, 1.0)
+    gap = rng.uniform(-0.003, 0.0006, n)  # from 3 mm of penetration (ERP) to inside the speculative margin
+    loc = np.stack([side * (float(P.racket_half_thick) + float(P.hull_margin) + r + gap), rng.uniform(-0.09, 0.09, n), rng.uniform(-0.25, 0.15, n)], 1)
+    vin = np.stack([-side * rng.uniform(0.05, 12, n), rng.uniform(-4, 4, n), rng.uniform(-4, 4, n)], 1)
+    rv, rw = rng.uniform(-2, 2, (n, 3)), rng.uniform(-6, 6, (n, 3))
+    fields = dict(racket_pos=rp, racket_quat=q, racket_vel=rv, racket_angvel=rw, ball_pos=rp + rot(q, loc), ball_vel=rv + rot(q, vin),
+                  ball_angvel=rng.uniform(-30, 30, (n, 3)))
+    # one sweep: the unit-normal convention shows (module docstring); four sweeps: both have converged to the same velocities (1e-13)
+    _compare(P, n, fields, goal=(-7.0, 1.0), sweeps=sweeps, want_hits=n // 2, tol=3e-6 if sweeps == 1 else 2e-9)
+
+
+def test_bounces_on_court_goal_and_net_match_a_dense_pgs():
+    """static rows: ball on the court (top face, near an edge of the box: corner normals), on the goal cylinder's top and rim, on the
+    net's side and top, with spin and sliding; racket far away, tumbling freely"""
+    n = 90
+    rng = np.random.default_rng(11)
+    P = default_params(solver_iters=3, solver_tol=0.0)
+    r = float(P.ball_radius)
+    goal = (-7.0, 1.0)
+    bp = np.zeros((n, 3))
+    k = n // 3
+    # court: over the top face, a few right at the x = +14 edge
+    bp[:k] = np.stack([rng.uniform(-13, 13.99, k), rng.uniform(-6.9, 6.9, k), float(P.ground_half[2]) + r + rng.uniform(-0.002, 0.0005, k)], 1)
+    bp[:6, 0] = float(P.ground_half[0]) + rng.uniform(0.0, 0.5 * r, 6)
+    # goal: on its top face and around its rim
+    ang, rad = rng.uniform(0, 2 * np.pi, k), np.concatenate([rng.uniform(0, 1.4, k // 2), float(P.goal_radius) + rng.uniform(-0.01, 0.5 * r, k - k // 2)])
+    bp[k:2 * k] = np.stack([goal[0] + rad * np.cos(ang), goal[1] + rad * np.sin(ang), float(P.goal_half_len) + r + rng.uniform(-0.002, 0.0005, k)], 1)
+    # net: against its +x / -x faces and on its top
+    sx = np.where(rng.random(n - 2 * k) < 0.5, -1.0, 1.0)
+    bp[2 * k:] = np.stack([sx * (float(P.net_half[0]) + r + rng.uniform(-0.002, 0.0005, n - 2 * k)), rng.uniform(-6, 6, n - 2 * k), rng.uniform(0.1, 0.45, n - 2 * k)], 1)
+    bp[-8:, 0] = rng.uniform(-0.05, 0.05, 8); bp[-8:, 2] = float(P.net_half[2]) + r + rng.uniform(-0.002, 0.0005, 8)
+    bv = np.stack([rng.uniform(-6, 6, n), rng.uniform(-6, 6, n), rng.uniform(-9, 0.5, n)], 1)
+    bv[2 * k:, 0] = -np.sign(bp[2 * k:, 0]) * rng.uniform(0.05, 8, n - 2 * k)
+    q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    fields = dict(racket_pos=(9.0, 0.0, 5.0), racket_quat=q, racket_vel=rng.uniform(-2, 2, (n, 3)), racket_angvel=rng.uniform(-6, 6, (n, 3)),
+                  ball_pos=bp, ball_vel=bv, ball_angvel=rng.uniform(-40, 40, (n, 3)))
+    _compare(P, n, fields, goal=goal, sweeps=3, want_hits=int(0.8 * n))
