@@ -328,8 +328,14 @@ class PPOTrainer:
         while self.num_timesteps < total_timesteps:
             t0 = time.perf_counter()
             last_value = self.collect()
+            shards = None
             if gather_rollouts and self.world > 1:
-                self.buf.all_gather()  # the collect-boundary exchange of SURVEY.md 8e (one collective)
+                # the collect-boundary exchange of SURVEY.md 8e (one collective). What consumes it HERE: the statistics below are
+                # the whole node's, as the reference's single-process learner reports them (ep_rew_mean over all its envs) -- the
+                # update itself stays data-parallel on the rank's own shard with gradient all-reduces (it is 300 x the collect's
+                # time, and every rank repeating it on the gathered batch would throw the other GPUs away); a single-learner design
+                # would take RolloutBuffer.concatenated(shards) instead. gather_rollouts=False skips the exchange.
+                shards = self.buf.all_gather()
             self.torch.cuda.synchronize(self.device)
             t1 = time.perf_counter()
             adv, returns = self.advantages(last_value)
@@ -340,9 +346,12 @@ class PPOTrainer:
             if c["nonfinite_states"] or c["lockstep_violations"]:
                 raise StepperError("rollout %d: %d env states went non-finite, %d episode ends fell outside the pipelined launches' slots "
                                    "(their terminal rewards are lost)" % (len(history), c["nonfinite_states"], c["lockstep_violations"]))
-            ep = float(self.buf.dones.sum())
+            if shards is None:
+                ep, rew_sum = float(self.buf.dones.sum()), float(self.buf.rewards.sum())
+            else:  # every rank holds every shard: global figures without another collective
+                ep, rew_sum = sum(float(sh[3].sum()) for sh in shards), sum(float(sh[2].sum()) for sh in shards)
             stats.update(timesteps=self.num_timesteps, episodes=ep,
-                         mean_episode_reward=float(self.buf.rewards.sum()) / max(ep, 1.0),
+                         mean_episode_reward=rew_sum / max(ep, 1.0),
                          collect_steps_per_s=self.n_steps * self.num_envs * self.world / (t1 - t0), update_s=t2 - t1)
             history.append(stats)
             if log and self.rank == 0:
