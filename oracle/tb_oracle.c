@@ -232,7 +232,7 @@ typedef struct {
   uint8_t done;
   Manifold m;
 #ifdef TBO_TRACE_STATIONARY
-  struct { int timed_out, first[5], bits_at_end, n_rg_at_end, substeps, first_racket, ball_below_court; } trace;
+  struct { int timed_out, first[5], bits_at_end, n_rg_at_end, substeps, first_racket, ball_below_court, solves, sweeps, rows; } trace;
 #endif
 } Env;
 
@@ -630,16 +630,26 @@ static inline void snap_take(Snap *s, const Env *e) {
 /* diagnostics (-DTBO_DIAG builds only): solver sweeps and solves so far. Plain globals: single-threaded use -- they are
  * not in the default builds, whose env loop runs under `#pragma omp parallel` (a data race, and a cache line every thread's
  * every solve would fight over inside the cpu_baseline leg). */
-#ifdef TBO_DIAG
+#ifdef TBO_TRACE_STATIONARY
+static __thread int t_sweeps, t_solves, t_rows;  /* of the calling thread's current env: summed into Env.trace by swing_step */
+#define TBO_COUNT(x) ((void)0)
+#define TBO_TRACE_SOLVE(nrg) (t_solves++, t_rows += (nrg))
+#define TBO_TRACE_SWEEP() (t_sweeps++)
+#elif defined(TBO_DIAG)
 static uint64_t g_sweeps, g_solves;
 void tbo_debug_solver(uint64_t out[2], int reset) { out[0] = g_sweeps; out[1] = g_solves; if (reset) { g_sweeps = 0; g_solves = 0; } }
 #define TBO_COUNT(x) ((x)++)
+#define TBO_TRACE_SOLVE(nrg) ((void)0)
+#define TBO_TRACE_SWEEP() ((void)0)
 #else
 #define TBO_COUNT(x) ((void)0)
+#define TBO_TRACE_SOLVE(nrg) ((void)0)
+#define TBO_TRACE_SWEEP() ((void)0)
 #endif
 static void solve_contacts(const Prm *P, Row *rows, int nrows, RowG *rg, int nrg, Racket *rk, Ball *b) {
   const real r = P->ball_radius;
   TBO_COUNT(g_solves);
+  TBO_TRACE_SOLVE(nrg);
   real jref = R(0); /* largest normal impulse seen in this solve: the scale updates are judged against */
   /* warm start of the racket<->court rows: the cached impulses of the last solve are applied before the first sweep */
   for (int i = 0; i < nrg; ++i) {
@@ -652,6 +662,7 @@ static void solve_contacts(const Prm *P, Row *rows, int nrows, RowG *rg, int nrg
   for (int it = 0; it < P->solver_iters; ++it) {
     int moved = 0;
     TBO_COUNT(g_sweeps);
+    TBO_TRACE_SWEEP();
     for (int i = 0; i < nrows; ++i) {
       Row *c = &rows[i];
       v3 rb = mul3(-r, c->n);
@@ -945,6 +956,7 @@ static real swing_step(const Prm *P, Env *e, const float *a, int *substeps, uint
     v3 Fp = zero; /* forces were cleared by the substep above */
 #ifdef TBO_TRACE_STATIONARY
     Snap ring[TRACE_MAXP + 1]; int first[TRACE_MAXP + 1] = {-1, -1, -1, -1, -1}, nloop = 0, first_racket = -1;
+    t_sweeps = 0; t_solves = 0; t_rows = 0;
     snap_take(&ring[0], e); nloop = 1; /* ring[0]: the state the loop starts from (no force pending: not comparable, kept for indexing) */
 #endif
     while (!e->done) { /* :106 */
@@ -973,7 +985,7 @@ static real swing_step(const Prm *P, Env *e, const float *a, int *substeps, uint
       if (e->step_count > 800) {
         e->trace.timed_out = !e->done; e->trace.bits_at_end = bits; e->trace.n_rg_at_end = e->m.n; e->trace.substeps = nloop - 1;
         for (int p = 0; p <= TRACE_MAXP; ++p) e->trace.first[p] = first[p];
-        e->trace.first_racket = first_racket;
+        e->trace.first_racket = first_racket; e->trace.solves = t_solves; e->trace.sweeps = t_sweeps; e->trace.rows = t_rows;
         e->trace.ball_below_court = e->b.p.z < -(P->ground_half[2] + P->ball_radius);
       }
 #endif
@@ -1146,12 +1158,13 @@ void tbo_set_state(TboBatch *B, const uint32_t *words, const uint8_t *done) {
 
 #ifdef TBO_TRACE_STATIONARY
 /* out[i] = {timed_out, first[1..4], contact bits of the last substep, cached racket<->court points, loop substeps,
- * first substep of the racket-and-cache-only fixed point, ball below the court at the end}; clears the records */
+ * first substep of the racket-and-cache-only fixed point, ball below the court at the end, contact solves / solver sweeps /
+ * racket<->court rows summed over the solves of that fast-forward}; clears the records */
 void tbo_trace_stationary(TboBatch *B, int32_t *out) {
   for (int i = 0; i < B->n; ++i) {
     Env *e = &B->e[i];
-    int32_t *o = out + 10 * (size_t)i;
-    o[8] = e->trace.first_racket; o[9] = e->trace.ball_below_court;
+    int32_t *o = out + 13 * (size_t)i;
+    o[8] = e->trace.first_racket; o[9] = e->trace.ball_below_court; o[10] = e->trace.solves; o[11] = e->trace.sweeps; o[12] = e->trace.rows;
     o[0] = e->trace.timed_out; for (int p = 1; p <= TRACE_MAXP; ++p) o[p] = e->trace.first[p];
     o[5] = e->trace.bits_at_end; o[6] = e->trace.n_rg_at_end; o[7] = e->trace.substeps;
     memset(&e->trace, 0, sizeof e->trace);

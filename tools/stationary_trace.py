@@ -79,11 +79,11 @@ def run(L, actions, episodes, n, threads, rolling, seed):
             a = pol.act(obs, rng) if pol else rng.uniform(-1, 1, (n, 6)).astype(np.float32)
             L.tbo_step(h, _p(a), _p(obs), _p(rew), _p(done), None, _p(sub))
         assert done.all()
-        tr = np.zeros((n, 10), np.int32)
+        tr = np.zeros((n, 13), np.int32)
         L.tbo_trace_stationary(h, _p(tr))
         recs.append(tr[tr[:, 0] != 0].copy())
     L.tbo_destroy(h)
-    return np.concatenate(recs) if recs else np.zeros((0, 10), np.int32)
+    return np.concatenate(recs) if recs else np.zeros((0, 13), np.int32)
 
 
 def summarize(tr, episodes):
@@ -112,6 +112,11 @@ def summarize(tr, episodes):
     if rk.any():
         k = tr[rk, 8]
         out["racket_alone_first_substep"] = {"min": int(k.min()), "median": int(np.median(k)), "max": int(k.max())}
+    on = tr[:, 6] > 0
+    if on.any():  # what a straggler with the racket on the court costs: solves of the loop, sweeps per solve, racket<->court rows per solve
+        out["grounded_stragglers_solves_mean"] = float(tr[on, 10].mean())
+        out["grounded_stragglers_sweeps_per_solve"] = float(tr[on, 11].sum() / max(tr[on, 10].sum(), 1))
+        out["grounded_stragglers_ground_rows_per_solve"] = float(tr[on, 12].sum() / max(tr[on, 10].sum(), 1))
     out["unsettled_ball_on_racket"] = int((((tr[:, 5] & 1) != 0) & (shortest == 0)).sum())
     out["unsettled_racket_on_court"] = int(((tr[:, 6] > 0) & (shortest == 0)).sum())
     return out
@@ -164,6 +169,10 @@ which has no gravity compensation (`:135-141`) -- lies on the court and slides a
 (-50 (x - spawn_x): a 4 kg body on a mu = 0.04 contact): it is not at rest at the limit either (last column). What round 3
 wrote about these envs ("the ball at rest on the grounded racket") was wrong: the ball is 13-20 m under the court.
 
+What such a straggler costs: with random actions a grounded one solves contacts in %s of its 775 loop substeps, **%s sweeps per
+solve over %s racket<->court rows** (3 directions each) -- the sequential-impulse solver converging on a racket that slides and
+spins on four points -- i.e. ~4000 dependent row updates per substep on ONE lane: the 12-20 us per substep measured on the GPU.
+
 Consequence: the 775 substeps cannot be skipped *exactly*. The outputs a skipped straggler would need are its reward (0),
 its `done`, its counters and -- without auto-reset, or with `terminal_observation` tracked -- the racket's final x, y,
 which is the result of 775 substeps of a 4-point contact solve. A conservative "the ball can no longer touch anything"
@@ -171,7 +180,9 @@ test would have to bound the sliding racket's motion for up to 3.2 s (it can lea
 same terminal speed: both bodies carry the same drag per unit mass); we found no bound that is both provable and fires
 before most of the substeps have been spent. `TB_F_RACKET_GROUND` therefore stays opt-in
 (110-150 M env steps/s at 4096 envs against 1.1 G without it: DESIGN.md section 3); the reason is this table.
-""" % (args.episodes, args.envs, "\n".join(rows))
+""" % (args.episodes, args.envs, "\n".join(rows), "%.0f" % results["random"].get("grounded_stragglers_solves_mean", float("nan")),
+       "%.1f" % results["random"].get("grounded_stragglers_sweeps_per_solve", float("nan")),
+       "%.1f" % results["random"].get("grounded_stragglers_ground_rows_per_solve", float("nan")))
 
 
 if __name__ == "__main__":
