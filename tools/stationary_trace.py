@@ -171,7 +171,8 @@ wrote about these envs ("the ball at rest on the grounded racket") was wrong: th
 
 What such a straggler costs: with random actions a grounded one solves contacts in %s of its 775 loop substeps, **%s sweeps per
 solve over %s racket<->court rows** (3 directions each) -- the sequential-impulse solver converging on a racket that slides and
-spins on four points -- i.e. ~4000 dependent row updates per substep on ONE lane: the 12-20 us per substep measured on the GPU.
+spins on four points -- i.e. ~100 row updates = ~4000 dependent instructions per substep on ONE lane: the 12-20 us per substep
+measured on the GPU.
 
 Consequence: the 775 substeps cannot be skipped *exactly*. The outputs a skipped straggler would need are its reward (0),
 its `done`, its counters and -- without auto-reset, or with `terminal_observation` tracked -- the racket's final x, y,
