@@ -29,7 +29,7 @@
 // The planes used to be kernel arguments: 36 SGPRs the loop-free step kernels had to spill at their very start.
 #define TB_HULL_PLANES (2 * TB_MAX_HULL)
 #define TB_HULL_KP (2 * TB_MAX_HULL + 9)
-// ... and behind the planes a copy of the whole KParams block (TB_KP_ROWS float4) for the COLD instantiations of substep
+// ... and behind the planes a copy of the whole KParams block (TB_KP_ROWS float4) for the SF_COLD forms of substep
 #define TB_KP_ROWS 18
 #define TB_HULL_LDS (TB_HULL_KP + TB_KP_ROWS)
 #define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
@@ -152,7 +152,7 @@ struct Hit {
 };
 
 constexpr int CT_RACKET = 1, CT_GROUND = 2, CT_NET = 4, CT_GOAL = 8, CT_RACKET_COURT = 16;
-constexpr int CT_ESCAPE = 32;  // not a contact: substep<ESC> left the env untouched, see there
+constexpr int CT_ESCAPE = 32;  // not a contact: substep's SF_ESC form left the env untouched, see there
 
 // TB_STAMP / TB_LANES / TB_DIAG_*: instrumentation of the diagnostic builds only (cycle stamps, lane census, timing ablations).
 // All of it lives in tb_diag.hpp; in the product build every one of these macros expands to nothing.
@@ -497,7 +497,7 @@ struct RowS {  // ball vs static shape
   float mu, target, jn, jt1, jt2;
 };
 // a static row in its lane's LDS column (word w of row i at st[(14 i + w) * stride]).
-// TWO: two slots instead of three -- the net's row and the goal's share the second (substep<ESC> hands an env that is near both
+// TWO: two slots instead of three -- the net's row and the goal's share the second (substep's SF_ESC form hands an env that is near both
 // to the next phase kernel before anything is stored): 28 words per lane instead of 42, a fourth wave per SIMD for the kernel
 // that runs nearly all of a large batch's fast-forward substeps.
 template <bool TWO> TB_DEV constexpr int row_slot(int i) { return TWO && i == 2 ? 1 : i; }
@@ -1138,17 +1138,17 @@ template <int KIND> TB_DEV bool near_goal(const KParams& P, float zlow) { return
 // the narrowphase is arranged as cheap per-lane culls + wave votes: a wave runs the outline
 // sweep / the static tests / the impulse solver only if __any lane needs them, and those
 // branches are wave-uniform (s_cbranch on the ballot), never if-converted into the hot path.
-// COLD: the contact path reads its constants from the LDS copy of the parameter block instead of holding them in SGPRs all the
+// SF_COLD: the contact path reads its constants from the LDS copy of the parameter block instead of holding them in SGPRs all the
 // time. Pays where SGPRs are scarce and contacts rare (the policy rollout kernel: 97 -> 70 spill writes, collect +10 %); costs VGPRs and
 // LDS reads where throughput counts (SwingRacket at 1 M envs -15 %, Tennisbot -4 %), so only that kernel asks for it.
-// ESC (first phase of the large-batch fast-forward): a lane whose ball gets past the racket's culls -- it needs the exact outline
+// SF_ESC (first phase of the large-batch fast-forward): a lane whose ball gets past the racket's culls -- it needs the exact outline
 // sweep, and probably a racket row in the solver next -- does not run them here, where 63 other lanes would wait for it (0.2 % of
 // the lanes ask, but every ninth wave-substep has one: sweep + racket row + its solve are ~15 % of the loop's instructions).
 // It returns CT_ESCAPE with the env UNTOUCHED (the culls read poses only and come first), the caller hands the env to the next
 // phase kernel as a survivor, and that kernel repeats this substep with everything compiled in -- among lanes that mostly want
 // the same. Same arithmetic, same order per env: bit-identical.
-// REGGROUND: see solve_contacts (the looping small-batch kernels ask for it)
-// LAZYTAB (the pipelined SwingRacket step kernel: ONE substep per launch): `hull`, the LDS copy of the outline table, is EMPTY on
+// SF_REGGROUND: see solve_contacts (the looping small-batch kernels ask for it)
+// SF_LAZYTAB (the pipelined SwingRacket step kernel: ONE substep per launch): `hull`, the LDS copy of the outline table, is EMPTY on
 // entry. Nothing reads it before a ball gets past the racket's slab test -- in the 25 short steps of a random-action episode none
 // does -- so the copy (2.5 KB from `table_mem`, by the wave that needs it, no barrier: a wave's LDS operations complete in order)
 // is made right there, behind a wave vote, instead of by every launch up front (0.4 us of a ~4 us launch, tools/diag/lanes_per_wave.hip).

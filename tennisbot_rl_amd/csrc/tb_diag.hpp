@@ -14,6 +14,7 @@
 //                            (tools/diag/diag_lanes.py)
 //   -DTB_DIAG_NO_ANGULAR / _NO_ORIENT / _NO_NARROW (/ _NO_RACKET / _NO_STATICS: its halves)
 //                            timing-only ablations (tools/diag/diag_substep.py); RESULTS ARE WRONG
+//   -DTB_DIAG_NO_PHILOX      timing-only: the reset's Philox draws replaced by a trivial hash (RESULTS ARE WRONG)
 //   -DTB_DIAG_SWEEP_HELPERS=k  helper lanes of the wave-cooperative outline sweep (default 8)
 //   -DTB_DIAG_LDS_PAD        (host side, tb_stepper.hip dyn_lds) pad every step launch's dynamic LDS by tb_diag_set_lds_pad(bytes):
 //                            fewer workgroups per CU (tools/diag/r03_occupancy_probe.py)
@@ -148,6 +149,12 @@ __device__ unsigned int g_diag_cadence_n;
 #define TB_DIAG_ABLATE_NARROW(flag) flag = false
 #else
 #define TB_DIAG_ABLATE_NARROW(flag) do { } while (0)
+#endif
+#ifdef TB_DIAG_NO_PHILOX  // (the reset's random draws replaced by a cheap hash of the same inputs: what does Philox cost a launch?)
+#define TB_DIAG_PHILOX(c0, c1, c2, c3, k0, k1, out) do { uint32_t h_ = (c0) * 2654435761u ^ (c2) * 40503u ^ (c3); \
+  (out)[0] = h_; (out)[1] = h_ * 3u + (k0); (out)[2] = h_ * 5u + (k1); (out)[3] = h_ * 7u + (c1); } while (0)
+#else
+#define TB_DIAG_PHILOX(c0, c1, c2, c3, k0, k1, out) philox4x32(c0, c1, c2, c3, k0, k1, out)
 #endif
 #if defined(TB_DIAG_NO_NARROW) || defined(TB_DIAG_NO_STATICS)
 #define TB_DIAG_ABLATE_STATICS(flag) flag = false

@@ -231,7 +231,7 @@ TB_DEV void reset_env(const KArgs& A, const float4* KP, int i, EnvRegs& e) {
   uint32_t k0 = (uint32_t)A.seed, k1 = (uint32_t)(A.seed >> 32);
   uint32_t c0 = (uint32_t)id, c1 = (uint32_t)(id >> 32);
   uint32_t u[4], w[4];
-  philox4x32(c0, c1, e.episode, 0u, k0, k1, u);
+  TB_DIAG_PHILOX(c0, c1, e.episode, 0u, k0, k1, u);
   vec3 zero = mk(0.0f, 0.0f, 0.0f);
   e.r.v = zero; e.r.w = zero; e.b.v = zero; e.b.w = zero;
   vec3 com = mk(P.racket_com[0], P.racket_com[1], P.racket_com[2]);
@@ -250,7 +250,7 @@ TB_DEV void reset_env(const KArgs& A, const float4* KP, int i, EnvRegs& e) {
     spin_block = 1u;
   } else {
     // tennisbot_env.py:227-246; objects.py:82-96 (ball born at (-9,0,1))
-    philox4x32(c0, c1, e.episode, 1u, k0, k1, w);
+    TB_DIAG_PHILOX(c0, c1, e.episode, 1u, k0, k1, w);
     float x = uniform(7.5f, 5.0f, u[0]), y = uniform(-5.0f, 10.0f, u[1]), z = uniform(0.2f, 0.21f - 0.2f, u[2]);
     quat q0; q0.x = 0.0f; q0.y = 0.0f; q0.z = 0.0f; q0.w = 1.0f;
     e.r.q = q0;
@@ -264,7 +264,7 @@ TB_DEV void reset_env(const KArgs& A, const float4* KP, int i, EnvRegs& e) {
     spin_block = 2u;
   }
   if (P.ball_spin_max != 0.0f) {  // extension; 0 reproduces the reference
-    philox4x32(c0, c1, e.episode, spin_block, k0, k1, w);
+    TB_DIAG_PHILOX(c0, c1, e.episode, spin_block, k0, k1, w);
     float m = P.ball_spin_max;
     e.b.w = mk(uniform(-m, 2.0f * m, w[0]), uniform(-m, 2.0f * m, w[1]), uniform(-m, 2.0f * m, w[2]));
   }
@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
   // pays more for the table's addresses than the copy costs it (918 -> 899 M, 32768 envs 5.17 -> 4.80 G): it keeps the LDS copy,
   // like every kernel that loops (fast-forward, tb_rollout, the fused policy).
   constexpr bool TABLE_IN_MEMORY = !POLICY && !MULTI && KIND == TB_ENV_TENNIS;
-  // LAZYTAB (tb_step on pipelined SwingRacket without the extended contact set): the LDS copy is made by the first wave that reads it (substep<LAZYTAB>)
+  // LAZYTAB (tb_step on pipelined SwingRacket without the extended contact set): the LDS copy is made by the first wave that reads it (substep's SF_LAZYTAB form)
   constexpr bool LAZYTAB = !POLICY && !MULTI && KIND == TB_ENV_SWING && LEAN && !RG;
   constexpr unsigned FORM = (RG ? SF_RG : 0u) | (REGROWS ? SF_REGROWS : 0u) | (LAZYTAB ? SF_LAZYTAB : 0u);
   __shared__ float4 s_lds_hull[TABLE_IN_MEMORY ? 1 : TB_HULL_LDS];
@@ -910,10 +910,10 @@ __global__ void __launch_bounds__(TB_FF_SORT_BLOCK) tb_ff_sort_kernel(KArgs A, f
 //   phases 2+: grid-stride over the *A.ff_src_count survivors of the previous phase, 64 per wave.
 // BIG: the instantiation for batches that fill the chip several times over (occupancy counts: cull planes re-read from
 // LDS, see racket_planes, and the outline sweep shared by the wave); below that the loop's latency counts and the planes stay in registers.
-// ESC: the first phase of a BIG fast-forward with a phase behind it also hands over every env whose ball reaches the racket (substep<ESC>).
+// ESC: the first phase of a BIG fast-forward with a phase behind it also hands over every env whose ball reaches the racket (substep's SF_ESC form).
 // (ESC without the extended contact set is also built for four waves per SIMD: 125 VGPRs without spills in rounds 1-2, 128 with 6
 //  spilled under round 3's build flags, where three waves at 129 VGPRs measure the same -- and, with the
-//  two-slot static rows of substep<ESC>, 9.5 KB of LDS per wave: 16 waves per CU instead of 12; 1 M envs, same box: 9.3-9.4 ->
+//  two-slot static rows of substep's SF_ESC form, 9.5 KB of LDS per wave: 16 waves per CU instead of 12; 1 M envs, same box: 9.3-9.4 ->
 //  10.0 G env steps/s)
 // POOL (up to 131 072 envs, TbOptions.ff_defer): THE POOL. Two uses of the same instantiation: (1) the POOL RUN -- whole episodes
 // that the step kernels parked straight into the pool (ff_defer = 2: the automatic choice up to 16 384 envs, see defer_mode), or
