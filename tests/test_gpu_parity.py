@@ -1384,6 +1384,37 @@ def test_pipeline_form_follows_size_flags_and_marks(torch):
         env.close()
 
 
+def test_pool_is_allocated_when_set_params_turns_racket_ground_on(torch):
+    """above 16384 envs a handle gets no pool (14 KB per env) unless its parameter block asks for racket<->court contact -- and a
+    handle that starts without the flag gets the pool from the tb_set_params call that turns it on (round 4: lazy allocation,
+    ADVICE r03). 20000 envs: slots form, then set_params -> slots + pool, and two episodes in lockstep with the oracle through it."""
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    n = 20000
+    env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=4, pipeline=True, track_terminal_obs=False)
+    assert env.pipeline_form() == "slots"
+    p = default_params(flags=F_DEFAULT | F_RACKET_GROUND)
+    env.set_params(p)
+    assert env.pipeline_form() == "slots+pool"
+    pf = p.copy(); pf.flags |= F_AUTO_RESET
+    ref = OracleBatch(pf, ENV_SWING, n, seed=4, precision="f32")
+    ref.L.tbo_set_threads(ref.h, 16)
+    rng = np.random.default_rng(8)
+    same(env.reset().cpu().numpy(), ref.reset(), "reset obs")
+    outs = []
+    for t in range(52):
+        a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
+        obs, rew, done = env.step(torch.from_numpy(a).cuda())
+        o2, r2, d2, s2 = ref.step(a)
+        same(done.cpu().numpy(), d2, "done %d" % t); same(obs.cpu().numpy(), o2, "obs %d" % t)
+        outs.append((rew, r2))
+    env.flush()
+    for t, (rew, r2) in enumerate(outs):
+        same(rew.cpu().numpy(), r2, "reward %d" % t)
+    got, want = env.counters(), ref.counters()
+    assert list(got.values()) == [int(x) for x in want], (got, want)
+    env.close()
+
+
 @pytest.mark.parametrize("rg,n,episodes,margin", [(False, 4096, 3, 0), (True, 2048, 3, 0), (False, 64, 700, 1), (True, 1000, 2, 200),
                                                   (False, 4096, 3, "all"), (True, 1000, 3, "all"), (False, 256, 70, "all"), (False, 8192, 17, "all")])
 def test_deferred_stragglers_are_bit_identical(torch, rg, n, episodes, margin):
