@@ -308,7 +308,8 @@ int tb_policy_step(TbHandle *h, const float *weights_dev, const float *obs_in_de
  * step_strides_bytes (or NULL = contiguous) gives the distance in bytes between consecutive steps of
  * {actions, raw_actions, logp, value, obs, reward, done} -- e.g. the record size of a packed rollout
  * buffer; a 0 entry means contiguous for that array. Per env the arithmetic and the noise (keyed by
- * env, episode, step) are those of tb_policy_step: identical results. Requires TB_F_AUTO_RESET; on
+ * env, episode, step) are those of tb_policy_step: identical results. actions_dev / raw_actions_dev and their
+ * step strides must be 8-byte aligned (rows are written two floats at a time). Requires TB_F_AUTO_RESET; on
  * SwingRacket-v0 also tb_set_pipeline(h, 1) and lockstep episodes (the launches end where the episodes
  * end, each followed by its fast-forward on a side stream; terminal rewards complete after tb_flush).
  */

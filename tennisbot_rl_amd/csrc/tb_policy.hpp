@@ -220,4 +220,29 @@ TB_DEV void policy_sample(const KArgs& A, const float* s_mean, int i, const EnvR
   A.pol_logp[t * A.st_logp + i] = logp;
 }
 
+// The same sampling for the rollout kernels' env wave, split in two so that nothing but arithmetic sits between the towers' means
+// and the substep: `policy_sample_regs` works on registers only (exp(log_std) and log_std kept by the caller for the whole launch:
+// the one-step form re-reads log_std from memory per step, six dependent loads in front of the step), `policy_store` writes the
+// step's rows afterwards -- 8-byte stores, a row of NA floats being 8-byte aligned like the action rows tb_step reads.
+// Same operations on the same values as policy_sample: bit-identical outputs.
+template <int NA>
+TB_DEV float policy_sample_regs(const float* mean, const float* eps, const float* stdv, const float* lstd, float* raw, float* a) {
+  float logp = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NA; ++k) {
+    const float ek = eps[k];
+    raw[k] = FMA(stdv[k], ek, mean[k]);
+    logp += FMA(-0.5f * ek, ek, -lstd[k]) - 0.9189385332046727f;
+    a[k] = fminf(fmaxf(raw[k], -1.0f), 1.0f);
+  }
+  return logp;
+}
+template <int NA>
+TB_DEV void store_row2(float* dst, size_t row, const float* v) {
+  static_assert(NA % 2 == 0, "action rows are written two floats at a time");
+  float2* p = reinterpret_cast<float2*>(dst + row * NA);
+#pragma unroll
+  for (int k = 0; k < NA / 2; ++k) p[k] = make_float2(v[2 * k], v[2 * k + 1]);
+}
+
 }  // namespace

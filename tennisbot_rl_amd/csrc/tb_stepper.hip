@@ -757,9 +757,9 @@ __global__ void __launch_bounds__((2 * S + 1) * 64) tb_policy_rollout_kernel(KAr
   bool any_reset = false;
   TB_DIAG_STAMPS_BEGIN(st);
   __syncthreads();
-  float stdv[NA];
+  float stdv[NA], lstd[NA];
 #pragma unroll
-  for (int k = 0; k < NA; ++k) stdv[k] = expf(A.pol_weights[2 * tower_floats<KIND>() + k]);
+  for (int k = 0; k < NA; ++k) { lstd[k] = A.pol_weights[2 * tower_floats<KIND>() + k]; stdv[k] = expf(lstd[k]); }
   // The free-flight constants of the substep as VECTOR registers for the whole launch. As kernel arguments they are scalar loads
   // that the compiler, at its SGPR limit in this kernel, re-issues inside the per-step loop (two dozen of them, each behind a wait
   // the lone env wave cannot hide); the env wave has ~300 vector registers to spare, and a value that went through an empty asm
@@ -778,10 +778,10 @@ __global__ void __launch_bounds__((2 * S + 1) * 64) tb_policy_rollout_kernel(KAr
     if (live) policy_draw<KIND>(A, i, e, eps);  // while the towers run
     __syncthreads();  // the action means of step t are in LDS
     {
-      float a[NA], o[NO];
+      float a[NA], raw[NA], o[NO], logp = 0.0f;
 #pragma unroll
-      for (int k = 0; k < NA; ++k) a[k] = 0.0f;
-      if (live) policy_sample<KIND>(A, s_mean, i, e, a, (size_t)t, eps, stdv);
+      for (int k = 0; k < NA; ++k) { a[k] = 0.0f; raw[k] = 0.0f; }
+      if (live) logp = policy_sample_regs<NA>(s_mean + lane * 8, eps, stdv, lstd, raw, a);
       int ns = 1;
       bool d = false, parked = false;
       float rew;
@@ -817,15 +817,21 @@ __global__ void __launch_bounds__((2 * S + 1) * 64) tb_policy_rollout_kernel(KAr
           make_obs<KIND>(e, o);
           any_reset = true;
         }
-        // the towers wait for the observations only: they go to LDS before the step's outputs go to memory
 #pragma unroll
         for (int k = 0; k < NO; ++k) s_obs[lane * NO + k] = o[k];
+      }
+      // The towers wait for the observations only: THEY are in LDS now. The step's rows go to memory behind the barrier, while
+      // the towers already run step t + 1 (the env wave's next stop is the barrier behind their means: ~1.2 us away).
+      __syncthreads();  // the observations after step t are in LDS
+      if (live) {
+        store_row2<NA>(A.pol_raw + (size_t)t * A.st_raw, (size_t)i, raw);
+        store_row2<NA>(A.pol_actions + (size_t)t * A.st_act, (size_t)i, a);
+        A.pol_logp[(size_t)t * A.st_logp + i] = logp;
         write_obs<KIND>(A.obs + (size_t)t * A.st_obs, (size_t)i, o);
         A.reward[(size_t)t * A.st_rew + i] = rew;
         A.done_out[(size_t)t * A.st_done + i] = d ? 1 : 0;
       }
     }
-    __syncthreads();  // the observations after step t are in LDS
   }
   if (live) {
     store_env<KIND>(A.words, A.done_state, A.n, i, e, any_reset);
@@ -2062,6 +2068,9 @@ int tb_policy_rollout(TbHandle* h, int n_steps, const float* weights_dev, const 
       if (step_strides_bytes[k]) st[k] = step_strides_bytes[k] / el;
     }
   }
+  // action rows are written 8 bytes at a time (like the action rows tb_step reads): bases and step strides must keep them aligned
+  if ((reinterpret_cast<uintptr_t>(actions_dev) | reinterpret_cast<uintptr_t>(raw_actions_dev)) % 8 || (st[0] * sizeof(float)) % 8 || (st[1] * sizeof(float)) % 8)
+    return fail(TB_E_INVAL, "tb_policy_rollout: actions / raw_actions and their step strides must be 8-byte aligned");
   DeviceGuard g(h->device);
   hipStream_t s = (hipStream_t)stream;
   const float* obs_in = obs_in_dev;
