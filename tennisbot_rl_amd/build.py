@@ -6,7 +6,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = [os.path.join(_HERE, "csrc", "tb_stepper.hip")]
-HEADERS = [os.path.join(_HERE, "csrc", "tb_device.hpp"), os.path.join(_HERE, "csrc", "tb_policy.hpp"), os.path.join(_HERE, "csrc", "tb_diag.hpp"), os.path.join(_HERE, "..", "include", "tb_stepper.h")]
+HEADERS = [os.path.join(_HERE, "csrc", "tb_kernels.hpp"), os.path.join(_HERE, "csrc", "tb_device.hpp"), os.path.join(_HERE, "csrc", "tb_policy.hpp"), os.path.join(_HERE, "csrc", "tb_diag.hpp"),
+           os.path.join(_HERE, "..", "include", "tb_stepper.h")]
 OUTPUT = os.path.join(_HERE, "libtb_stepper.so")
 
 # -ffp-contract=off: the only fused multiply-adds are the explicit __builtin_fmaf calls

@@ -202,7 +202,7 @@ TB_DEV bool racket_planes(const KParams& P, const float4* hull, vec3 l, float s)
   float sep = -3.0e38f;
   int first = TB_HULL_PLANES;
 #ifndef TB_HINT_RELOAD_PLANES
-#define TB_HINT_RELOAD_PLANES 1  // (a scheduling hint like those listed in tb_stepper.hip; tools/diag/r04_hint_recheck.py)
+#define TB_HINT_RELOAD_PLANES 1  // (a scheduling hint like those listed in tb_kernels.hpp; tools/diag/r04_hint_recheck.py)
 #endif
   if (RELOAD && TB_HINT_RELOAD_PLANES) asm volatile("" : "+v"(first));  // a row index the compiler cannot see through: the reads stay here (the index, not the
                                               // pointer: laundering the pointer loses its address space and the reads become flat loads)

@@ -1,7 +1,7 @@
 // tb_diag.hpp -- everything the DIAGNOSTIC builds add to the kernels, behind one include.
 //
 // The product build (tennisbot_rl_amd/build.py) defines none of the TB_DIAG_* macros: every macro
-// below then expands to nothing and the kernels in tb_device.hpp / tb_stepper.hip read -- and
+// below then expands to nothing and the kernels in tb_device.hpp / tb_kernels.hpp read -- and
 // compile -- as if this file did not exist. The diagnostic builds are made by tools/diag/*.py into
 // /tmp and loaded through stepper.use_library(); they are never the in-tree libtb_stepper.so.
 //

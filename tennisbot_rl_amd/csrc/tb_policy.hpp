@@ -1,5 +1,5 @@
 // Policy inference for the fused policy + step kernels (tb_policy_step, tb_policy_rollout). Device code only; included by
-// tb_stepper.hip after KArgs / EnvRegs / Dims / philox4x32 are defined. This file is part of the HIP
+// tb_kernels.hpp after KArgs / EnvRegs / Dims / philox4x32 are defined. This file is part of the HIP
 // library's single translation unit (everything lives in one anonymous namespace there).
 #pragma once
 

@@ -3,7 +3,7 @@ stepped in lockstep on one MI355X.
 
 This is the measured path: `step(actions)` takes and returns device tensors and never
 synchronises with the host. torch is used for device memory and streams only; all
-arithmetic happens in libtb_stepper.so (hand-written HIP, csrc/tb_stepper.hip). There is
+arithmetic happens in libtb_stepper.so (hand-written HIP: csrc/tb_kernels.hpp, tb_device.hpp, tb_policy.hpp; host side csrc/tb_stepper.hip). There is
 no CPU or eager-PyTorch fallback: if the library or a GPU is missing, construction raises.
 
 Reference counterparts: `SwingRacketEnv` (tennisbot/envs/swingracket_env.py:24-192) and

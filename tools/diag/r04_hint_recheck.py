@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Re-check the product's four scheduling hints after a toolchain change. Each hint is an empty `asm volatile`
-that only NAMES values, so that the compiler fetches scalar arguments where a lone wave can hide the wait (tb_stepper.hip, "SCHEDULING
+that only NAMES values, so that the compiler fetches scalar arguments where a lone wave can hide the wait (tb_kernels.hpp, "SCHEDULING
 HINTS"; tb_device.hpp racket_planes). They were chosen on AMD clang 22 / ROCm 7.2; a compiler bump can undo or invert any of them.
 For every hint: the library built with -DTB_HINT_<x>=0 (A) against the default build (B), same box, each workload a replayed rollout
 graph in a process of its own (tools/diag/r03_flag_ab.py does the builds and the timing). A hint whose B is not ahead of its A by
