@@ -254,22 +254,28 @@ def pick_exchange_form(chunked_wall, chunked_ok, single_wall, single_ok):
 XGMI_LINK_GBS = 153.0
 
 
-def predict_exchange(world, bytes_per_rank, rollout_ms, chunks, exposed_chunk_fraction=None):
-    """predicted rollout + exchange time per rank and the scaling efficiency it implies (value(N) / (N x value(1))), for the single
-    all-gather after the rollout (nothing overlapped) and for the chunked form (all but the last chunk's exchange hidden behind
-    later chunks' steps, when a chunk's exchange is shorter than a chunk's steps)"""
+def predict_exchange(world, bytes_per_rank, rollout_ms, chunks, rollout_ms_pool_form=None):
+    """predicted rollout + exchange time per rank and the scaling efficiency it implies, for the single all-gather after the
+    rollout (nothing overlapped) and for the chunked form (all but the last chunk's exchange hidden behind later chunks' steps, when
+    a chunk's exchange is shorter than a chunk's steps). rollout_ms: the rank's rollout in the chunked form (marked graph, one
+    fast-forward kernel per episode end); rollout_ms_pool_form: its rollout without marks (what the single all-gather follows, and
+    what N = 1 runs): `efficiency` is against the form's own rollout, `efficiency_vs_n1` against the N = 1 rollout -- the figure the
+    driver's value(N) / (N x value(1)) will show."""
     if world < 2:
         return None
-    out = {"assumed": {"xgmi_link_GBs": XGMI_LINK_GBS, "links_per_gpu": 7, "world": world, "bytes_per_rank": int(bytes_per_rank), "rollout_ms": rollout_ms,
+    pool_ms = rollout_ms_pool_form if rollout_ms_pool_form else rollout_ms
+    out = {"assumed": {"xgmi_link_GBs": XGMI_LINK_GBS, "links_per_gpu": 7, "world": world, "bytes_per_rank": int(bytes_per_rank), "rollout_ms_chunked_form": rollout_ms,
+                       "rollout_ms_pool_form": pool_ms,
                        "note": "peak link rate, no protocol overhead: an upper bound on the efficiency; the first SCALE record is to be read against it"}}
     for name, hops in (("direct", 1), ("ring", world - 1)):
         ag_ms = hops * bytes_per_rank / (XGMI_LINK_GBS * 1e9) * 1e3
-        single = rollout_ms + ag_ms
+        single = pool_ms + ag_ms
         per_chunk = ag_ms / chunks
         steps_chunk = rollout_ms / chunks
         chunked = rollout_ms + per_chunk + max(0.0, per_chunk - steps_chunk) * (chunks - 1)
-        out[name] = {"all_gather_ms": ag_ms, "single_all_gather": {"ms_per_rollout": single, "efficiency": rollout_ms / single},
-                     "chunked": {"chunks": chunks, "ms_per_rollout": chunked, "efficiency": rollout_ms / chunked}}
+        out[name] = {"all_gather_ms": ag_ms,
+                     "single_all_gather": {"ms_per_rollout": single, "efficiency": pool_ms / single, "efficiency_vs_n1": pool_ms / single},
+                     "chunked": {"chunks": chunks, "ms_per_rollout": chunked, "efficiency": rollout_ms / chunked, "efficiency_vs_n1": pool_ms / chunked}}
     return out
 
 
@@ -775,8 +781,9 @@ def main():
                                 "longer than the un-profiled cadence and is not what frac rests on (profiles/README.md)"})
         if exch is not None:
             if R.collective and exch.get("rollout_ms"):
-                exch["predicted"] = predict_exchange(max(world, exch.get("ranks_seen", world)), exch["bytes_per_rank"], exch["rollout_ms"], max(R.chunks, 1))
-                exch["predicted_for_8_gpus"] = predict_exchange(8, exch["bytes_per_rank"], exch["rollout_ms"], max(R.chunks, 1))
+                pool_ms = single["rollout_ms"] if single is not None else None
+                exch["predicted"] = predict_exchange(max(world, exch.get("ranks_seen", world)), exch["bytes_per_rank"], exch["rollout_ms"], max(R.chunks, 1), pool_ms)
+                exch["predicted_for_8_gpus"] = predict_exchange(8, exch["bytes_per_rank"], exch["rollout_ms"], max(R.chunks, 1), pool_ms)
             result["exchange"] = exch
         if replicas_only is not None:  # never to be mistaken for the metric: the rollouts were NOT exchanged
             result["replicas_only"] = True

@@ -143,6 +143,10 @@ def test_bench_reports_one_fixed_exchange_form():
     assert abs(p["direct"]["all_gather_ms"] - 226e6 / 153e9 * 1e3) < 1e-9 and abs(p["ring"]["all_gather_ms"] / p["direct"]["all_gather_ms"] - 7) < 1e-9
     assert 0.70 < p["direct"]["single_all_gather"]["efficiency"] < 0.74 and 0.94 < p["direct"]["chunked"]["efficiency"] < 0.96
     assert p["ring"]["single_all_gather"]["efficiency"] < 0.3 and p["ring"]["chunked"]["efficiency"] < p["direct"]["chunked"]["efficiency"]
+    # against the N = 1 rollout (pool form, 3.8 ms) a chunked form whose own marked rollout takes 5.8 ms starts at 65 %
+    p2 = bench.predict_exchange(8, 226e6, 5.8, 8, 3.8)
+    assert 0.62 < p2["direct"]["chunked"]["efficiency_vs_n1"] < 0.66 and p2["direct"]["chunked"]["efficiency"] > 0.95
+    assert abs(p2["direct"]["single_all_gather"]["efficiency_vs_n1"] - p["direct"]["single_all_gather"]["efficiency"]) < 1e-12
     assert bench.predict_exchange(1, 226e6, 3.8, 8) is None
     c = bench.cadence_profile("swing", 4096)
     assert c is not None and 1.0 < c[0]["kernel_us"] < 3.0 and 0.8 < c[0]["gap_us"] < 2.5 and c[1].endswith("cadence.json")
