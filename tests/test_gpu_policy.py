@@ -385,3 +385,38 @@ def test_fused_rollout_under_the_trained_policy_matches_the_oracle(torch, n, sli
         assert torch.equal(outs[t], rew[t]), "tb_step reward differs at step %d" % t
     assert twin.counters() == got
     twin.close()
+
+
+@pytest.mark.parametrize("n,slices,scale", [(2000, 1, 3.0), (1500, 3, 2.3), (900, 1, 1.0)])
+def test_tennis_fused_rollout_with_scaled_rackets_matches_the_oracle(torch, n, slices, scale):
+    """Tennisbot's fused rollout against the oracle, directly: curriculum-sized rackets (train.py:164-176: scale 3 at the start) are hit
+    by most balls, so the env wave's racket narrowphase -- the scaled query, the one-edge-per-lane sweep of the 16-env form, the lane-by-
+    lane sweep of the 48-env form -- the racket row of the solver and the contact reward all run, with a random policy. 900 steps
+    from a common reset (the balls need 2-3 s to reach the rackets), every observation / reward / done and the counters bit for bit."""
+    from tennisbot_rl_amd.params import F_AUTO_RESET, default_params
+    from tennisbot_rl_amd.ppo import TENNIS_DEFAULTS, build_actor_critic, pack_policy
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    from oracle import OracleBatch
+    torch.manual_seed(3)
+    policy = build_actor_critic(OBS_DIM[ENV_TENNIS], ACT_DIM[ENV_TENNIS], tuple(TENNIS_DEFAULTS["net_arch"])).to("cuda:0")
+    blob = pack_policy(policy)
+    p = default_params(racket_scale=scale)
+    env = BatchedEnv(ENV_TENNIS, n, device="cuda:0", seed=9, track_terminal_obs=False, params=p, options=dict(policy_slices=slices))
+    pf = p.copy(); pf.flags |= F_AUTO_RESET
+    ref = OracleBatch(pf, ENV_TENNIS, n, seed=9, precision="f32")
+    ref.L.tbo_set_threads(ref.h, 16)
+    o = env.reset()
+    assert np.array_equal(o.cpu().numpy(), ref.reset())
+    T = 900
+    (obs, rew, done), (act, raw, logp, value) = env.policy_rollout(blob, o, T, seed=11)
+    torch.cuda.synchronize()
+    act_h, obs_h, rew_h, done_h = act.cpu().numpy(), obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+    for t in range(T):
+        o2, r2, d2, s2 = ref.step(np.ascontiguousarray(act_h[t]))
+        assert np.array_equal(obs_h[t].view(np.uint32), o2.view(np.uint32)), "obs differs at step %d" % t
+        assert np.array_equal(rew_h[t].view(np.uint32), r2.view(np.uint32)), "reward differs at step %d" % t
+        assert np.array_equal(done_h[t] != 0, d2 != 0), "done differs at step %d" % t
+    got, want = env.counters(), ref.counters()
+    assert list(got.values()) == [int(x) for x in want], (got, want)
+    assert got["racket_ball_contact_substeps"] > (50 if scale > 1.5 else 0) and got["episodes_finished"] > n // 2 and got["nonfinite_states"] == 0, got
+    env.close()
