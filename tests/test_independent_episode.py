@@ -45,11 +45,12 @@ class Geometry:
         self.ground = np.array([f64(x) for x in P.ground_half]); self.net = np.array([f64(x) for x in P.net_half])
         self.goal_r, self.goal_hl = f64(P.goal_radius), f64(P.goal_half_len)
 
-    def racket(self, rp, R, c):
+    def racket(self, rp, R, c, scale=1.0):
+        """globalScaling s (tennisbot_env.py:234): the hull grows, margin and ball do not; dist(p, s Hull) = s dist(p / s, Hull)"""
         d = c - rp
-        if d @ d > (self.bound + self.margin + self.r + self.thr) ** 2:
+        if d @ d > (self.bound * scale + self.margin + self.r + self.thr) ** 2:
             return None
-        l = R.T @ d
+        l = (R.T @ d) / scale
         a, b = self.verts, np.roll(self.verts, -1, axis=0)
         e, w = b - a, l[1:3] - a
         cr = e[:, 0] * w[:, 1] - e[:, 1] * w[:, 0]  # > 0: the point is on the inner side of a CCW edge
@@ -70,7 +71,7 @@ class Geometry:
             dx = sx * ax if ax > 0 else 0.0
             dist = np.sqrt(dx * dx + rvec[k] @ rvec[k])
             nl = np.array([dx, rvec[k, 0], rvec[k, 1]]) / dist
-        dist = dist - self.margin - self.r
+        dist = dist * scale - self.margin - self.r
         if not dist < self.thr:
             return None
         n = R @ nl
@@ -227,3 +228,97 @@ def test_whole_episodes_match_a_third_implementation(seed, n):
                     e.reset()
                 events["bonus"] += (not d) and r == 2.0
     assert events["bonus"] > 0 and events["long"] > 0, events  # racket strikes during the short steps, and flights they lengthened
+
+
+class PyTennisEnv:
+    """Tennisbot-v0 for ONE env, written from tennisbot/envs/tennisbot_env.py:104-261 and objects.py:82-96"""
+
+    def __init__(self, P, geo, seed, env_id, sweeps):
+        self.P, self.geo, self.seed, self.env_id, self.sweeps = P, geo, seed, env_id, sweeps
+        self.episode = -1
+        self.e_rb, self.mu_rb, self.e_ct, self.mu_ct = f64(P.rest_racket), f64(P.fric_racket), f64(P.rest_court), f64(P.fric_court)
+
+    def reset(self):
+        self.episode += 1
+        key = (self.seed & M32, self.seed >> 32)
+        u = philox4x32((self.env_id & M32, self.env_id >> 32, self.episode, 0), key)
+        w = philox4x32((self.env_id & M32, self.env_id >> 32, self.episode, 1), key)
+        x, y, z = uniform(7.5, 5.0, u[0]), uniform(-5.0, 10.0, u[1]), uniform(0.2, 0.21 - 0.2, u[2])  # tennisbot_env.py:227-229
+        self.scale = f64(self.P.racket_scale)                                                        # :230-234 globalScaling
+        com = np.array([f64(c) for c in self.P.racket_com])
+        self.rk = [np.array([x, y, z]) + self.scale * com, np.array([0.0, 0.0, 0.0, 1.0]), np.zeros(3), np.zeros(3)]
+        self.shoot = (uniform(25.0, 12.5, u[3]), uniform(-10.0, 20.0, w[0]), 20.0)                   # :237-241
+        self.bl = [np.array([uniform(-12.0, 6.0, w[1]), uniform(-1.0, 2.0, w[2]), uniform(1.0, 0.5, w[3])]), np.zeros(3), np.zeros(3)]  # objects.py:91-93
+        self.step_count, self.done = 0, False
+        return self.obs()
+
+    def obs(self):
+        return np.concatenate([self.rk[0], self.rk[2], self.bl[0], self.bl[1]])  # :134-136
+
+    @staticmethod
+    def tier(d):  # :90-102
+        return 20.0 if d < 0.5 else 15.0 if d < 1 else 10.0 if d < 2 else 5.0 if d < 3 else 1.0 if d < 4 else 0.0
+
+    def step(self, a):
+        a = [float(np.float32(x)) for x in a]
+        F = (10.0 * a[0], 10.0 * a[1], 4 * 9.81)                              # :112-115
+        Fb = self.shoot if self.step_count < 5 else (0.0, 0.0, 0.0)          # :118-119
+        R = rotmat(self.rk[1])
+        cs, hit_racket = [], False
+        h = self.geo.racket(self.rk[0], R, self.bl[0], self.scale)
+        if h:
+            cs.append(dict(h, e=self.e_rb, mu=self.mu_rb)); hit_racket = True
+        for half in (self.geo.ground, self.geo.net):
+            h = self.geo.box(half, self.bl[0])
+            if h:
+                cs.append(dict(h, e=self.e_ct, mu=self.mu_ct))
+        rk, bl = substep_dense(self.P, tuple(self.rk), tuple(self.bl), F, (0.0, 0.0, 0.0), cs, self.sweeps, F_ball=Fb, scale=self.scale)  # :121
+        self.rk, self.bl = list(rk), list(bl)
+        self.step_count += 1
+        if self.step_count < 5:                                              # :138-139
+            return self.obs(), 0.0, False
+        delta = np.hypot(self.bl[0][2] - self.rk[0][2], self.bl[0][1] - self.rk[0][1])  # :142-143
+        reward = 0.0
+        if hit_racket:                                                       # :170-174
+            reward += 25.0 + self.tier(delta)
+        if not (self.bl[0][0] - self.rk[0][0] < 0.5):                        # :182-194
+            self.done = True
+            reward += self.tier(delta)
+        if self.step_count > 1000:                                           # :201-203
+            self.done = True
+        return self.obs(), reward, self.done
+
+
+@pytest.mark.parametrize("seed,scale", [(5, 3.0), (6, 1.0)])
+def test_whole_tennisbot_episodes_match_a_third_implementation(seed, scale):
+    """the same for Tennisbot-v0: shoot pulse, drag-limited flight, bounces on the court, a racket at the curriculum's scale 3
+    (train.py:164-176) steered into the ball's path so that it is struck (contact reward 25 + tier), pass-the-racket terminations"""
+    from tennisbot_rl_amd.params import ENV_TENNIS
+    sweeps, n = 8, 6
+    P = default_params(racket_scale=scale, flags=F_DEFAULT | F_AUTO_RESET, solver_iters=sweeps, solver_tol=0.0)
+    geo = Geometry(P)
+    ora = OracleBatch(P, ENV_TENNIS, n, seed=seed, precision="f64")
+    envs = [PyTennisEnv(P, geo, seed, i, sweeps) for i in range(n)]
+    o_ref = ora.reset()
+    o_py = np.array([e.reset() for e in envs])
+    assert np.abs(o_py - o_ref).max() < 2e-6
+    rng = np.random.default_rng(seed)
+    strikes = ends = bounces = 0
+    for t in range(800):
+        a = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+        for i, e in enumerate(envs):  # steer the racket toward the ball's y (and a little toward it in x)
+            a[i, 1] = np.clip(1.5 * (e.bl[0][1] - e.rk[0][1]) - 1.0 * e.rk[2][1] + 0.1 * a[i, 1], -1, 1)
+            a[i, 0] = np.clip(0.3 * a[i, 0], -1, 1)
+        o_ref, r_ref, d_ref, s_ref, term = ora.step(a, want_terminal=True)
+        for i, e in enumerate(envs):
+            o, r, d = e.step(a[i])
+            tag = "step %d env %d" % (t, i)
+            assert bool(d) == bool(d_ref[i]), tag + ": done flags differ"
+            assert abs(r - float(r_ref[i])) < 1e-9, (tag, r, float(r_ref[i]))
+            shown = term[i] if d else o_ref[i]
+            assert np.abs(o - shown).max() < 3e-6, (tag, o, shown)
+            strikes += r >= 25.0
+            if d:
+                ends += 1
+                e.reset()
+    assert ends >= 1 and (strikes > 0 or scale < 2), (ends, strikes)

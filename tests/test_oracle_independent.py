@@ -48,12 +48,13 @@ def plane_space(n):
     return p, q
 
 
-def substep_dense(P, rk, bl, F_racket, T_racket, contacts, sweeps):
+def substep_dense(P, rk, bl, F_racket, T_racket, contacts, sweeps, F_ball=(0.0, 0.0, 0.0), scale=1.0):
     """rk = (p, q, v, w), bl = (p, v, w); contacts: list of dicts(n, dist, rr or None, e, mu) in the solver's row order.
-    Returns the state after one substep."""
+    F_ball: external force on the ball (Tennisbot's shoot pulse); scale: the racket's globalScaling (its shape-derived inertia
+    grows with scale^2, its mass does not: DESIGN.md section 3). Returns the state after one substep."""
     mr, mb, r = 1.0 / f64(P.racket_inv_mass), 1.0 / f64(P.ball_inv_mass), f64(P.ball_radius)
     Ib = 1.0 / f64(P.ball_inv_inertia)
-    I = np.diag([f64(x) for x in P.racket_inertia])
+    I = np.diag([f64(x) for x in P.racket_inertia]) * (scale * scale)
     k1, k2, a1, a2, g = f64(P.lin_damp), f64(P.lin_damp_quad), f64(P.ang_damp), f64(P.ang_damp_quad), f64(P.gravity)
     erp, vthr = f64(P.erp), f64(P.rest_vel_threshold)
     rp, rq, rv, rw = (np.array(x, float) for x in rk)
@@ -66,7 +67,7 @@ def substep_dense(P, rk, bl, F_racket, T_racket, contacts, sweeps):
         L = I @ wb
         wb_dot = np.linalg.solve(I, R.T @ np.array(T_racket) - np.cross(wb, L) - L * (a1 + a2 * np.linalg.norm(wb)))
         rw = rw + DT * (R @ wb_dot)
-    bv = bv + DT * (-np.array([0, 0, g]) - bv * (k1 + k2 * np.linalg.norm(bv)))
+    bv = bv + DT * (np.array(F_ball) / mb - np.array([0, 0, g]) - bv * (k1 + k2 * np.linalg.norm(bv)))
     if np.any(bw != 0):
         bw = bw + DT * (-bw * (a1 + a2 * np.linalg.norm(bw)))
     # (3) projected Gauss-Seidel on generalised velocities u = [racket v, racket w, ball v, ball w]
