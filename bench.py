@@ -420,7 +420,8 @@ def open_loop_rate(kind, N, flags, pipeline, dev, seed, torch):
 def parity_text():
     """what the line may claim about parity, and -- from the committed sensitivity table (tools/pin_sensitivity.py ->
     profiles/r03_pin_sensitivity.json) -- which recalled engine constants the reference's one PyBullet record constrains at all"""
-    txt = ("bit-exact vs the CPU restatement; PyBullet parity UNPINNED at trajectory level (the reference ships no tests or golden vectors, PyBullet is "
+    txt = ("bit-exact vs the CPU restatement, which agrees with a third, independently written implementation (dense-matrix substep, numpy narrowphase, plain-Python "
+           "env logic and Philox: tests/test_oracle_independent.py, test_independent_episode.py) through whole episodes of both envs; PyBullet parity UNPINNED at trajectory level (the reference ships no tests or golden vectors, PyBullet is "
            "not available offline); pinned statistically by what the reference's ppo_swing.zip holds: the returns of its last 100 PyBullet episodes "
            "(two-sample KS + double-bonus count, with a leave-half-out selection test) and its critic's predictions (state-conditional calibration on 16 384 episodes)")
     try:

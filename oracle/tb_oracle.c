@@ -20,6 +20,10 @@
  *       last 100 PyBullet training episodes stored inside backup_models/ppo_swing.zip
  *       (tests/golden/ppo_swing_reference_episodes.json). No
  *       trajectory-level PyBullet vector exists, hence "unpinned" stays in this header.
+ *   (3) Since round 4 a third implementation that shares no code and no hand-derived formula with this file or with the HIP
+ *       kernels (tests/test_oracle_independent.py: 12 x 12 inverse mass matrix, Jacobian rows, plain projected Gauss-Seidel;
+ *       tests/test_independent_episode.py: numpy narrowphase, Python Philox, the env logic re-read from the reference) agrees
+ *       with the float64 build through whole episodes of both envs. That pins the derivations, not Bullet's constants.
  *
  * One source, two builds:  -DTBO_F64 -> libtb_oracle_f64.so  (the numerical "truth")
  *                          (default) -> libtb_oracle_f32.so  (same operation order as the
