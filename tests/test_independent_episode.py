@@ -322,3 +322,74 @@ def test_whole_tennisbot_episodes_match_a_third_implementation(seed, scale):
                 ends += 1
                 e.reset()
     assert ends >= 1 and (strikes > 0 or scale < 2), (ends, strikes)
+
+
+def test_racket_court_manifold_matches_a_brute_force_manager():
+    """row f3's contact MANAGEMENT (oracle racket_vs_ground: one support point per substep found by walking the outline downhill from
+    the last one, a persistent cache of <= 4 hull vertices refreshed, dropped and replaced by the area rule) against a manager
+    written the slow way: the support vertex by brute force over all 76 hull vertices, the cache as a Python list. Rackets are
+    dropped onto the court tumbling, pushed and spun (SwingRacket envs past their episode end: one substep per step() call, no
+    fast-forward), and after every substep the oracle's cached vertex ids -- in cache order -- must be the brute-force manager's."""
+    from tennisbot_rl_amd.params import F_RACKET_GROUND
+    n, steps = 16, 260
+    P = default_params(flags=F_DEFAULT | F_RACKET_GROUND)
+    geo = Geometry(P)
+    rng = np.random.default_rng(12)
+    q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    from helpers import make_words
+    w, d = make_words(ENV_SWING, n, racket_pos=np.stack([rng.uniform(4, 11, n), rng.uniform(-4, 4, n), rng.uniform(0.5, 0.9, n)], 1), racket_quat=q,
+                      racket_vel=np.stack([rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), rng.uniform(-2, 0, n)], 1), racket_angvel=rng.uniform(-4, 4, (n, 3)),
+                      ball_pos=(0.0, 3.0, 50.0), goal=(-7.0, 1.0), spawn_pos=(9, 0, 0.6), init_dist=10.0, step_count=900, done=1)
+    b = OracleBatch(P, ENV_SWING, n, precision="f64")  # (no auto-reset: `done` is sticky, every step() is one substep)
+    b.set_state_words(w, d)
+    top, margin, hx = geo.ground[2], geo.margin, geo.hx
+    thr = float(P.racket_ground_threshold)
+    verts = np.array([[(-hx if s == 0 else hx), y, z] for (y, z) in geo.verts for s in (0, 1)])  # hull vertex k = 2 i + side
+    caches = [[] for _ in range(n)]
+    full = changed = 0
+    act = np.zeros((n, 6), np.float32)
+    for t in range(steps):
+        s0 = b.get_state()
+        act[:, 2] = -0.05 + 0.02 * rng.uniform(-1, 1, n)   # ~20 N of weight left on the court
+        act[:, 0] = 0.01 * rng.uniform(-1, 1, n); act[:, 5] = 0.3 * rng.uniform(-1, 1, n)
+        b.step(act)
+        for i in range(n):
+            p, R = s0["racket_pos"][i], rotmat(s0["racket_quat"][i])
+            M = caches[i]
+            if (p[2] - (geo.bound + margin)) - top >= thr or not p[2] > top:
+                M.clear()
+            else:
+                hts = p[2] + (R @ verts.T)[2] - margin - top          # height of every hull vertex above the court's top face
+                world = p[:, None] + R @ verts.T
+                over = (np.abs(world[0]) <= geo.ground[0]) & (np.abs(world[1]) <= geo.ground[1])
+                zr = R.T @ np.array([0.0, 0.0, 1.0])
+                side = 0 if zr[0] > 0 else 1                          # the face that looks down
+                cand = np.arange(side, len(verts), 2)
+                kd = int(cand[np.argmin(hts[cand])])                  # the support vertex: the lowest of the down-looking face
+                if M or hts[kd] < thr:
+                    M[:] = [k for k in M if hts[k] < thr and over[k]]
+                    if kd not in M and hts[kd] < thr and over[kd]:
+                        if len(M) == 4:
+                            deepest = int(np.argmin([hts[k] for k in M]))
+                            if hts[kd] < hts[M[deepest]]:
+                                deepest = -1
+
+                            def area(ids):
+                                p0, p1, p2, p3 = (verts[k] for k in ids)
+                                cs = (np.cross(p0 - p1, p2 - p3), np.cross(p0 - p2, p1 - p3), np.cross(p0 - p3, p1 - p2))
+                                return max(c @ c for c in cs)
+                            best, slot = -1.0, -1
+                            for j in range(4):
+                                if j == deepest:
+                                    continue
+                                a = area([kd if m == j else M[m] for m in range(4)])
+                                if a > best:
+                                    best, slot = a, j
+                            M[slot] = kd
+                            changed += 1
+                        else:
+                            M.append(kd)
+            ids, _ = b.manifold(i)
+            assert list(ids) == M, (t, i, list(ids), M)
+            full += len(M) == 4
+    assert full > 200 and changed > 0, (full, changed)  # rackets did come to lie on four points, and the replacement rule did run
