@@ -2,7 +2,7 @@
 """Soak of the fused policy rollout (tb_policy_rollout: policy, sampling and env steps in one kernel) against the f32 CPU oracle, under
 the reference's trained policy -- where a fifth of an env wave's substeps run the outline sweep (one edge per lane of the env wave in
 the 16-env form) and the contact solver. The oracle is stepped with the actions the kernel reports; every observation, reward, done flag
-and counter bit for bit. Run on the GPU box:  tests/soak_policy.py <n_envs> <steps> [slices] [rg]"""
+and counter bit for bit. Run on the GPU box:  tests/soak_policy.py <n_envs> <steps> [slices] [rg] [seed=K]"""
 import os
 import sys
 
@@ -20,20 +20,21 @@ def main():
     n, T = int(sys.argv[1]), int(sys.argv[2])
     slices = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3].isdigit() else 0
     rg = "rg" in sys.argv[3:]
+    seed = ([int(x[5:]) for x in sys.argv[3:] if x.startswith("seed=")] or [21])[0]
     policy = build_actor_critic(OBS_DIM[ENV_SWING], ACT_DIM[ENV_SWING], tuple(SWING_DEFAULTS["net_arch"])).to("cuda:0")
     policy.load_sb3_arrays(dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ppo_swing_policy.npz"))))
     blob = pack_policy(policy)
     p = default_params(flags=F_DEFAULT | (F_RACKET_GROUND if rg else 0), **(reference_rolling_friction() if rg else {}))
-    env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=21, pipeline=True, track_terminal_obs=False, params=p, options=dict(policy_slices=slices))
+    env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=seed, pipeline=True, track_terminal_obs=False, params=p, options=dict(policy_slices=slices))
     pf = p.copy(); pf.flags |= F_AUTO_RESET
-    ref = OracleBatch(pf, ENV_SWING, n, seed=21, precision="f32")
+    ref = OracleBatch(pf, ENV_SWING, n, seed=seed, precision="f32")
     ref.L.tbo_set_threads(ref.h, 16)
     o = env.reset()
     assert np.array_equal(o.cpu().numpy(), ref.reset())
     done_steps = 0
     while done_steps < T:
         chunk = min(260, T - done_steps)  # whole episodes per call (<= 64 of them between two joins)
-        (obs, rew, done), (act, raw, logp, value) = env.policy_rollout(blob, o, chunk, seed=5 + done_steps)
+        (obs, rew, done), (act, raw, logp, value) = env.policy_rollout(blob, o, chunk, seed=5 * seed + done_steps)
         env.flush()
         torch.cuda.synchronize()
         act_h, obs_h, rew_h, done_h = act.cpu().numpy(), obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
