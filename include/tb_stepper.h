@@ -191,6 +191,15 @@ typedef struct TbOptions {
                              * ask for terminal-observation / substep outputs. */
   int32_t ff_defer_margin;  /* substeps beyond the estimate before an env is deferred (auto: 16) */
   int32_t policy_slices;    /* tb_policy_rollout: 16-env slices per workgroup, 1 (three waves per 16 envs) or 3 (seven waves per 48 envs) (auto: 1 up to 4096 envs) */
+  int32_t ff_seal;          /* the pool's sealed-fate exit: 1 / 0 on (auto), -1 off. A SwingRacket-v0 flight whose ball has fallen below the court,
+                             * out of the racket's reach for good, can only end in the 800-substep timeout with reward 0
+                             * (swingracket_env.py:127-128); with auto-reset nothing else of it is ever read, so the pool books the remaining
+                             * substeps (counters[6], substeps and timeouts are those of the full flight) instead of running them. Every
+                             * result is the one the full flight gives (the oracle has no such exit and the parity tests compare against
+                             * it); the pool's waves stop paying ~400 substeps for one such ball (a trained policy's collect: +5-8 %).
+                             * Only without the Magnus extension and the extended contact set, with parameters inside the limits the
+                             * argument needs (tb_kernels.hpp, fate_sealed), and never for launches that write terminal observations.
+                             * tb_sealed_substeps reports how many substeps were booked this way. */
 } TbOptions;
 
 /* library identity / shape queries (host only, no device touched) */
@@ -425,6 +434,9 @@ int tb_set_state(TbHandle *h, const uint32_t *words, const uint8_t *done, int on
 #define TB_N_COUNTERS 9
 int tb_counters(TbHandle *h, uint64_t *out, void *stream);
 int tb_counters_reset(TbHandle *h, void *stream);
+/* how many of counters[6]'s substeps the pool's sealed-fate exit (TbOptions.ff_seal) booked without running them, since create or
+ * the last tb_counters_reset. Joins the pipeline and synchronises the stream like tb_counters. */
+int tb_sealed_substeps(TbHandle *h, uint64_t *out, void *stream);
 
 /* Diagnostics (not part of the env surface): copies `rows` SoA rows of n 32-bit words,
  * src[r*n + i] -> dst[r*n + i], one dword per lane exactly like the step kernel's state

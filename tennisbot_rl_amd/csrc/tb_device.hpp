@@ -342,53 +342,81 @@ TB_DEV SweepOut outline_sweep_serial(const float4* hull, int n_hull, float py, f
   return o;
 }
 
-// The sweep with ONE EDGE PER LANE (the env wave of the policy rollout kernels, which brings all 64 lanes into substep: 16 or 48 of
-// them hold envs, the others a far-away dummy and nothing to do). Lane j evaluates edge j -- the arithmetic of sweep_edge -- for the
-// query point of each asking lane in turn, and a six-step butterfly combines the 64 partial results by the sequential loop's own
-// rule: the lexicographic minimum of (squared distance, edge index) over the facing edges, the lexicographic (largest signed
-// distance, smallest edge index), the conjunction of "seen from inside". Both orders are total on what takes part (a NaN never
-// replaced the running value in the loop and is left out here), so the order of combination does not matter: bit-identical to
-// outline_sweep_serial, in ~150 instructions per query instead of ten dependent trips through LDS.
-// MUST be reached by all 64 lanes of the wave (n_hull <= 64 = TB_MAX_HULL edges, one lane each).
-TB_DEV SweepOut outline_sweep_wide(const float4* hull, int n_hull, bool need, float qy, float qz) {
-  const int lane = (int)(threadIdx.x & 63);
+// The sweep SHARED BY THE WHOLE WAVE, FOUR QUERIES AT A TIME (the env wave of the policy rollout kernels, which brings all 64 lanes into
+// substep: 16 or 48 of them hold envs, the others a far-away dummy and nothing to do). The wave's four rows of 16 lanes each take one
+// asking lane's query; a lane evaluates the edges col, col + 16, col + 32, col + 48 of the outline for it -- the arithmetic of
+// sweep_edge -- and the 16 partial results of a row are combined by four rotate-and-combine steps on DPP (row_ror 8, 4, 2, 1:
+// register moves, not the LDS crossbar a shuffle goes through), by the sequential loop's own rule: the lexicographic minimum of
+// (squared distance, edge index) over the facing edges, the lexicographic (largest signed distance, smallest edge index), the
+// conjunction of "seen from inside". Both orders are total on what takes part (a NaN never replaced the running value in the loop
+// and is left out here), so the grouping does not matter: bit-identical to outline_sweep_serial.
+// For the lone env wave every LDS round trip is ~150 exposed cycles. A lane sweeping for itself pays ten of them; round 4's first
+// shared form -- one edge per lane over all 64, one query at a time, six shuffle steps -- paid eight per asking lane (stamps, PPO
+// collect under the trained policy: 3.5 lanes ask where one does, 2400 cycles each); a PASS here pays two -- the queries out, the
+// results back -- and serves four lanes (racket narrowphase 2190 -> 1580 cycles per wave and step).
+// MUST be reached by all 64 lanes of the wave (n_hull <= 64 = TB_MAX_HULL edges).
+template <int N> TB_DEV int ror16(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x120 + N, 0xf, 0xf, false); }
+template <int N> TB_DEV float ror16(float v) { return __int_as_float(ror16<N>(__float_as_int(v))); }
+struct SweepPart { float d2, ry, rz, sd; int bi, di, ins; };
+TB_DEV void sweep_merge(SweepPart& a, float od2, float ory, float orz, int obi, float osd, int odi, int oins) {
+  const bool closer = od2 < a.d2 || (od2 == a.d2 && obi < a.bi);
+  a.d2 = closer ? od2 : a.d2; a.ry = closer ? ory : a.ry; a.rz = closer ? orz : a.rz; a.bi = closer ? obi : a.bi;
+  const bool deeper = osd > a.sd || (osd == a.sd && odi < a.di);
+  a.sd = deeper ? osd : a.sd; a.di = deeper ? odi : a.di;
+  a.ins &= oins;
+}
+template <int N> TB_DEV void sweep_merge_ror(SweepPart& a) {
+  sweep_merge(a, ror16<N>(a.d2), ror16<N>(a.ry), ror16<N>(a.rz), ror16<N>(a.bi), ror16<N>(a.sd), ror16<N>(a.di), ror16<N>(a.ins));
+}
+TB_DEV SweepOut outline_sweep_rows(const float4* hull, int n_hull, bool need, float qy, float qz) {
+  const int lane = (int)(threadIdx.x & 63), row = lane >> 4, col = lane & 15;
   SweepOut mine;
   mine.best_d2 = 3.0e38f; mine.best_ry = 0.0f; mine.best_rz = 0.0f; mine.max_sd = -3.0e38f; mine.deep_edge = 0; mine.inside = true;
-  const bool has = lane < n_hull;
-  EdgeRec r;
-  r.e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f); r.e1 = make_float2(0.0f, 0.0f);
-  if (has) r = outline_edge(hull, lane);
-  for (unsigned long long todo = __ballot(need); todo; todo &= todo - 1ull) {
-    const int src = __ffsll((long long)todo) - 1;
-    const float py = __shfl(qy, src, 64), pz = __shfl(qz, src, 64);
-    float d2 = 3.0e38f, ry = 0.0f, rz = 0.0f, sd = -3.0e38f;
-    int bi = 0x7fffffff, di = 0x7fffffff, ins = 1;
-    if (has) {
-      const float4 e0 = r.e0;
-      float wy = py - e0.x, wz = pz - e0.y;
-      float cr = FMA(e0.z, wz, -(e0.w * wy));
-      float s1 = -(cr * r.e1.y);
-      if (s1 > -3.0e38f) { sd = s1; di = lane; }
-      const bool faces = cr < 0.0f;
-      float t = FMA(wy, e0.z, wz * e0.w) * r.e1.x;
-      t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
-      float y1 = FMA(-t, e0.z, wy), z1 = FMA(-t, e0.w, wz);
-      float q1 = FMA(y1, y1, z1 * z1);
-      if (faces & (q1 < 3.0e38f)) { d2 = q1; ry = y1; rz = z1; bi = lane; }
-      ins = faces ? 0 : 1;
-    }
+  EdgeRec r[4];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const float od2 = __shfl_xor(d2, off, 64), ory = __shfl_xor(ry, off, 64), orz = __shfl_xor(rz, off, 64), osd = __shfl_xor(sd, off, 64);
-      const int obi = __shfl_xor(bi, off, 64), odi = __shfl_xor(di, off, 64), oins = __shfl_xor(ins, off, 64);
-      const bool closer = od2 < d2 || (od2 == d2 && obi < bi);
-      d2 = closer ? od2 : d2; ry = closer ? ory : ry; rz = closer ? orz : rz; bi = closer ? obi : bi;
-      const bool deeper = osd > sd || (osd == sd && odi < di);
-      sd = deeper ? osd : sd; di = deeper ? odi : di;
-      ins &= oins;
+  for (int k = 0; k < 4; ++k) {
+    r[k].e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f); r[k].e1 = make_float2(0.0f, 0.0f);
+    if (col + 16 * k < n_hull) r[k] = outline_edge(hull, col + 16 * k);
+  }
+  const unsigned long long ask = __ballot(need);
+  const int rank = __popcll(ask & ((1ull << lane) - 1ull));  // this lane's place among the asking lanes
+  int pass = 0;
+  for (unsigned long long todo = ask; todo; ++pass) {
+    // the next four asking lanes, one per row (fewer left: the spare rows repeat the first and nobody reads them)
+    const int s0 = __ffsll((long long)todo) - 1;
+    int src = s0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (todo) { const int sk = __ffsll((long long)todo) - 1; src = row == k ? sk : src; todo &= todo - 1ull; }
     }
-    if (lane == src) {
-      mine.best_d2 = d2; mine.best_ry = ry; mine.best_rz = rz; mine.max_sd = sd; mine.deep_edge = di == 0x7fffffff ? 0 : di; mine.inside = ins != 0;
+    const float py = __shfl(qy, src, 64), pz = __shfl(qz, src, 64);
+    SweepPart a;
+    a.d2 = 3.0e38f; a.ry = 0.0f; a.rz = 0.0f; a.sd = -3.0e38f; a.bi = 0x7fffffff; a.di = 0x7fffffff; a.ins = 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = col + 16 * k;
+      if (16 * k < n_hull) {  // (wave-uniform)
+        const float4 e0 = r[k].e0;
+        float wy = py - e0.x, wz = pz - e0.y;
+        float cr = FMA(e0.z, wz, -(e0.w * wy));
+        float s1 = -(cr * r[k].e1.y);
+        const bool faces = cr < 0.0f;
+        float t = FMA(wy, e0.z, wz * e0.w) * r[k].e1.x;
+        t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+        float y1 = FMA(-t, e0.z, wy), z1 = FMA(-t, e0.w, wz);
+        float q1 = FMA(y1, y1, z1 * z1);
+        const bool has = idx < n_hull;
+        const bool takes_sd = has & (s1 > -3.0e38f), takes_d2 = has & faces & (q1 < 3.0e38f);
+        sweep_merge(a, takes_d2 ? q1 : 3.0e38f, y1, z1, takes_d2 ? idx : 0x7fffffff, takes_sd ? s1 : -3.0e38f, takes_sd ? idx : 0x7fffffff, (has & faces) ? 0 : 1);
+      }
+    }
+    sweep_merge_ror<8>(a); sweep_merge_ror<4>(a); sweep_merge_ror<2>(a); sweep_merge_ror<1>(a);
+    // every lane of a row holds its query's result now: the asking lane reads it from the row that served it
+    const int from = ((rank - 4 * pass) & 3) << 4;
+    const float fd2 = __shfl(a.d2, from, 64), fry = __shfl(a.ry, from, 64), frz = __shfl(a.rz, from, 64), fsd = __shfl(a.sd, from, 64);
+    const int fdi = __shfl(a.di, from, 64), fins = __shfl(a.ins, from, 64);
+    if (need && (rank >> 2) == pass) {
+      mine.best_d2 = fd2; mine.best_ry = fry; mine.best_rz = frz; mine.max_sd = fsd; mine.deep_edge = fdi == 0x7fffffff ? 0 : fdi; mine.inside = fins != 0;
     }
   }
   return mine;
@@ -1161,7 +1189,7 @@ enum : unsigned {
   SF_ESC = 16u,        // first phase of the large-batch fast-forward: hand over instead of sweeping (CT_ESCAPE)
   SF_REGGROUND = 32u,  // the racket<->court rows of a solve in registers (small-batch kernels that loop)
   SF_LAZYTAB = 64u,    // the LDS outline table is copied by the first wave that reads it (pipelined SwingRacket step kernel)
-  SF_WIDE = 128u,      // all 64 lanes of the wave are in the substep: the outline sweep takes one edge per lane (outline_sweep_wide)
+  SF_WIDE = 128u,      // all 64 lanes of the wave are in the substep: the outline sweep is shared, four queries at a time (outline_sweep_rows)
 };
 template <int KIND, unsigned FORM>
 TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Manifold& M, vec3 Fr, vec3 Tr, vec3 Fb, float goal_x, float goal_y, float scale TB_STAMP_ARG,
@@ -1248,7 +1276,7 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
     TB_LANES(4, need);        // [4] lanes that need the outline sweep, [5] wave-substeps with one
     if constexpr (WIDE) {  // all 64 lanes are here, one edge each (the narrow policy rollout kernels: 16 envs and 48 dummies per env wave)
       if (__any(need)) {
-        const SweepOut so = outline_sweep_wide(hull, P.n_hull, need, ql.y, ql.z);
+        const SweepOut so = outline_sweep_rows(hull, P.n_hull, need, ql.y, ql.z);
         if (need) hr = racket_finish<KIND == TB_ENV_TENNIS>(P, hull, rk, d, scale, ql, qax, so);
       }
     } else if constexpr (!RELOAD) {  // each lane for itself

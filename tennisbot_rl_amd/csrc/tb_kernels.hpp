@@ -47,6 +47,7 @@ struct KArgs {
   float** pool_dst_out;   // [ff_cap] where the deferred env's terminal reward goes: written next to its record
   float* const* pool_dst_in;  // the pool kernel reads it back (null: A.reward + env index)
   int defer;
+  unsigned long long* ff_sealed;  // the pool's sealed-fate exit (fate_sealed): where the substeps it did not run are counted; null = exit off
   // fused policy inference (tb_policy_step): actions are computed in-kernel from pol_obs
   const float* pol_weights;  // packed SB3 MlpPolicy towers, see PolicyNet
   const float* pol_obs;      // [n][O] the observation each env acts on
@@ -352,6 +353,40 @@ TB_DEV vec3 restoring_force(const EnvRegs& e) {  // swingracket_env.py:135-141
   return mk(-50.0f * (e.r.p.x - e.aux[2]), -2.0f * (e.r.p.y - e.aux[3]), -2.0f * ((e.r.p.z - e.aux[4]) - 4.0f));
 }
 
+// THE SEALED FATE of a fast-forward (the pool's instantiations only, TbOptions.ff_seal). Under a trained policy a struck ball often
+// leaves the court: it then falls until the 800-substep limit ends the episode with reward 0 (swingracket_env.py:127-128), and
+// with auto-reset nothing else of that flight is ever read -- not the state (the env restarts), not an observation (the pool
+// writes none), only the reward, the done flag and the substep count. A wave pays for its longest lane, so a quarter of the pool's
+// waves ran ~400 substeps for one such ball. This test names the flights whose outcome CANNOT be anything but the timeout; the
+// caller then books the remaining substeps (counters[6], the substeps output and step_count are what the full flight gives) and
+// leaves. It claims, from this substep on:
+//   (1) the ball is below every static shape -- all of them are centred on z = 0 and reach at most static_top from it -- and is
+//       falling: gravity and the drag -v kd (kd dt < 1: a velocity component keeps its sign) leave v.z < 0 and the horizontal
+//       velocity components their signs for as long as nothing touches the ball (no Magnus force: magnus_k == 0 is required);
+//   (2) the racket cannot touch it either: on one horizontal axis the ball is beyond the racket's reach and moving away (or
+//       still), and the racket's centre on that axis is a damped oscillator about its anchor (force -k xi of :135-141, drag
+//       -v kd with kd >= 0 varying) whose amplitude stays under 1.25 sqrt(xi^2 + v^2 / w^2) + 0.05 m. (The discrete
+//       recurrence v' = v (1 - c) - w^2 dt xi, xi' = xi + dt v' with an adversary choosing c in [0, 0.2] every substep stays under
+//       1.06 of that root for w dt <= 0.2; the host checks both limits on the parameters: seal_params_ok. The racket's own
+//       contact with the court is the extended contact set, whose instantiations do not have this exit.)
+//   So no contact ever happens again: (1) and (2) hold at the next substep by the same argument, the termination tests of
+//   :111-123 stay false and :127 fires at step_count 801. Rounding is no part of the argument: every margin above is orders of
+//   magnitude beyond an ulp. Checked every 8th substep, by waves with a ball under the court only.
+// The oracle does not have this exit: every pool-form parity test compares against the flight run to its end.
+TB_DEV bool state_is_finite(const EnvRegs& e);
+TB_DEV bool fate_sealed(const KParams& P, const EnvRegs& e) {
+  if (!(e.b.v.z < 0.0f) || !(dot(e.b.v, e.b.v) < 1.0e6f) || !(dot(e.r.v, e.r.v) < 1.0e6f) || !state_is_finite(e)) return false;
+  if (!(P.flags & TB_F_RACKET_BALL)) return true;
+  const float reach = (((P.hull_bound_radius + P.hull_margin) + P.ball_radius) + P.contact_threshold) + 0.01f;
+  const float xi = e.r.p.x - e.aux[2], yi = e.r.p.y - e.aux[3];
+  const float bx = 1.25f * sqrtf(xi * xi + (e.r.v.x * e.r.v.x) / (50.0f * P.racket_inv_mass)) + 0.05f;
+  const float by = 1.25f * sqrtf(yi * yi + (e.r.v.y * e.r.v.y) / (2.0f * P.racket_inv_mass)) + 0.05f;
+  const float dx = e.b.p.x - e.aux[2], dy = e.b.p.y - e.aux[3];
+  const bool away_x = (e.b.v.x >= 0.0f && dx - bx > reach) || (e.b.v.x <= 0.0f && -dx - bx > reach);
+  const bool away_y = (e.b.v.y >= 0.0f && dy - by > reach) || (e.b.v.y <= 0.0f && -dy - by > reach);
+  return away_x || away_y;
+}
+
 // swingracket_env.py:75-145 as ONE loop around ONE substep call site (the substep is the bulk of
 // the kernel's code and registers; two inlined copies cost occupancy):
 //   iteration 0      the agent's substep (:76-83), contact bonus while step_count < 25 (:98-101)
@@ -367,9 +402,11 @@ TB_DEV vec3 restoring_force(const EnvRegs& e) {  // swingracket_env.py:135-141
 // SF_ESC  = first phase of the large-batch tb_ff_kernel: a lane that needs the racket's exact narrowphase leaves the loop BEFORE
 //           that substep (`parked` again, nothing of the substep applied); see substep.
 // SF_LAZYTAB = see substep (the pipelined step kernel: `hull` is filled from `table_mem` by the first wave that reads it)
-template <unsigned FORM, bool BUDGET = false>
+// SEAL    = tb_ff_kernel's pool instantiations: the sealed-fate exit (fate_sealed); `sealed` counts the substeps it books without running
+template <unsigned FORM, bool BUDGET = false, bool SEAL = false>
 TB_DEV float swing_loop(const KParams& P, const float4* hull, EnvRegs& e, Manifold& M, vec3 F, vec3 T, bool in_ff, bool defer, bool& parked,
-                        int& ns, uint32_t* cnt TB_STAMP_ARG, int budget = 0, const float4* table_mem = nullptr) {
+                        int& ns, uint32_t* cnt TB_STAMP_ARG, int budget = 0, const float4* table_mem = nullptr, bool seal = false,
+                        uint32_t* sealed = nullptr) {
   const vec3 zero = mk(0.0f, 0.0f, 0.0f);
   float reward = 0.0f;
   for (;;) {
@@ -388,6 +425,19 @@ TB_DEV float swing_loop(const KParams& P, const float4* hull, EnvRegs& e, Manifo
       if (bits & CT_GOAL) { reward += moved_dist_to_goal(e); reward += 50.0f; e.done = TB_DONE_PENDING_FORCE; cnt[2]++; }  // :119-123
       if (e.step_count > 800) { if (!e.done) cnt[3]++; e.done = TB_DONE_PENDING_FORCE; }  // :127-128
       if (e.done) break;
+      if constexpr (SEAL) {
+        if (seal && (e.step_count & 7) == 0) {
+          const bool under = ((e.b.p.z + P.ball_radius) + P.contact_threshold) < -P.static_top - 1.0e-3f;
+          if (__any(under)) {
+            if (under && fate_sealed(P, e)) {  // nothing but the timeout of :127-128 can end this flight: book it
+              const int left = 801 - e.step_count;
+              ns += left; *sealed += (uint32_t)left;
+              e.step_count = 801; cnt[3]++; e.done = TB_DONE_PENDING_FORCE;
+              break;
+            }
+          }
+        }
+      }
       F = restoring_force(e);  // :135-141 (also issued when done just became true; it then waits in the accumulator: TB_DONE_PENDING_FORCE)
       if (BUDGET && --budget <= 0) { parked = true; break; }
     }
@@ -718,7 +768,7 @@ __global__ void __launch_bounds__((2 * S + 1) * 64) tb_policy_rollout_kernel(KAr
   const bool live = lane < E && i < A.n;
   // Lanes without an env (48 of the 64 at S = 1) step a DUMMY: a racket hovering at rest, a ball a kilometre up, a step counter that
   // never reaches an episode end. It touches nothing, asks for nothing and is never stored -- but its lane is IN the substep, so the
-  // racket narrowphase can hand every lane one edge of an asking env's outline sweep (outline_sweep_wide).
+  // racket narrowphase can share the outline sweeps of the asking envs among all 64 lanes (outline_sweep_rows).
   EnvRegs e;
   {
     const vec3 z3 = mk(0.0f, 0.0f, 0.0f);
@@ -772,9 +822,10 @@ __global__ void __launch_bounds__((2 * S + 1) * 64) tb_policy_rollout_kernel(KAr
       bool d = false, parked = false;
       float rew;
       // (every lane of the wave, dummies included: see above)
-      // (the wide sweep where 48 of the 64 lanes are dummies; with 48 envs per wave -- S = 3 -- its one-query-at-a-time loop loses to every
-      //  lane sweeping for itself: PPO collect under the trained policy, same box, S = 1: 570-574 -> 592-595 M env steps/s, S = 3: 461 -> 426 M)
-      constexpr unsigned FORM = (RG ? SF_RG : 0u) | SF_COLD | (S == 1 ? SF_WIDE : 0u);
+      // (the shared outline sweep, four asking lanes at a time: outline_sweep_rows. PPO collect under the trained policy, same box, 16 envs per
+      //  env wave, 4096 envs: each lane sweeping for itself 570-574, one query at a time over 64 lanes 592-595 -> 622, four at a time 644 M env
+      //  steps/s; 48 envs per wave, 16384 envs: for itself 1036 -> 1057 M -- there the one-query form had lost, 461 -> 426 M at 4096 envs)
+      constexpr unsigned FORM = (RG ? SF_RG : 0u) | SF_COLD | SF_WIDE;
       if (KIND == TB_ENV_SWING) rew = swing_step<FORM>(Pl, s_hull, e, M, a, ns, cnt, true, parked TB_STAMP_PASS);  // never loops in here: see tb_step_kernel<LEAN>
       else rew = tennis_step<FORM | SF_REGROWS>(Pl, s_hull, e, M, a, o, d, cnt TB_STAMP_PASS);
       if (live) {
@@ -824,6 +875,8 @@ __global__ void __launch_bounds__((2 * S + 1) * 64) tb_policy_rollout_kernel(KAr
     if constexpr (RG) { if (M.n > 0 || had_contacts) store_manifold(A, i, M, had_contacts); }
   }
   flush_counters(A.counters, cnt);
+  TB_DIAG_STAMPS_END(st);
+  TB_DIAG_ADD_LANE0(9, 1);
 }
 
 // progress mark (tb_mark_record): one thread bumps a counter in pinned host memory. Relaxed on purpose: the kernels this
@@ -933,6 +986,7 @@ __global__ void __launch_bounds__(64, (ESC && !RG) ? 4 : 1) tb_ff_kernel(KArgs A
   uint32_t cnt[TB_N_COUNTERS];
 #pragma unroll
   for (int k = 0; k < TB_N_COUNTERS; ++k) cnt[k] = 0u;
+  uint32_t n_sealed = 0u;
   TB_DIAG_STAMPS_BEGIN(st);
   int n_src = A.ff_src_count ? *A.ff_src_count : A.n;
   if (A.pool_dst_in && n_src > A.ff_cap) n_src = A.ff_cap;  // (the pool's counter runs on past its capacity; what did not fit was finished in place)
@@ -977,12 +1031,14 @@ __global__ void __launch_bounds__(64, (ESC && !RG) ? 4 : 1) tb_ff_kernel(KArgs A
       const int ns0 = ns;
       // (small batches: the racket<->court rows of a solve in registers -- one wave per SIMD anyway, and a grounded racket's lane is alone in its wave)
       constexpr unsigned FORM = (RG ? SF_RG : 0u) | (BIG ? SF_RELOAD : 0u) | (ESC ? SF_ESC : 0u) | (RG && !BIG ? SF_REGGROUND : 0u);
-      float rew = swing_loop<FORM, true>(A.P, s_hull, e, M, F0, zero, true, false, unfinished, ns, cnt TB_STAMP_PASS, budget);
+      constexpr bool SEAL = POOL && !RG;
+      const bool seal = SEAL && A.ff_sealed != nullptr && !A.term_obs;
+      float rew = swing_loop<FORM, true, SEAL>(A.P, s_hull, e, M, F0, zero, true, false, unfinished, ns, cnt TB_STAMP_PASS, budget, nullptr, seal, &n_sealed);
       if constexpr (POOL) {
         // a full pool: finish here after all (the counter is read, not reserved: see the slack above)
         if (unfinished && A.ff_next && *reinterpret_cast<volatile int*>(A.ff_next_count) >= A.ff_cap) {
           unfinished = false;
-          rew = swing_loop<FORM, true>(A.P, s_hull, e, M, restoring_force(e), zero, true, false, unfinished, ns, cnt TB_STAMP_PASS, 0x7fffffff);
+          rew = swing_loop<FORM, true, SEAL>(A.P, s_hull, e, M, restoring_force(e), zero, true, false, unfinished, ns, cnt TB_STAMP_PASS, 0x7fffffff, nullptr, seal, &n_sealed);
         }
       }
       cnt[6] += (uint32_t)(ns - ns0);
@@ -1020,6 +1076,13 @@ __global__ void __launch_bounds__(64, (ESC && !RG) ? 4 : 1) tb_ff_kernel(KArgs A
     }
   }
   flush_counters(A.counters, cnt);
+  if constexpr (POOL && !RG) {
+    if (__ballot(n_sealed != 0u) != 0ull) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) n_sealed += __shfl_xor(n_sealed, off, 64);
+      if (lane == 0) atomicAdd(A.ff_sealed, (unsigned long long)n_sealed);
+    }
+  }
   TB_DIAG_STAMPS_END(st);
   TB_DIAG_ADD_LANE0(9, 1);
 }

@@ -136,7 +136,7 @@ struct TbHandle {
   float4* d_hull;
   float4* h_hull;  // pinned staging copy of the outline table
   float cull_planes[TB_N_CULL][3];  // derived from the outline (to_kparams); they travel behind it in the same table
-  unsigned long long* d_counters;     // [TB_COUNTER_SHARDS][TB_N_COUNTERS]
+  unsigned long long* d_counters;     // [TB_COUNTER_SHARDS][TB_N_COUNTERS] + one word: substeps booked by the pool's sealed-fate exit
   uint32_t* d_mani;                   // [TB_MANI_WORDS][n] racket<->court contact caches
   uint8_t* d_mflag;                   // [n]
   // pipelined fast-forward
@@ -214,10 +214,21 @@ int pick_block(int kind, int n, const TbOptions& o) {
   return kind == TB_ENV_SWING && n >= 49152 && n <= 131072 ? 64 : 128;
 }
 
+// the parameter side of the pool's sealed-fate exit (fate_sealed in tb_kernels.hpp states the argument these limits belong to)
+bool seal_params_ok(const TbHandle* h) {
+  const KParams& k = h->kp;
+  if (h->opt.ff_seal < 0 || h->kind != TB_ENV_SWING || !(k.flags & TB_F_AUTO_RESET) || k.magnus_k != 0.0f) return false;
+  if (!(k.dt > 0.0f) || !(k.gravity > 0.0f) || !(k.racket_inv_mass > 0.0f) || !(k.lin_damp >= 0.0f) || !(k.lin_damp_quad >= 0.0f)) return false;
+  const double wdt2 = 50.0 * (double)k.racket_inv_mass * (double)k.dt * (double)k.dt;      // (w dt)^2 of the stiffer axis
+  const double c_max = (double)k.dt * ((double)k.lin_damp + 1000.0 * (double)k.lin_damp_quad);  // drag per substep at the 1000 m/s the test admits
+  return wdt2 <= 0.04 && c_max <= 0.2;
+}
+
 KArgs base_args(const TbHandle* h) {
   KArgs a;
   memset(&a, 0, sizeof a);
   a.P = h->kp; a.words = h->d_words; a.done_state = h->d_done; a.hull = h->d_hull; a.counters = h->d_counters;
+  a.ff_sealed = seal_params_ok(h) ? h->d_counters + TB_N_COUNTERS * TB_COUNTER_SHARDS : nullptr;
   a.mani = h->d_mani; a.mflag = h->d_mflag;
   a.seed = h->seed; a.env_id_base = h->env_id_base; a.n = h->n; a.T = 1;
   return a;
@@ -593,6 +604,7 @@ int tb_create(const TbParams* params, const TbOptions* options, int env_kind, in
     if (opt.policy_slices != 0 && opt.policy_slices != 1 && opt.policy_slices != 3) return fail(TB_E_INVAL, "tb_create: TbOptions.policy_slices must be 0, 1 or 3");
     if (opt.ff_defer < -1 || opt.ff_defer > 2) return fail(TB_E_INVAL, "tb_create: TbOptions.ff_defer must be -1, 0, 1 or 2");
     if (opt.ff_defer_margin < 0 || opt.ff_defer_margin > 800) return fail(TB_E_INVAL, "tb_create: TbOptions.ff_defer_margin must be in [0, 800]");
+    if (opt.ff_seal < -1 || opt.ff_seal > 1) return fail(TB_E_INVAL, "tb_create: TbOptions.ff_seal must be -1, 0 or 1");
   }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -626,8 +638,8 @@ int tb_create(const TbParams* params, const TbOptions* options, int env_kind, in
   CREATE_TRY(hipMalloc((void**)&h->d_done, (size_t)n_envs));
   CREATE_TRY(hipMalloc((void**)&h->d_hull, sizeof(float4) * TB_HULL_LDS));
   CREATE_TRY(hipHostMalloc((void**)&h->h_hull, sizeof(float4) * TB_HULL_LDS, hipHostMallocDefault));
-  CREATE_TRY(hipMalloc((void**)&h->d_counters, sizeof(unsigned long long) * TB_N_COUNTERS * TB_COUNTER_SHARDS));
-  CREATE_TRY(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * TB_N_COUNTERS * TB_COUNTER_SHARDS, 0));
+  CREATE_TRY(hipMalloc((void**)&h->d_counters, sizeof(unsigned long long) * (TB_N_COUNTERS * TB_COUNTER_SHARDS + 1)));
+  CREATE_TRY(hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * (TB_N_COUNTERS * TB_COUNTER_SHARDS + 1), 0));
   CREATE_TRY(hipMalloc((void**)&h->d_mani, sizeof(uint32_t) * (size_t)TB_MANI_WORDS * n_envs));
   CREATE_TRY(hipMalloc((void**)&h->d_mflag, (size_t)n_envs));
   CREATE_TRY(hipMemsetAsync(h->d_mflag, 0, (size_t)n_envs, 0));
@@ -1124,6 +1136,15 @@ int tb_counters(TbHandle* h, uint64_t* out, void* stream) {
   return TB_OK;
 }
 
+int tb_sealed_substeps(TbHandle* h, uint64_t* out, void* stream) {
+  if (!h || !out) return fail(TB_E_INVAL, "tb_sealed_substeps: null argument");
+  DeviceGuard g(h->device);
+  if (int rc = flush_all(h, (hipStream_t)stream)) return rc;
+  HIP_TRY(hipMemcpyAsync(out, h->d_counters + TB_N_COUNTERS * TB_COUNTER_SHARDS, sizeof(uint64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return TB_OK;
+}
+
 int tb_diag_stream_copy(const uint32_t* src_dev, uint32_t* dst_dev, int n, int rows, int device, void* stream) {
   if (!src_dev || !dst_dev || n <= 0 || rows <= 0) return fail(TB_E_INVAL, "tb_diag_stream_copy: bad argument");
   DeviceGuard g(device);
@@ -1150,7 +1171,7 @@ int tb_diag_idle(int waves, int microseconds, int device, void* stream) {
 int tb_counters_reset(TbHandle* h, void* stream) {
   if (!h) return fail(TB_E_INVAL, "tb_counters_reset: null handle");
   DeviceGuard g(h->device);
-  HIP_TRY(hipMemsetAsync(h->d_counters, 0, sizeof(uint64_t) * TB_N_COUNTERS * TB_COUNTER_SHARDS, (hipStream_t)stream));
+  HIP_TRY(hipMemsetAsync(h->d_counters, 0, sizeof(uint64_t) * (TB_N_COUNTERS * TB_COUNTER_SHARDS + 1), (hipStream_t)stream));
   h->first_substeps = 0;
   return TB_OK;
 }

@@ -84,10 +84,11 @@ class TbOptions(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("block", ctypes.c_int32), ("tennis_reg_rows", ctypes.c_int32),
                 ("swing_reg_rows", ctypes.c_int32), ("ff_lanes_per_wave", ctypes.c_int32), ("ff_sort", ctypes.c_int32),
                 ("ff_phases", ctypes.c_int32), ("ff_defer", ctypes.c_int32), ("ff_defer_margin", ctypes.c_int32),
-                ("policy_slices", ctypes.c_int32)]
+                ("policy_slices", ctypes.c_int32), ("ff_seal", ctypes.c_int32)]
 
 
-def make_options(block=0, tennis_reg_rows=None, swing_reg_rows=None, ff_lanes_per_wave=0, ff_sort=None, ff_phases=0, policy_slices=0, ff_defer=None, ff_defer_margin=0):
+def make_options(block=0, tennis_reg_rows=None, swing_reg_rows=None, ff_lanes_per_wave=0, ff_sort=None, ff_phases=0, policy_slices=0, ff_defer=None, ff_defer_margin=0,
+                 ff_seal=None):
     """None = auto; True / False force a variant on / off"""
     def tri(x):
         return 0 if x is None else (1 if x else -1)
@@ -96,6 +97,7 @@ def make_options(block=0, tennis_reg_rows=None, swing_reg_rows=None, ff_lanes_pe
     o.block, o.tennis_reg_rows, o.swing_reg_rows = int(block), tri(tennis_reg_rows), tri(swing_reg_rows)
     o.ff_lanes_per_wave, o.ff_sort, o.ff_phases = int(ff_lanes_per_wave), tri(ff_sort), int(ff_phases)
     o.policy_slices, o.ff_defer_margin = int(policy_slices), int(ff_defer_margin)
+    o.ff_seal = tri(ff_seal)
     o.ff_defer = 2 if ff_defer == "all" else tri(ff_defer)  # "all": every parked env straight into the pool
     return o
 

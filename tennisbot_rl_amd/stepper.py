@@ -68,6 +68,7 @@ def load_library():
     L.tb_set_state.argtypes = [vp, vp, vp, i32, vp]
     L.tb_counters.argtypes = [vp, vp, vp]
     L.tb_counters_reset.argtypes = [vp, vp]
+    L.tb_sealed_substeps.argtypes = [vp, vp, vp]
     L.tb_set_pipeline.argtypes = [vp, i32]
     L.tb_set_pipeline.restype = i32
     L.tb_flush.argtypes = [vp, vp]
@@ -579,6 +580,12 @@ class BatchedEnv:
         c = (ctypes.c_uint64 * N_COUNTERS)()
         _check(self.L, self.L.tb_counters(self._h, c, self._stream()), "tb_counters")
         return dict(zip(COUNTER_NAMES, [int(x) for x in c]))
+
+    def sealed_substeps(self):
+        """how many of counters()['substeps'] the pool's sealed-fate exit booked without running them (TbOptions.ff_seal)"""
+        c = ctypes.c_uint64(0)
+        _check(self.L, self.L.tb_sealed_substeps(self._h, ctypes.byref(c), self._stream()), "tb_sealed_substeps")
+        return int(c.value)
 
     def counters_reset(self):
         _check(self.L, self.L.tb_counters_reset(self._h, self._stream()), "tb_counters_reset")

@@ -51,8 +51,10 @@ def main():
     if list(got.values()) != want:
         raise SystemExit("MISMATCH counters: %r vs %r" % (got, want))
     print("fused policy rollout under the reference's trained policy, %d envs x %d steps (%s envs per env wave%s): %d racket-ball contact substeps, %d goal hits, "
-          "%d episode ends, every observation / reward / done and the counters bit-identical to the f32 oracle"
-          % (n, T, {0: "auto", 1: "16", 3: "48"}[slices], ", full contact set" if rg else "", got["racket_ball_contact_substeps"], got["goal_hits"], got["episodes_finished"]))
+          "%d episode ends, %d timeouts (%d of %d substeps booked by the pool's sealed-fate exit, not run), every observation / reward / done and the "
+          "counters bit-identical to the f32 oracle"
+          % (n, T, {0: "auto", 1: "16", 3: "48"}[slices], ", full contact set" if rg else "", got["racket_ball_contact_substeps"], got["goal_hits"], got["episodes_finished"],
+             got["timeouts"], env.sealed_substeps(), got["substeps"]))
 
 
 if __name__ == "__main__":

@@ -1187,6 +1187,66 @@ def test_fast_forward_with_balls_thrown_at_a_spinning_racket(torch, n, options):
     env.close()
 
 
+@pytest.mark.parametrize("options", [dict(ff_defer="all"), dict(ff_defer=True, ff_defer_margin=40)], ids=["pool", "stragglers"])
+def test_sealed_fate_exit_books_exactly_what_the_full_flight_gives(torch, options):
+    """TbOptions.ff_seal: the pool leaves a flight whose ball has fallen below the court, out of the racket's reach for good, and books
+    the substeps up to the 800-substep timeout instead of running them. The oracle has no such exit: rewards, done flags,
+    observations and every counter (substeps and timeouts among them) must be those of the flights run to their end. The states
+    are chosen against the exit's argument: rackets that the court does not hold (default contact set) fall under it beside the
+    balls, swinging about their anchors at up to 8 m/s, balls pass within centimetres of them below the court, and a racket that
+    does strike there can send the ball back up into the court's underside -- an exit taken one check too early shows as a
+    missing racket contact, a wrong reward or a wrong substep count."""
+    from tennisbot_rl_amd.stepper import BatchedEnv
+    n = 8192
+    rng = np.random.default_rng(4321)
+    p = default_params()
+    pf = p.copy(); pf.flags |= F_AUTO_RESET
+    ref = OracleBatch(pf, ENV_SWING, n, seed=5, precision="f32")
+    ref.L.tbo_set_threads(ref.h, 16)
+    q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    spawn = np.array([9.0, 0.0, 0.6])
+    rp = spawn[None, :] + np.stack([rng.uniform(-1.5, 1.5, n), rng.uniform(-4, 4, n), rng.uniform(-8, 3, n)], 1)
+    rv = np.stack([rng.uniform(-8, 8, n), rng.uniform(-4, 4, n), rng.uniform(-6, 2, n)], 1)
+    u = rng.normal(size=(n, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    bp = rp + u * rng.uniform(0.7, 6.0, n)[:, None]
+    kind = rng.integers(0, 3, n)
+    # a third drift beside the racket, a third are thrown at where it will be, a third fly anywhere (most of those out of the court)
+    tof = rng.uniform(0.1, 1.5, n)
+    aimed = (rp + rv * tof[:, None] - bp) / tof[:, None] + rng.normal(scale=0.5, size=(n, 3))
+    bv = np.where((kind == 0)[:, None], rv + rng.normal(scale=0.7, size=(n, 3)), np.where((kind == 1)[:, None], aimed, rng.normal(scale=12.0, size=(n, 3))))
+    fields = dict(racket_pos=rp, racket_quat=q, racket_vel=rv, racket_angvel=rng.uniform(-9, 9, (n, 3)), ball_pos=bp, ball_vel=bv,
+                  ball_angvel=rng.uniform(-30, 30, (n, 3)), goal=np.stack([rng.uniform(-11, -4, n), rng.uniform(-4, 4, n)], 1), spawn_pos=tuple(spawn),
+                  init_dist=rng.uniform(8, 20, n), step_count=25)
+    w, d = make_words(ENV_SWING, n, **fields)
+    ref.set_state_words(w, d)
+    acts = [rng.uniform(-1, 1, (n, 6)).astype(np.float32) for _ in range(27)]
+    want = [ref.step(a) for a in acts[:1]]
+    ref_first = want[0]
+    assert ref_first[2].all()
+    late = ref.counters()
+    assert late[3] > n // 4 and late[0] > n // 50, late  # timeouts; racket contacts inside the fast-forward
+    want += [ref.step(a) for a in acts[1:]]
+    results = {}
+    for seal in (True, False):
+        env = BatchedEnv(ENV_SWING, n, device="cuda:0", seed=5, params=p, pipeline=True, track_terminal_obs=False, options=dict(options, ff_seal=seal))
+        env.set_state_words(torch.from_numpy(w.view(np.int32)).cuda(), torch.from_numpy(d).cuda())
+        outs = []
+        for t, a in enumerate(acts):
+            obs, rew, done = env.step(torch.from_numpy(a).cuda())
+            same(done.cpu().numpy(), want[t][2], "done %d" % t); same(obs.cpu().numpy(), want[t][0], "obs %d" % t)
+            outs.append(rew)
+        env.flush()
+        for t, rew in enumerate(outs):
+            same(rew.cpu().numpy(), want[t][1], "reward %d (ff_seal %s)" % (t, seal))
+        got = env.counters()
+        assert list(got.values()) == [int(x) for x in ref.counters()], (seal, got, ref.counters())
+        results[seal] = (env.sealed_substeps(), got["substeps"])
+        env.close()
+    assert results[False][0] == 0
+    booked, total = results[True]
+    assert booked > 0.3 * total, results  # the exit did fire: a good part of these flights' substeps were never run
+
+
 def thrown_at_racket_through_the_short_steps(torch, n, n_edges, options, step0=12, threads=16):
     """balls thrown at spinning rackets from inside the bounding sphere to well outside it, starting at agent step `step0`: half of
     them arrive during the short steps step0+1 .. 25 (the step kernels' racket narrowphase), the others in the fast-forward; the rest

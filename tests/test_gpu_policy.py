@@ -330,14 +330,14 @@ def test_trainer_collect_by_rollout_launch_equals_per_step_launches(torch):
 
 
 @pytest.mark.parametrize("n,slices,n_edges", [(1000, 0, 0), (4096, 0, 0), (5000, 0, 0), (1000, 3, 0), (1000, 1, 64), (777, 1, 63), (900, 1, 5), (900, 1, 3),
-                                              (600, 3, 11)])
+                                              (600, 3, 11), (800, 1, 16), (800, 1, 17), (800, 1, 33), (800, 1, 48), (800, 1, 49), (700, 3, 64), (640, 3, 3)])
 def test_fused_rollout_under_the_trained_policy_matches_the_oracle(torch, n, slices, n_edges):
     """the env wave of tb_policy_rollout against the ORACLE, directly, where it works hardest: under the reference's trained policy the
     racket goes for the ball, and a fifth of an env wave's substeps run the outline sweep and the contact solver (random weights
     hardly ever get there). Three episodes in one call; the oracle is stepped with the actions the kernel reports; every
     observation, reward, done flag and counter bit for bit, with batch sizes that end in partial waves and slices.
-    n_edges: other racket outlines (tests/outlines.py) -- the 16-env form sweeps an outline with ONE EDGE PER LANE of the env wave
-    (outline_sweep_wide: 64 edges = every lane, 63 = one lane without, 3 and 5 = most lanes without), the 48-env form lane by lane"""
+    n_edges: other racket outlines (tests/outlines.py) -- the env wave shares its outline sweeps, four queries at a time, 16 lanes each
+    (outline_sweep_rows; 16 / 17, 48 / 49 = a lane's second / fourth edge begins; 64 edges = four per lane, 63 = one lane with three, 3 and 5 = most lanes with none, 11 = one edge for some), with 16 and with 48 envs per env wave"""
     import os
     from tennisbot_rl_amd.params import F_AUTO_RESET, default_params
     from tennisbot_rl_amd.ppo import SWING_DEFAULTS, build_actor_critic, pack_policy
