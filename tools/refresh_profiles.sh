@@ -49,5 +49,9 @@ else
   python3 tools/diag/r02_ff_ab.py lanes rg > $OUT/racket_ground_lanes.log 2>&1 || { tail -20 $OUT/racket_ground_lanes.log; exit 1; }
   python3 tools/diag/r04_cadence.py > $OUT/cadence.log 2>&1 || { tail -20 $OUT/cadence.log; exit 1; }
   cp $R/gpurun_out/r04_cadence.json $OUT/cadence.json
+  python3 tools/diag/r04_seal_ab.py > $OUT/seal_ab.log 2>&1 || { tail -20 $OUT/seal_ab.log; exit 1; }
+  cp $R/gpurun_out/r04_seal_ab.json $OUT/seal_ab.json
+  python3 tools/diag/r04_policy_stamps.py 2>&1 | grep -v amdgpu.ids > $OUT/policy_stamps.txt || exit 1
+  python3 tools/diag/r03_policy_census.py 2>&1 | grep -v amdgpu.ids > $OUT/policy_census.txt || exit 1
   grep -v amdgpu.ids $OUT/ppo_probe.log $OUT/collect_breakdown.log | cut -c1-600
 fi
