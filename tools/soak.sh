@@ -10,5 +10,6 @@ done
 for args in "4096 1040" "4096 520 3" "1000 520 1 rg" "20000 104"; do
   timeout -k 10 500 python3 tests/soak_policy.py $args 2>&1 | grep -v amdgpu.ids | tail -1 || exit 1
 done
+timeout -k 10 900 python3 tests/soak_seal.py 12 32768 2>&1 | grep -v amdgpu.ids | tail -1 || exit 1
 } > $O/soak_parity.txt
 cat $O/soak_parity.txt
