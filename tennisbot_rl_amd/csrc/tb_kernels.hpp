@@ -70,6 +70,14 @@ struct EnvRegs {
   uint32_t done;
 };
 
+// an empty asm that reads every state register: whatever loaded them has landed behind it (the compiler places the waits)
+TB_DEV void landed_env(const EnvRegs& e) {
+  asm volatile("" :: "v"(e.r.p.x), "v"(e.r.p.y), "v"(e.r.p.z), "v"(e.r.q.x), "v"(e.r.q.y), "v"(e.r.q.z), "v"(e.r.q.w), "v"(e.r.v.x), "v"(e.r.v.y), "v"(e.r.v.z),
+               "v"(e.r.w.x), "v"(e.r.w.y), "v"(e.r.w.z));
+  asm volatile("" :: "v"(e.b.p.x), "v"(e.b.p.y), "v"(e.b.p.z), "v"(e.b.v.x), "v"(e.b.v.y), "v"(e.b.v.z), "v"(e.b.w.x), "v"(e.b.w.y), "v"(e.b.w.z));
+  asm volatile("" :: "v"(e.aux[0]), "v"(e.aux[1]), "v"(e.aux[2]), "v"(e.aux[3]), "v"(e.aux[4]), "v"(e.aux[5]), "v"(e.step_count), "v"(e.episode), "v"(e.done));
+}
+
 template <int KIND> struct Dims;
 template <> struct Dims<TB_ENV_SWING> { static constexpr int W = TB_SWING_WORDS, A = TB_SWING_ACT_DIM, O = TB_SWING_OBS_DIM, NAUX = 6; };
 template <> struct Dims<TB_ENV_TENNIS> { static constexpr int W = TB_TENNIS_WORDS, A = TB_TENNIS_ACT_DIM, O = TB_TENNIS_OBS_DIM, NAUX = 4; };
@@ -661,9 +669,19 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
     bool any_reset = false;
     int ns_total = 0;
     const int n_steps = MULTI ? A.T : 1;
+    // MULTI: every state load has landed before the loop is entered. Left alone, the loop's first use of each state value carries a
+    // wait that the compiler must place for the first trip -- and that, in every later trip, waits for the previous step's STORES
+    // and for the action prefetch below (the memory counter is one, and in order): a full round trip per step with nothing to hide it.
+    if constexpr (MULTI && !POLICY) landed_env(e);
     for (int t = 0; t < n_steps; ++t) {
       const size_t row = (size_t)t * A.n + i;
-      if (!POLICY && t > 0) load_actions<KIND>(A.actions, row, a);
+      // MULTI: the actions of step t + 1 are requested before step t is computed -- nothing else of a step waits for memory (the state
+      // is in registers), so a load at the top of each step was a whole memory round trip per step that nothing hid
+      // (tb_rollout at 4096 envs, same box: SwingRacket 2.0 -> 3.x G env steps/s, see profiles/r04_rollout_rate.json)
+      float a_next[NA];
+      if constexpr (MULTI && !POLICY) {
+        if (t + 1 < n_steps) load_actions<KIND>(A.actions, row + (size_t)A.n, a_next);
+      }
       float o[NO];
       int ns = 1;
       bool d, parked = false;
@@ -705,6 +723,12 @@ __global__ void __launch_bounds__(256) tb_step_kernel(const uint32_t* __restrict
       write_obs<KIND>(A.obs, row, o);
       A.reward[row] = rew;
       A.done_out[row] = d ? 1 : 0;
+      if constexpr (MULTI && !POLICY) {
+        if (t + 1 < n_steps) {
+#pragma unroll
+          for (int k = 0; k < NA; ++k) a[k] = a_next[k];
+        }
+      }
     }
     TB_DIAG_ADD_LANE0(15, stamp_now() - t_loaded);  // compute + output stores issued
     if (A.substeps) A.substeps[i] = ns_total;
