@@ -15,6 +15,8 @@
 //   -DTB_DIAG_NO_ANGULAR / _NO_ORIENT / _NO_NARROW (/ _NO_RACKET / _NO_STATICS: its halves)
 //                            timing-only ablations (tools/diag/diag_substep.py); RESULTS ARE WRONG
 //   -DTB_DIAG_NO_PHILOX      timing-only: the reset's Philox draws replaced by a trivial hash (RESULTS ARE WRONG)
+//   -DTB_DIAG_NO_TOWERS / _NO_ENVSTEP  timing-only: the policy rollout kernels without the MLP towers / without the env step
+//                            (tools/diag/r04_policy_ablate.py; RESULTS ARE WRONG)
 //   -DTB_DIAG_SWEEP_HELPERS=k  helper lanes of the wave-cooperative outline sweep (default 8)
 //   -DTB_DIAG_LDS_PAD        (host side, tb_stepper.hip dyn_lds) pad every step launch's dynamic LDS by tb_diag_set_lds_pad(bytes):
 //                            fewer workgroups per CU (tools/diag/r03_occupancy_probe.py)

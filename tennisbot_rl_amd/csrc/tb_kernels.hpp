@@ -780,7 +780,11 @@ __global__ void __launch_bounds__((2 * S + 1) * 64) tb_policy_rollout_kernel(KAr
       float x0[TowerRegs<KIND>::NC0], out[4];
       if (t == 0) policy_inputs<KIND>(A.pol_obs + (size_t)env_c * NO, lane, x0);
       else policy_inputs<KIND>(s_obs + slot * NO, lane, x0);
+#ifdef TB_DIAG_NO_TOWERS  // timing-only (tools/diag/r04_policy_ablate.py): RESULTS ARE WRONG
+      out[0] = x0[0] * 0.1f; out[1] = x0[0] * 0.2f; out[2] = x0[0] * 0.3f; out[3] = x0[0] * 0.4f;
+#else
       regs.apply(x0, out);
+#endif
       if (tower == 0) { if (grp < 2) *reinterpret_cast<float4*>(s_mean + slot * 8 + grp * 4) = make_float4(out[0], out[1], out[2], out[3]); }
       else if (lane < 16 && env < A.n) A.pol_value[(size_t)t * A.st_val + env] = out[0];
       __syncthreads();  // the action means of step t are in LDS
@@ -850,8 +854,13 @@ __global__ void __launch_bounds__((2 * S + 1) * 64) tb_policy_rollout_kernel(KAr
       //  env wave, 4096 envs: each lane sweeping for itself 570-574, one query at a time over 64 lanes 592-595 -> 622, four at a time 644 M env
       //  steps/s; 48 envs per wave, 16384 envs: for itself 1036 -> 1057 M -- there the one-query form had lost, 461 -> 426 M at 4096 envs)
       constexpr unsigned FORM = (RG ? SF_RG : 0u) | SF_COLD | SF_WIDE;
+#ifdef TB_DIAG_NO_ENVSTEP  // timing-only (tools/diag/r04_policy_ablate.py): RESULTS ARE WRONG
+      rew = a[0]; e.step_count += 1;
+      if (KIND == TB_ENV_TENNIS) make_obs<KIND>(e, o);
+#else
       if (KIND == TB_ENV_SWING) rew = swing_step<FORM>(Pl, s_hull, e, M, a, ns, cnt, true, parked TB_STAMP_PASS);  // never loops in here: see tb_step_kernel<LEAN>
       else rew = tennis_step<FORM | SF_REGROWS>(Pl, s_hull, e, M, a, o, d, cnt TB_STAMP_PASS);
+#endif
       if (live) {
         if (KIND == TB_ENV_SWING) {
           make_obs<TB_ENV_SWING>(e, o);
