@@ -853,7 +853,8 @@ __global__ void __launch_bounds__((2 * S + 1) * 64) tb_policy_rollout_kernel(KAr
       // (the shared outline sweep, four asking lanes at a time: outline_sweep_rows. PPO collect under the trained policy, same box, 16 envs per
       //  env wave, 4096 envs: each lane sweeping for itself 570-574, one query at a time over 64 lanes 592-595 -> 622, four at a time 644 M env
       //  steps/s; 48 envs per wave, 16384 envs: for itself 1036 -> 1057 M -- there the one-query form had lost, 461 -> 426 M at 4096 envs)
-      constexpr unsigned FORM = (RG ? SF_RG : 0u) | SF_COLD | SF_WIDE;
+      //  (not with 48 envs per wave AND the extended contact set: at that instantiation's 256-VGPR limit the shared sweep's edge records spill)
+      constexpr unsigned FORM = (RG ? SF_RG : 0u) | SF_COLD | (S == 1 || !RG ? SF_WIDE : 0u);
 #ifdef TB_DIAG_NO_ENVSTEP  // timing-only (tools/diag/r04_policy_ablate.py): RESULTS ARE WRONG
       rew = a[0]; e.step_count += 1;
       if (KIND == TB_ENV_TENNIS) make_obs<KIND>(e, o);

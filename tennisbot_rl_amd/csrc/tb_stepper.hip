@@ -352,7 +352,7 @@ int run_pool(TbHandle* h, hipStream_t q) {
   g = g < 1024 ? 1024 : g > 16384 ? 16384 : g;  // (workgroups beyond the pool's fill exit at once; grid-stride beyond 1 M records)
   (void)hipGetLastError();
   // whole episodes in the pool make it a LARGE batch -- 43 episodes x 4096 envs = 2752 waves: the instantiation built for occupancy
-  // (143 VGPRs, three waves per SIMD, wave-shared outline sweep) holds them all at once, the small-batch one (178 VGPRs, two per
+  // (153 VGPRs, three waves per SIMD, wave-shared outline sweep) holds them all at once, the small-batch one (188 VGPRs, two per
   // SIMD) ran them in two rounds
   const bool big = !rg && h->pool_episodes > 0 && records >= 131072;
   if (rg) hipLaunchKernelGGL((tb_ff_kernel<true, false, false, true>), dim3((unsigned)g), dim3(64), dyn_lds(false, true, 64), q, k);
