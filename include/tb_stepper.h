@@ -163,7 +163,8 @@ typedef struct TbHandle TbHandle;
 
 /*
  * Kernel-selection options (since ABI v3; they replace the TB_BLOCK / TB_TENNIS_REG_ROWS / TB_SWING_REG_ROWS
- * environment variables of v2; v4 names the former `reserved` field and changes the policy blob's fragment order). Every field: 0 = let the library choose from the batch size. None of
+ * environment variables of v2; v4 names the former `reserved` field and changes the policy blob's fragment order; `ff_seal` was appended
+ * within v4: `struct_size` tells the library whether a caller has it, and an older caller gets the automatic choice). Every field: 0 = let the library choose from the batch size. None of
  * them changes any result -- the variants are bit-identical (tests/test_gpu_parity.py runs them all) --
  * only which instantiation of the same arithmetic is launched.
  */
