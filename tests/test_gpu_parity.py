@@ -1188,7 +1188,7 @@ def test_fast_forward_with_balls_thrown_at_a_spinning_racket(torch, n, options):
 
 
 @pytest.mark.parametrize("options", [dict(ff_defer="all"), dict(ff_defer=True, ff_defer_margin=40)], ids=["pool", "stragglers"])
-def test_sealed_fate_exit_books_exactly_what_the_full_flight_gives(torch, options, seed=4321, n=8192):
+def test_sealed_fate_exit_books_exactly_what_the_full_flight_gives(torch, options, seed=4321, n=8192, over=None):
     """TbOptions.ff_seal: the pool leaves a flight whose ball has fallen below the court, out of the racket's reach for good, and books
     the substeps up to the 800-substep timeout instead of running them. The oracle has no such exit: rewards, done flags,
     observations and every counter (substeps and timeouts among them) must be those of the flights run to their end. The states
@@ -1198,7 +1198,7 @@ def test_sealed_fate_exit_books_exactly_what_the_full_flight_gives(torch, option
     missing racket contact, a wrong reward or a wrong substep count."""
     from tennisbot_rl_amd.stepper import BatchedEnv
     rng = np.random.default_rng(seed)
-    p = default_params()
+    p = default_params(**(over or {}))  # over: engine parameters OUTSIDE the exit's argument -- it must then stay off (and everything still match)
     pf = p.copy(); pf.flags |= F_AUTO_RESET
     ref = OracleBatch(pf, ENV_SWING, n, seed=5, precision="f32")
     ref.L.tbo_set_threads(ref.h, 16)
@@ -1223,7 +1223,7 @@ def test_sealed_fate_exit_books_exactly_what_the_full_flight_gives(torch, option
     ref_first = want[0]
     assert ref_first[2].all()
     late = ref.counters()
-    assert late[3] > n // 4 and late[0] > n // 50, late  # timeouts; racket contacts inside the fast-forward
+    assert late[3] > n // (4 if not over else 40) and (over or late[0] > n // 50), late  # timeouts; racket contacts inside the fast-forward
     want += [ref.step(a) for a in acts[1:]]
     results = {}
     for seal in (True, False):
@@ -1243,7 +1243,18 @@ def test_sealed_fate_exit_books_exactly_what_the_full_flight_gives(torch, option
         env.close()
     assert results[False][0] == 0
     booked, total = results[True]
-    assert booked > 0.3 * total, results  # the exit did fire: a good part of these flights' substeps were never run
+    if over:
+        assert booked == 0, results
+    else:
+        assert booked > 0.3 * total, results  # the exit did fire: a good part of these flights' substeps were never run
+
+
+@pytest.mark.parametrize("over", [dict(magnus_k=0.002), dict(racket_mass=0.005), dict(lin_damp_quad=0.1)], ids=["magnus", "stiff-racket-spring", "heavy-drag"])
+def test_sealed_fate_exit_stays_off_outside_its_argument(torch, over):
+    """the exit's argument needs no Magnus force (a spinning ball's lift can bring it back), (w dt)^2 <= 0.04 for the racket's
+    restoring spring and dt kd <= 0.2 at 1000 m/s for the drag (fate_sealed, seal_params_ok): with parameters beyond any of them
+    the pool runs every flight to its end -- nothing booked -- and every output still matches the oracle"""
+    test_sealed_fate_exit_books_exactly_what_the_full_flight_gives(torch, dict(ff_defer="all"), seed=77, n=4096, over=over)
 
 
 def thrown_at_racket_through_the_short_steps(torch, n, n_edges, options, step0=12, threads=16):
