@@ -113,32 +113,39 @@ def _fragment_indices(n_in, n_out, first_layer):
 def pack_policy(policy, out=None):
     """The blob `tb_policy_step` reads: pi tower layers, action head, vf tower layers, value head (each
     in MFMA fragment order, see _fragment_indices), then log_std padded to a multiple of 4 floats.
-    `out`: a preallocated device tensor to refresh in place (its address is baked into captured graphs)."""
+    `out`: a preallocated device tensor to refresh in place (its address is baked into captured graphs).
+    ONE gather: the parameters are concatenated as they lie in memory ([bias, weight (out x in) row-major] per layer, log_std,
+    one 0.0) and a cached index vector -- _fragment_indices composed with the weight's transpose -- picks the blob out of that
+    (two kernels per call; the per-layer cat / transpose / index form was ~40 launches, 0.2 ms of a 4.5 ms collect)."""
     import torch
     dev = policy.log_std.device
-    cache = getattr(policy, "_pack_index", None)
     layers = []
     for body, head in ((policy.policy_net, policy.action_net), (policy.value_net_body, policy.value_net)):
         layers += [m for m in body if isinstance(m, torch.nn.Linear)] + [head]
-    if cache is None or cache[0].device != dev:
-        cache, first = [], True
+    cache = getattr(policy, "_pack_index", None)
+    if cache is None or cache.device != dev:
         n_body = (len(layers) - 2) // 2
+        total = sum(m.out_features * (m.in_features + 1) for m in layers) + policy.log_std.numel()  # ... and the 0.0 lies at `total`
+        gidx, off = [], 0
         for li, m in enumerate(layers):
-            first = li % (n_body + 1) == 0
-            cache.append(torch.tensor(_fragment_indices(m.in_features, m.out_features, first), dtype=torch.long, device=dev))
+            n_in, n_out = m.in_features, m.out_features
+            for k in _fragment_indices(n_in, n_out, li % (n_body + 1) == 0):
+                if k < n_out:                      # bias
+                    gidx.append(off + k)
+                elif k < n_out + n_in * n_out:     # W^T[i][o] = weight[o][i]
+                    i, o = divmod(k - n_out, n_out)
+                    gidx.append(off + n_out + o * n_in + i)
+                else:
+                    gidx.append(total)
+            off += n_out * (n_in + 1)
+        gidx += [off + k for k in range(policy.log_std.numel())] + [total] * (-policy.log_std.numel() % 4)
+        cache = torch.tensor(gidx, dtype=torch.long, device=dev)
         policy._pack_index = cache
-    parts = []
     with torch.no_grad():
-        zero = torch.zeros(1, device=dev)
-        for m, idx in zip(layers, cache):
-            src = torch.cat([m.bias.detach().float(), m.weight.detach().float().t().reshape(-1), zero])
-            parts.append(src[idx])
-        parts.append(policy.log_std.detach().float())
-        parts.append(torch.zeros(-policy.log_std.numel() % 4, device=dev))
-        flat = torch.cat(parts)
-    if out is None:
-        return flat.contiguous()
-    out.copy_(flat)
+        src = torch.cat([t.detach().float().reshape(-1) for m in layers for t in (m.bias, m.weight)] + [policy.log_std.detach().float().reshape(-1), torch.zeros(1, device=dev)])
+        if out is None:
+            return src.index_select(0, cache)
+        torch.index_select(src, 0, cache, out=out)
     return out
 
 
@@ -193,6 +200,7 @@ class PPOTrainer:
             # (tb_policy_rollout) that is 43 launches + 43 fast-forwards per 1100 steps, nothing a graph would save
             self.use_graph = False
         self.num_timesteps = 0
+        self._aux_stream = None  # the collect's bookkeeping, beside the join (see _collect_fused)
         # fused=True: the policy runs inside the step kernel (tb_policy_step); the torch module is
         # then only the learner's view of the same weights, repacked once per rollout
         self.fused = bool(fused) and tuple(d["net_arch"]) == tuple((SWING_DEFAULTS if kind == ENV_SWING else TENNIS_DEFAULTS)["net_arch"])
@@ -228,13 +236,22 @@ class PPOTrainer:
             env.policy_step_ptrs(wp, cur, buf.actions[k].data_ptr(), self._raw_actions[k].data_ptr(), self.logps[k].data_ptr(),
                                  self.values[k].data_ptr(), obs_k.data_ptr(), buf.rewards[k].data_ptr(), buf.dones[k].data_ptr(), self.noise_seed)
             cur = obs_k.data_ptr()
-        # observations are final when the step kernels are; only terminal rewards still trickle in from
-        # the side streams -- so the bookkeeping below overlaps with the last fast-forward
-        self.obs_seq[1:].copy_(buf.obs[:-1])
-        last = buf.obs[self.n_steps - 1]
-        self.last_value.copy_(self.policy(last)[1])
-        self.obs_in.copy_(last)
+        # observations are final when the step kernels are; only terminal rewards are still missing. The join (in the pool form: ONE
+        # launch over every episode end of the rollout, ~0.5-0.8 ms of the main stream) and the bookkeeping -- a dozen small torch
+        # kernels -- run side by side: the bookkeeping on a stream of its own, forked behind the rollout kernels and joined at the end
+        t = self.torch
+        main = t.cuda.current_stream(self.device)
+        if self._aux_stream is None:
+            self._aux_stream = t.cuda.Stream(device=self.device)
+        aux = self._aux_stream
+        aux.wait_stream(main)
         env.flush()
+        with t.cuda.stream(aux):
+            self.obs_seq[1:].copy_(buf.obs[:-1])
+            last = buf.obs[self.n_steps - 1]
+            self.last_value.copy_(self.policy(last)[1])
+            self.obs_in.copy_(last)
+        main.wait_stream(aux)
 
     def _collect_body(self):
         t = self.torch
