@@ -1274,7 +1274,7 @@ TB_DEV int substep(const KParams& P, const float4* hull, Racket& rk, Ball& b, Ma
     // step kernels beside them than that gives back (702 -> 655 M env steps/s), and in the loop-free step kernels its ballot masks
     // cost SGPR spills at kernel start (-10 %)
     TB_LANES(4, need);        // [4] lanes that need the outline sweep, [5] wave-substeps with one
-    if constexpr (WIDE) {  // all 64 lanes are here, one edge each (the narrow policy rollout kernels: 16 envs and 48 dummies per env wave)
+    if constexpr (WIDE) {  // all 64 lanes are here (the policy rollout kernels' env wave: lanes without an env step a dummy) and share the sweeps, four queries at a time
       if (__any(need)) {
         const SweepOut so = outline_sweep_rows(hull, P.n_hull, need, ql.y, ql.z);
         if (need) hr = racket_finish<KIND == TB_ENV_TENNIS>(P, hull, rk, d, scale, ql, qax, so);
