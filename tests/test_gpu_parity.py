@@ -1188,7 +1188,7 @@ def test_fast_forward_with_balls_thrown_at_a_spinning_racket(torch, n, options):
 
 
 @pytest.mark.parametrize("options", [dict(ff_defer="all"), dict(ff_defer=True, ff_defer_margin=40)], ids=["pool", "stragglers"])
-def test_sealed_fate_exit_books_exactly_what_the_full_flight_gives(torch, options, seed=4321, n=8192, over=None):
+def test_sealed_fate_exit_books_exactly_what_the_full_flight_gives(torch, options, seed=4321, n=8192, over=None, off=False):
     """TbOptions.ff_seal: the pool leaves a flight whose ball has fallen below the court, out of the racket's reach for good, and books
     the substeps up to the 800-substep timeout instead of running them. The oracle has no such exit: rewards, done flags,
     observations and every counter (substeps and timeouts among them) must be those of the flights run to their end. The states
@@ -1198,7 +1198,7 @@ def test_sealed_fate_exit_books_exactly_what_the_full_flight_gives(torch, option
     missing racket contact, a wrong reward or a wrong substep count."""
     from tennisbot_rl_amd.stepper import BatchedEnv
     rng = np.random.default_rng(seed)
-    p = default_params(**(over or {}))  # over: engine parameters OUTSIDE the exit's argument -- it must then stay off (and everything still match)
+    p = default_params(**(over or {}))  # over: other engine parameters; off: they are OUTSIDE the exit's argument -- it must then stay off (and everything still match)
     pf = p.copy(); pf.flags |= F_AUTO_RESET
     ref = OracleBatch(pf, ENV_SWING, n, seed=5, precision="f32")
     ref.L.tbo_set_threads(ref.h, 16)
@@ -1243,10 +1243,19 @@ def test_sealed_fate_exit_books_exactly_what_the_full_flight_gives(torch, option
         env.close()
     assert results[False][0] == 0
     booked, total = results[True]
-    if over:
+    if off:
         assert booked == 0, results
     else:
         assert booked > 0.3 * total, results  # the exit did fire: a good part of these flights' substeps were never run
+
+
+@pytest.mark.parametrize("over", [dict(lin_damp=0.0, lin_damp_quad=0.0), dict(racket_mass=0.6, lin_damp_quad=0.0), dict(racket_mass=12.0, gravity=3.0), dict(lin_damp=0.5, lin_damp_quad=0.04)],
+                         ids=["no-drag", "light-racket", "heavy-racket-low-gravity", "thick-air"])
+def test_sealed_fate_exit_with_other_engine_parameters_inside_its_argument(torch, over):
+    """the oscillator bound of the exit's claim (2) against the engine itself, not against the recurrence it was derived on: an undamped racket
+    (its swing never decays), a light one (w dt = 0.04, near the limit's order), a heavy slow one under weak gravity (long flights, slow
+    falls), thick air -- the exit fires and every output is still that of the full flights"""
+    test_sealed_fate_exit_books_exactly_what_the_full_flight_gives(torch, dict(ff_defer="all"), seed=99, n=8192, over=over)
 
 
 @pytest.mark.parametrize("over", [dict(magnus_k=0.002), dict(racket_mass=0.005), dict(lin_damp_quad=0.1)], ids=["magnus", "stiff-racket-spring", "heavy-drag"])
@@ -1254,7 +1263,7 @@ def test_sealed_fate_exit_stays_off_outside_its_argument(torch, over):
     """the exit's argument needs no Magnus force (a spinning ball's lift can bring it back), (w dt)^2 <= 0.04 for the racket's
     restoring spring and dt kd <= 0.2 at 1000 m/s for the drag (fate_sealed, seal_params_ok): with parameters beyond any of them
     the pool runs every flight to its end -- nothing booked -- and every output still matches the oracle"""
-    test_sealed_fate_exit_books_exactly_what_the_full_flight_gives(torch, dict(ff_defer="all"), seed=77, n=4096, over=over)
+    test_sealed_fate_exit_books_exactly_what_the_full_flight_gives(torch, dict(ff_defer="all"), seed=77, n=4096, over=over, off=True)
 
 
 def thrown_at_racket_through_the_short_steps(torch, n, n_edges, options, step0=12, threads=16):
