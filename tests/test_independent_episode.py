@@ -230,6 +230,80 @@ def test_whole_episodes_match_a_third_implementation(seed, n):
     assert events["bonus"] > 0 and events["long"] > 0, events  # racket strikes during the short steps, and flights they lengthened
 
 
+def _claim_2(P, rk, bl, spawn):
+    """claim (2) of the pool's sealed-fate exit (csrc/tb_kernels.hpp, racket_cannot_reach), restated: on one horizontal axis the ball is
+    beyond the racket's reach and moving away, the racket's centre being a damped oscillator about its anchor whose amplitude stays under
+    1.25 sqrt(xi^2 + v^2 / w^2) + 0.05. Returns (axis, anchor, bound) or None."""
+    reach = f64(P.hull_bound_radius) + f64(P.hull_margin) + f64(P.ball_radius) + f64(P.contact_threshold) + 0.01
+    for ax, k in ((0, 50.0), (1, 2.0)):
+        w2 = k * f64(P.racket_inv_mass)
+        B = 1.25 * np.sqrt((rk[0][ax] - spawn[ax]) ** 2 + rk[2][ax] ** 2 / w2) + 0.05
+        d = bl[0][ax] - spawn[ax]
+        if (bl[1][ax] >= 0 and d - B > reach) or (bl[1][ax] <= 0 and -d - B > reach):
+            return ax, spawn[ax], B
+    return None
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_the_sealed_fate_argument_holds_substep_by_substep_on_the_third_implementation(seed):
+    """The pool kernels leave a flight once (1) its ball is under the court and falling and (2) the racket can never reach it again, and
+    book the substeps up to the 800-substep limit (TbOptions.ff_seal). The GPU tests check the outcome against the oracle's full
+    flights; this one checks the ARGUMENT itself, substep by substep, on the plain-Python env: from the first substep at which claim
+    (2) holds -- tested at EVERY substep here, not every 8th -- the racket never touches the ball again, its centre never leaves
+    anchor +- bound on that axis, the ball keeps moving away on it; and a flight for which (1) holds as well ends by the limit, at
+    step_count 801, with reward 0. States: rackets swinging at up to 8 m/s about their anchors, falling through the court (the
+    default contact set does not hold them), balls thrown past them, at them and away from them."""
+    sweeps = 8
+    P = default_params(flags=F_DEFAULT | F_AUTO_RESET, solver_iters=sweeps, solver_tol=0.0)
+    geo = Geometry(P)
+    rng = np.random.default_rng(seed)
+    top = max(f64(P.ground_half[2]), f64(P.goal_half_len), f64(P.net_half[2]))
+    sealed_flights = timeouts = late_contacts = 0
+    for i in range(14):
+        e = PySwingEnv(P, geo, seed, i, sweeps)
+        e.reset()
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        e.rk = [e.spawn + np.array([rng.uniform(-1.5, 1.5), rng.uniform(-3, 3), rng.uniform(-6, 3)]), q,
+                np.array([rng.uniform(-8, 8), rng.uniform(-4, 4), rng.uniform(-5, 2)]), rng.uniform(-9, 9, 3)]
+        u = rng.normal(size=3); u /= np.linalg.norm(u)
+        bp = e.rk[0] + u * rng.uniform(0.7, 4.0)
+        kind = i % 3  # thrown at where the racket will be / drifting beside it / flying anywhere
+        tof = rng.uniform(0.1, 1.2)
+        bv = (e.rk[0] + e.rk[2] * tof - bp) / tof if kind == 0 else e.rk[2] + rng.normal(scale=0.7, size=3) if kind == 1 else rng.normal(scale=12.0, size=3)
+        e.bl = [bp, bv, rng.uniform(-30, 30, 3)]
+        e.step_count, e.done = 26, False
+        Fp, held, fate, reward = (0.0, 0.0, 0.0), None, False, 0.0
+        while not e.done:  # the loop of swingracket_env.py:105-141, as in PySwingEnv.step
+            bits = e.substep(Fp, (0.0, 0.0, 0.0))
+            e.step_count += 1
+            if held is not None:
+                ax, anchor, bound = held
+                assert "racket" not in bits, (i, e.step_count, "the racket touched a ball it could not reach")
+                assert abs(e.rk[0][ax] - anchor) <= bound, (i, e.step_count, e.rk[0][ax] - anchor, bound)
+            elif "racket" in bits:
+                late_contacts += 1
+            if "court" in bits:
+                e.done = True; reward += e.moved_dist()
+            if "goal" in bits:
+                reward += e.moved_dist() + 50.0; e.done = True
+            if e.step_count > 800:
+                timeouts += not e.done
+                e.done = True
+            if fate:
+                assert not (bits & {"court", "goal"}) and reward == 0.0, (i, e.step_count, bits)
+            if not e.done:
+                if held is None and e.step_count >= 32:  # (the kernel's first test is at step 32: from its second loop substep on the restoring force acts)
+                    held = _claim_2(P, e.rk, e.bl, e.spawn)
+                    sealed_flights += held is not None
+                if held is not None and not fate:
+                    fate = bool(e.bl[0][2] + f64(P.ball_radius) + f64(P.contact_threshold) < -top - 1e-3 and e.bl[1][2] < 0)
+            c, sp = e.rk[0], e.spawn
+            Fp = (-50.0 * (c[0] - sp[0]), -2.0 * (c[1] - sp[1]), -2.0 * ((c[2] - sp[2]) - 4.0))
+        if fate:
+            assert e.step_count == 801 and reward == 0.0, (i, e.step_count, reward)
+    assert sealed_flights >= 6 and timeouts >= 3, (sealed_flights, timeouts, late_contacts)
+
+
 class PyTennisEnv:
     """Tennisbot-v0 for ONE env, written from tennisbot/envs/tennisbot_env.py:104-261 and objects.py:82-96"""
 
