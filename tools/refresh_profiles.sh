@@ -53,5 +53,6 @@ else
   cp $R/gpurun_out/r04_seal_ab.json $OUT/seal_ab.json
   python3 tools/diag/r04_policy_stamps.py 2>&1 | grep -v amdgpu.ids > $OUT/policy_stamps.txt || exit 1
   python3 tools/diag/r03_policy_census.py 2>&1 | grep -v amdgpu.ids > $OUT/policy_census.txt || exit 1
+  python3 tools/diag/r04_policy_ablate.py 2>&1 | grep -v amdgpu.ids > $OUT/policy_ablate.txt || exit 1
   grep -v amdgpu.ids $OUT/ppo_probe.log $OUT/collect_breakdown.log | cut -c1-600
 fi
